@@ -1,0 +1,322 @@
+"""Generate tests/golden/*.npz by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  Usage:  python oracle/make_golden.py [--ref /root/reference]
+
+What is committed is DATA ONLY: inputs, per-parameter scales, outputs and
+gradients.  Weights are not stored: each parameter is rebuilt as
+scale * oracle.detfill.unit_fill(shape, crc32(name)) on both sides.
+
+Third-party packages the reference imports but the image lacks (no network) are
+replaced by in-memory stand-ins below.  Only two of them touch arithmetic on the
+path: `tensorly.einsum` (-> torch.einsum; for factorization=None the reference
+issues a plain two-operand einsum, neuralop/models/spectral_convolution.py:31-36)
+and `tltorch.FactorizedTensor` (-> a dense complex parameter container; it only
+stores the weight, spectral_convolution.py:253-268).  Everything else is an empty
+placeholder so that `import neuralop` succeeds.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.detfill import fill_named  # noqa: E402
+
+
+# ----------------------------------------------------------------------------
+# stand-ins for absent third-party modules
+# ----------------------------------------------------------------------------
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, k):
+        return _Anything()
+
+
+class _Placeholder(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Anything
+
+
+class DenseComplexWeight(nn.Module):
+    """Dense-only stand-in for tltorch's ComplexDense FactorizedTensor: a complex
+    tensor stored as a real (.., 2) nn.Parameter."""
+    name = "ComplexDense"
+
+    def __init__(self, shape):
+        super().__init__()
+        self.shape = tuple(shape)
+        self.tensor = nn.Parameter(torch.zeros(*shape, 2))
+
+    @classmethod
+    def new(cls, shape, rank=None, factorization="ComplexDense", fixed_rank_modes=None, **kw):
+        if "dense" not in factorization.lower():
+            raise NotImplementedError("stand-in supports factorization=None only")
+        return cls(shape)
+
+    def normal_(self, mean=0.0, std=1.0):
+        with torch.no_grad():
+            self.tensor.normal_(mean, std)
+        return self
+
+    def to_tensor(self):
+        return torch.view_as_complex(self.tensor)
+
+    def __getitem__(self, idx):
+        return self.to_tensor()[idx]
+
+
+def install_standins():
+    tl = _Placeholder("tensorly")
+    tl.set_backend = lambda *_: None
+    tl.einsum = torch.einsum
+    tl.ndim = lambda t: t.dim()
+    plugins = _Placeholder("tensorly.plugins")
+    plugins.use_opt_einsum = lambda *_: None
+    tl.plugins = plugins
+    tlt = _Placeholder("tltorch")
+    ft = _Placeholder("tltorch.factorized_tensors")
+    core = _Placeholder("tltorch.factorized_tensors.core")
+    core.FactorizedTensor = DenseComplexWeight
+    tlt.FactorizedTensor = DenseComplexWeight
+    mods = {
+        "tensorly": tl, "tensorly.plugins": plugins,
+        "tltorch": tlt, "tltorch.factorized_tensors": ft,
+        "tltorch.factorized_tensors.core": core,
+        "tltorch.utils": _Placeholder("tltorch.utils"),
+    }
+    for name in ["torch_harmonics", "torch_harmonics.examples", "torchvision",
+                 "torchvision.transforms", "h5py", "zarr", "wandb", "configmypy",
+                 "mpi4py", "opt_einsum", "cv2", "imageio", "torchdiffeq", "pympler",
+                 "matlab", "matlab.engine"]:
+        mods.setdefault(name, _Placeholder(name))
+    for k, v in mods.items():
+        if k not in sys.modules:
+            sys.modules[k] = v
+
+
+# ----------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------
+def refill_parameters(model, std_override=None):
+    """Replace every parameter by scale * unit_fill(crc32(name)); scale = RMS of the
+    reference's own init (so magnitudes stay realistic).  Returns {name: scale}."""
+    scales = {}
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if prm.is_complex():
+                rms = float(torch.view_as_real(prm.detach()).pow(2).mean().sqrt())
+            else:
+                rms = float(prm.detach().float().pow(2).mean().sqrt()) if prm.numel() else 1.0
+            if not np.isfinite(rms) or rms == 0.0:
+                rms = 1.0
+            scale = float(np.float32(rms * 1.7))      # unit_fill has RMS 1/sqrt(3)
+            if std_override and name in std_override:
+                scale = std_override[name]
+            scales[name] = scale
+            if prm.is_complex():
+                v = fill_named(name, tuple(prm.shape), scale, complex_=True)
+            else:
+                v = fill_named(name, tuple(prm.shape), scale)
+            prm.copy_(torch.from_numpy(v))
+    return scales
+
+
+def input_fill(name, shape, scale=1.0):
+    return torch.from_numpy(fill_named("input:" + name, shape, scale))
+
+
+def grads_of(model):
+    out = {}
+    for name, prm in model.named_parameters():
+        g = prm.grad
+        if g is None:
+            continue
+        g = g.detach()
+        out[name] = (torch.view_as_real(g) if g.is_complex() else g).numpy().copy()
+    return out
+
+
+def save(path, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = np.asarray(vv)
+        else:
+            flat[k] = np.asarray(v.detach().numpy() if torch.is_tensor(v) else v)
+    np.savez_compressed(path, **flat)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ----------------------------------------------------------------------------
+# fixture generators
+# ----------------------------------------------------------------------------
+def gen_specconv_A(outdir):
+    from neuralop.models.spectral_convolution import FactorizedSpectralConv
+    cases = {
+        # name: (cin, cout, n_modes, spatial, n_layers, fft_norm, batch)
+        "A2d": (4, 6, (6, 8), (16, 20), 2, "forward", 3),
+        "A2d_ortho_odd": (3, 3, (4, 6), (12, 15), 1, "ortho", 2),
+        "A2d_backward": (5, 2, (8, 4), (8, 32), 1, "backward", 2),
+        "A3d": (3, 4, (4, 6, 4), (8, 10, 12), 2, "forward", 2),
+    }
+    for cname, (cin, cout, n_modes, sp, nl, norm, B) in cases.items():
+        torch.manual_seed(0)
+        conv = FactorizedSpectralConv(cin, cout, n_modes, n_layers=nl, fft_norm=norm,
+                                      factorization=None, implementation="factorized",
+                                      rank=1.0)
+        scales = refill_parameters(conv)
+        x = input_fill(cname + ".x", (B, cin, *sp)).requires_grad_(True)
+        dy = input_fill(cname + ".dy", (B, cout, *sp))
+        idx = nl - 1
+        y = conv(x, idx)
+        y.backward(dy)
+        save(os.path.join(outdir, f"specconv_{cname}.npz"),
+             x=x, dy=dy, y=y, dx=x.grad, grads=grads_of(conv), scales=scales,
+             meta=np.array([cin, cout, nl, idx, B, len(n_modes), *n_modes, *sp]),
+             fft_norm=np.array(norm))
+
+
+def gen_specconv_B(outdir):
+    from neuralop.models.rno import SpectralConv2d
+    for cname, (cin, cout, m1, m2, n, B) in {"B2d": (4, 5, 3, 5, 16, 3),
+                                             "B2d_full": (2, 2, 6, 7, 12, 2)}.items():
+        torch.manual_seed(0)
+        conv = SpectralConv2d(cin, cout, m1, m2)
+        scales = refill_parameters(conv)
+        x = input_fill(cname + ".x", (B, cin, n, n)).requires_grad_(True)
+        dy = input_fill(cname + ".dy", (B, cout, n, n))
+        y = conv(x)
+        y.backward(dy)
+        save(os.path.join(outdir, f"specconv_{cname}.npz"), x=x, dy=dy, y=y, dx=x.grad,
+             grads=grads_of(conv), scales=scales, meta=np.array([cin, cout, m1, m2, n, B]))
+
+
+def gen_specconv_C(outdir):
+    from libs.models.pino_models.basics import SpectralConv2d, SpectralConv3d
+    torch.manual_seed(0)
+    cin, cout, m1, m2, B = 4, 3, 3, 4, 2
+    conv = SpectralConv2d(cin, cout, m1, m2)
+    scales = refill_parameters(conv)
+    x = input_fill("C2d.x", (B, cin, 10, 16)).requires_grad_(True)
+    dy = input_fill("C2d.dy", (B, cout, 10, 16))
+    y = conv(x)
+    y.backward(dy)
+    save(os.path.join(outdir, "specconv_C2d.npz"), x=x, dy=dy, y=y, dx=x.grad,
+         grads=grads_of(conv), scales=scales, meta=np.array([cin, cout, m1, m2, 10, 16, B]))
+    # 3-D: regular; Nz/2+1 < modes3; T = 1 (PINObserverFullField, model_timestep 1)
+    for cname, (cin, cout, m1, m2, m3, sp, B) in {
+            "C3d": (3, 4, 2, 3, 3, (8, 8, 10), 2),
+            "C3d_shortz": (3, 3, 3, 2, 6, (8, 6, 6), 2),
+            "C3d_T1": (4, 4, 3, 3, 3, (8, 8, 1), 2)}.items():
+        torch.manual_seed(0)
+        conv = SpectralConv3d(cin, cout, m1, m2, m3)
+        scales = refill_parameters(conv)
+        x = input_fill(cname + ".x", (B, cin, *sp)).requires_grad_(True)
+        dy = input_fill(cname + ".dy", (B, cout, *sp))
+        y = conv(x)
+        y.backward(dy)
+        save(os.path.join(outdir, f"specconv_{cname}.npz"), x=x, dy=dy, y=y, dx=x.grad,
+             grads=grads_of(conv), scales=scales,
+             meta=np.array([cin, cout, m1, m2, m3, *sp, B]))
+
+
+def _lp_rel_sum(x, y):
+    from libs.utilities3 import LpLoss
+    return LpLoss(size_average=False)(x, y)
+
+
+def gen_fno_models(outdir):
+    from neuralop.models import FNO2d, FNO3d
+    cfgs = {
+        # name: (ctor, args, input shape, keep_all_grads)
+        "fno2d_cfg1": (FNO2d, (8, 8, 32), (4, 3, 64, 64), True),
+        "fno2d_cfg2small": (FNO2d, (12, 12, 64), (2, 3, 128, 128), False),
+        "fno3d_small": (FNO3d, (8, 8, 8, 32), (1, 3, 32, 32, 32), False),
+    }
+    for cname, (ctor, args, shp, keep_all) in cfgs.items():
+        torch.manual_seed(0)
+        model = ctor(*args, in_channels=3, out_channels=1)
+        scales = refill_parameters(model)
+        x = input_fill(cname + ".x", shp)
+        tgt = input_fill(cname + ".target", (shp[0], 1, *shp[2:]))
+        y = model(x)
+        loss = _lp_rel_sum(y, tgt)
+        loss.backward()
+        g = grads_of(model)
+        gnorm = {k: np.array([np.sqrt((v.astype(np.float64) ** 2).sum())]) for k, v in g.items()}
+        if not keep_all:
+            # keep small params whole, and a leading slab of the big spectral weights
+            g = {k: (v if v.size <= 20000 else v.reshape(-1)[:4096].copy()) for k, v in g.items()}
+        save(os.path.join(outdir, f"{cname}.npz"), x=x, target=tgt, y=y,
+             loss=np.array([float(loss.detach())]), grads=g, gnorm=gnorm, scales=scales,
+             shapes={k: np.array(v.shape) for k, v in model.state_dict().items()})
+
+
+def gen_observer_adam(outdir):
+    """Trainer counterpart of run_pde_observers.py:185-193 (FNO2dObserver, LpLoss sum,
+    Adam lr 1e-3 wd 1e-4): 3 steps, record the loss trajectory."""
+    from libs.models.fno_models import FNO2dObserver
+    torch.manual_seed(0)
+    model = FNO2dObserver(8, 8, 16)
+    scales = refill_parameters(model)
+    B, S = 4, 32
+    p_plane = input_fill("obs.p", (B, S, S, 1))
+    target = input_fill("obs.t", (B, S, S, 1))
+    mean = input_fill("obs.mean", (S, S), 0.3).numpy()
+    std = np.abs(input_fill("obs.std", (S, S), 0.5).numpy()) + 0.5
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    mean_t, std_t = torch.from_numpy(mean), torch.from_numpy(std)
+    losses, y0 = [], None
+    for step in range(3):
+        opt.zero_grad()
+        pred = model(p_plane, None)                       # (B,1,S,S)
+        pred = pred.reshape(B, S, S)
+        # NormalizerGivenMeanStd.cuda_decode (libs/utilities3.py:115-129): x*(std+eps)+mean
+        pd = pred * (std_t + 1e-5) + mean_t
+        td = target.reshape(B, S, S) * (std_t + 1e-5) + mean_t
+        loss = _lp_rel_sum(pd, td)
+        if step == 0:
+            y0 = pred.detach().clone()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    save(os.path.join(outdir, "observer_adam3.npz"), p_plane=p_plane, target=target,
+         mean=mean, std=std, y0=y0, losses=np.array(losses), scales=scales)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    install_standins()
+    sys.path.insert(0, args.ref)
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(8)
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam]
+    for g in gens:
+        if args.only and args.only not in g.__name__:
+            continue
+        print(g.__name__)
+        g(args.out)
+
+
+if __name__ == "__main__":
+    main()
