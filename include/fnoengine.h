@@ -1,0 +1,139 @@
+/* fnoengine C ABI - MI355X (gfx950) FNO spectral-convolution engine.
+ *
+ * Drop-in boundary for the hot path of neuraloperator/pde-policylearning
+ * (SURVEY.md section 8b).  The reference is pure Python/PyTorch, so "what its FFI
+ * would bind" is the set of torch-op sequences below; each entry point names the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no torch / C++ types.
+ *   - every pointer is DEVICE memory owned by the caller (activations NCHW /
+ *     NCDHW contiguous fp32, complex tensors interleaved (re, im) fp32) unless
+ *     stated otherwise.  The library owns only immutable twiddle tables inside
+ *     a plan (freed by *_plan_destroy).
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*), no
+ *     implicit synchronisation, no allocation inside forward / backward
+ *     (graph-capturable).
+ *   - return 0 on success, negative FNO_E* on failure; text via fno_last_error().
+ */
+#ifndef FNOENGINE_H
+#define FNOENGINE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNO_MAX_LAYERS 16
+#define FNO_VERSION 100
+
+enum { FNO_OK = 0, FNO_EINVAL = -1, FNO_EUNSUPPORTED = -2, FNO_EHIP = -3, FNO_ENOMEM = -4 };
+/* torch.fft `norm=` strings */
+enum { FNO_NORM_BACKWARD = 0, FNO_NORM_FORWARD = 1, FNO_NORM_ORTHO = 2 };
+
+int fno_version(void);
+const char* fno_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Standalone spectral convolution  y = irfftn(pad(W_c . rfftn(x)[corner_c])) (+ bias)
+ * Covers the reference's three dialects:
+ *   A  neuralop/models/spectral_convolution.py:303-347 (FactorizedSpectralConv, dense;
+ *      modes[d] = n_modes[d] // 2, norm FORWARD via FNO default tfno.py:129, bias)
+ *   B  neuralop/models/rno.py:60-77          (SpectralConv2d, modes as given, ORTHO)
+ *   C  libs/models/pino_models/basics.py:79-96, 114-143 (SpectralConv2d/3d, BACKWARD;
+ *      3-D: weight_last_extent = modes3, modes[2] = min(Nz/2+1, modes3))
+ * Corner weights are the reference's own parameter tensors, complex64 viewed as
+ * fp32 pairs, shape (Cin, Cout, modes[0], [modes[1],] weight_last_extent), in the
+ * canonical corner order (lo), (hi) in 2-D and (lo,lo), (lo,hi), (hi,lo), (hi,hi)
+ * over the two leading dims in 3-D.
+ * ---------------------------------------------------------------------- */
+typedef struct FnoSpecDesc {
+  int ndim;                /* 2 or 3 */
+  int Cin, Cout;
+  int dims[3];             /* spatial extents */
+  int modes[3];            /* kept extent per corner along each dim */
+  int weight_last_extent;  /* last-dim extent of the stored weights (>= modes[ndim-1]) */
+  int norm;                /* FNO_NORM_* */
+} FnoSpecDesc;
+
+typedef struct FnoSpecPlan FnoSpecPlan;
+int fno_spec_plan_create(const FnoSpecDesc* desc, FnoSpecPlan** out);
+void fno_spec_plan_destroy(FnoSpecPlan* plan);
+size_t fno_spec_workspace_bytes(const FnoSpecPlan* plan, int batch);
+size_t fno_spec_xhat_bytes(const FnoSpecPlan* plan, int batch);
+/* y = specconv(x) + bias.  xhat_save (fno_spec_xhat_bytes) receives the truncated
+ * spectrum of x, the only thing backward needs besides dy; may be NULL. */
+int fno_spec_forward(const FnoSpecPlan* plan, int batch, const float* x, const float* const* w_corners,
+                     const float* bias /*nullable (Cout)*/, float* y, float* xhat_save, void* ws, size_t ws_bytes,
+                     void* stream);
+/* autograd of the above: any of dx / dw_corners / dbias may be NULL. */
+int fno_spec_backward(const FnoSpecPlan* plan, int batch, const float* dy, const float* xhat_save,
+                      const float* const* w_corners, float* dx, float* const* dw_corners, float* dbias, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Whole-model fused path: neuralop.models.FNO on its default configuration
+ * (tfno.py:195-211: Lifting :11-20 -> n_layers x FNOBlocks.forward fno_block.py:123-170
+ * with fno_skip='linear', GELU gate `index < n_layers - index` :149 -> Projection :23-38).
+ * One fused kernel per block (skip 1x1 conv + last-dim inverse DFT + bias + gated GELU +
+ * last-dim forward DFT of the next block), activations stored pre-activation.
+ * ---------------------------------------------------------------------- */
+typedef struct FnoModelDesc {
+  int ndim;            /* 2 or 3 */
+  int Cin, C, Cout;    /* lifting in, hidden width, projection out */
+  int hidden_proj;     /* projection_channels (256) */
+  int n_layers;
+  int dims[3];
+  int modes[3];        /* kept per corner per dim = n_modes[d] // 2 (spectral_convolution.py:202-203) */
+  int norm;            /* FNO_NORM_* (FNO default: FORWARD) */
+  unsigned gelu_mask;  /* bit l set <=> GELU after block l (fno_block.py:149) */
+} FnoModelDesc;
+
+typedef struct FnoModelParams {       /* all fp32 device pointers, reference parameter layouts */
+  const float* lift_w;                /* lifting.fc.weight (C, Cin, 1..)  */
+  const float* lift_b;                /* lifting.fc.bias (C)              */
+  const float* skip_w[FNO_MAX_LAYERS];      /* fno_blocks.fno_skips.l.weight (C, C, 1..) */
+  const float* spec_w[FNO_MAX_LAYERS][4];   /* fno_blocks.convs.weight[2^(d-1) l + corner] (C, C, m.., 2) */
+  const float* spec_bias;             /* fno_blocks.convs.bias (L, C, 1..) or NULL */
+  const float* proj_w1;               /* projection.fc1.weight (hidden_proj, C, 1..) */
+  const float* proj_b1;
+  const float* proj_w2;               /* projection.fc2.weight (Cout, hidden_proj, 1..) */
+  const float* proj_b2;
+} FnoModelParams;
+
+typedef struct FnoModelGrads {        /* same shapes as the parameters; written, not accumulated */
+  float* lift_w;
+  float* lift_b;
+  float* skip_w[FNO_MAX_LAYERS];
+  float* spec_w[FNO_MAX_LAYERS][4];
+  float* spec_bias;
+  float* proj_w1;
+  float* proj_b1;
+  float* proj_w2;
+  float* proj_b2;
+} FnoModelGrads;
+
+typedef struct FnoModelPlan FnoModelPlan;
+int fno_model_plan_create(const FnoModelDesc* desc, FnoModelPlan** out);
+void fno_model_plan_destroy(FnoModelPlan* plan);
+size_t fno_model_workspace_bytes(const FnoModelPlan* plan, int batch);
+/* bytes of the forward->backward stash: (n_layers+1) pre-activation tensors +
+ * n_layers truncated spectra */
+size_t fno_model_saved_bytes(const FnoModelPlan* plan, int batch);
+int fno_model_forward(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x, float* y,
+                      void* saved /*nullable: inference*/, void* ws, size_t ws_bytes, void* stream);
+int fno_model_backward(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
+                       const float* dy, const void* saved, const FnoModelGrads* g, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* Names and average device time (ms, HIP events on `stream`) of the kernels launched
+ * by the last fno_model_* call made with profiling enabled; used by bench.py for the
+ * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */
+void fno_profile_enable(int on);
+int fno_profile_count(void);
+int fno_profile_get(int idx, const char** name, float* total_ms, int* launches);
+void fno_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

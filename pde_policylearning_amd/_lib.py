@@ -1,0 +1,111 @@
+"""ctypes binding of the fnoengine C ABI (include/fnoengine.h).
+
+The shared library is built in-tree by `python -m pde_policylearning_amd.build`
+(or __graft_entry__.build()) with hipcc for gfx950.  There is NO fallback: if
+the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfnoengine.so")
+
+FNO_MAX_LAYERS = 16
+NORM_CODES = {"backward": 0, None: 0, "forward": 1, "ortho": 2}
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class FnoSpecDesc(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("dims", C.c_int * 3), ("modes", C.c_int * 3),
+                ("weight_last_extent", C.c_int), ("norm", C.c_int)]
+
+
+class FnoModelDesc(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("Cin", C.c_int), ("C", C.c_int), ("Cout", C.c_int),
+                ("hidden_proj", C.c_int), ("n_layers", C.c_int),
+                ("dims", C.c_int * 3), ("modes", C.c_int * 3),
+                ("norm", C.c_int), ("gelu_mask", C.c_uint)]
+
+
+class FnoModelParams(C.Structure):
+    _fields_ = [("lift_w", C.c_void_p), ("lift_b", C.c_void_p),
+                ("skip_w", C.c_void_p * FNO_MAX_LAYERS),
+                ("spec_w", (C.c_void_p * 4) * FNO_MAX_LAYERS),
+                ("spec_bias", C.c_void_p),
+                ("proj_w1", C.c_void_p), ("proj_b1", C.c_void_p),
+                ("proj_w2", C.c_void_p), ("proj_b2", C.c_void_p)]
+
+
+FnoModelGrads = FnoModelParams   # same layout, mutable pointers
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"fnoengine: {LIB_PATH} not found. Build it with `python -m pde_policylearning_amd.build` "
+            "(needs hipcc; gfx950). There is no CPU / PyTorch fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.fno_version.restype = ci
+    L.fno_last_error.restype = C.c_char_p
+    L.fno_spec_plan_create.argtypes = [C.POINTER(FnoSpecDesc), C.POINTER(vp)]
+    L.fno_spec_plan_destroy.argtypes = [vp]
+    L.fno_spec_plan_destroy.restype = None
+    L.fno_spec_workspace_bytes.argtypes = [vp, ci]
+    L.fno_spec_workspace_bytes.restype = sz
+    L.fno_spec_xhat_bytes.argtypes = [vp, ci]
+    L.fno_spec_xhat_bytes.restype = sz
+    L.fno_spec_forward.argtypes = [vp, ci, vp, C.POINTER(vp), vp, vp, vp, vp, sz, vp]
+    L.fno_spec_backward.argtypes = [vp, ci, vp, vp, C.POINTER(vp), vp, C.POINTER(vp), vp, vp, sz, vp]
+    L.fno_model_plan_create.argtypes = [C.POINTER(FnoModelDesc), C.POINTER(vp)]
+    L.fno_model_plan_destroy.argtypes = [vp]
+    L.fno_model_plan_destroy.restype = None
+    L.fno_model_workspace_bytes.argtypes = [vp, ci]
+    L.fno_model_workspace_bytes.restype = sz
+    L.fno_model_saved_bytes.argtypes = [vp, ci]
+    L.fno_model_saved_bytes.restype = sz
+    L.fno_model_forward.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp, vp, sz, vp]
+    L.fno_model_backward.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp,
+                                     C.POINTER(FnoModelGrads), vp, sz, vp]
+    L.fno_profile_enable.argtypes = [ci]
+    L.fno_profile_enable.restype = None
+    L.fno_profile_reset.restype = None
+    L.fno_profile_count.restype = ci
+    L.fno_profile_get.argtypes = [ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(ci)]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().fno_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"fnoengine {what} failed (code {rc}): {msg}")
+
+
+EXPORTED_SYMBOLS = [
+    "fno_version", "fno_last_error",
+    "fno_spec_plan_create", "fno_spec_plan_destroy", "fno_spec_workspace_bytes", "fno_spec_xhat_bytes",
+    "fno_spec_forward", "fno_spec_backward",
+    "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",
+    "fno_model_forward", "fno_model_backward",
+    "fno_profile_enable", "fno_profile_count", "fno_profile_get", "fno_profile_reset",
+]
+
+
+def profile_summary():
+    """[(kernel name, total ms, launches)] recorded since the last reset (profiling on)."""
+    L = lib()
+    out = []
+    for i in range(L.fno_profile_count()):
+        name, ms, n = C.c_char_p(), C.c_float(), C.c_int()
+        L.fno_profile_get(i, C.byref(name), C.byref(ms), C.byref(n))
+        out.append((name.value.decode(), float(ms.value), int(n.value)))
+    return out

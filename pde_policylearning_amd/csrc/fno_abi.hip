@@ -1,0 +1,736 @@
+// fnoengine C-ABI implementation: plans (twiddle tables), workspace carving and the
+// kernel sequences for the standalone spectral convolution and the fused FNO model.
+// Host-side only orchestration; every kernel is hand-written HIP for gfx950.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fnoengine.h"
+#include "k_block_bwd.h"
+#include "k_pointwise.h"
+#include "k_projection.h"
+#include "k_spectral_mid.h"
+
+// --------------------------------------------------------------------------
+// errors
+// --------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(FNO_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int fno_version(void) { return FNO_VERSION; }
+extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
+
+// --------------------------------------------------------------------------
+// optional per-kernel timing (HIP events on the launch stream)
+// --------------------------------------------------------------------------
+struct ProfRec { std::string name; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+struct ProfAgg { std::string name; float ms; int n; };
+static std::vector<ProfAgg> g_agg;
+
+extern "C" void fno_profile_enable(int on) { g_prof = on != 0; }
+extern "C" void fno_profile_reset(void) {
+  for (auto& r : g_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  g_recs.clear();
+  g_agg.clear();
+}
+static void prof_aggregate() {
+  if (g_recs.empty()) return;
+  std::map<std::string, size_t> idx;
+  for (auto& r : g_recs) {
+    hipEventSynchronize(r.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    auto it = idx.find(r.name);
+    if (it == idx.end()) { idx[r.name] = g_agg.size(); g_agg.push_back({r.name, ms, 1}); }
+    else { g_agg[it->second].ms += ms; g_agg[it->second].n += 1; }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_recs.clear();
+}
+extern "C" int fno_profile_count(void) { prof_aggregate(); return (int)g_agg.size(); }
+extern "C" int fno_profile_get(int i, const char** name, float* total_ms, int* launches) {
+  prof_aggregate();
+  if (i < 0 || i >= (int)g_agg.size()) return FNO_EINVAL;
+  *name = g_agg[i].name.c_str();
+  *total_ms = g_agg[i].ms;
+  *launches = g_agg[i].n;
+  return FNO_OK;
+}
+
+template <typename... KArgs, typename... Args>
+static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                  Args... args) {
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return FNO_OK;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(FNO_EHIP, "%s: set LDS %zu: %s", name, lds, hipGetErrorString(e));
+  }
+  ProfRec rec;
+  if (g_prof) {
+    rec.name = name;
+    hipEventCreate(&rec.a);
+    hipEventCreate(&rec.b);
+    hipEventRecord(rec.a, st);
+  }
+  hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<KArgs>(args)...);
+  hipError_t e = hipGetLastError();
+  if (g_prof) { hipEventRecord(rec.b, st); g_recs.push_back(rec); }
+  if (e != hipSuccess) return fail(FNO_EHIP, "launch %s: %s", name, hipGetErrorString(e));
+  return FNO_OK;
+}
+#define LAUNCHCHK(expr) do { int rc_ = (expr); if (rc_ != FNO_OK) return rc_; } while (0)
+
+// --------------------------------------------------------------------------
+// geometry + tables shared by both plan kinds
+// --------------------------------------------------------------------------
+struct Geom {
+  int ndim, nlead;
+  int dims[3];
+  int modes[3];
+  int W, P, PW;
+  int Klead[2];   // 2*modes on the leading dims
+  int Klast, J, NJ;
+  int Ktot;
+  int wl_stride;
+  double s_f, s_i;
+};
+
+struct Tables {
+  float* tfwd_f = nullptr;   // (16*NJ, W)  cos / -sin
+  float* tfwd_b = nullptr;   // same, gamma-weighted (transform of gradients)
+  float* tinv_f = nullptr;   // (J, W) gamma * s_i * (cos, -sin)
+  float* tinv_b = nullptr;   // (J, W) s_f * (cos, -sin)
+  float2* tw_fwd_sf[2] = {nullptr, nullptr};  // leading dim d: (Klead, N) e^{-i}, d==0 scaled by s_f
+  float2* tw_fwd_si[2] = {nullptr, nullptr};  // d==0 scaled by s_i (gradient direction)
+  float2* tw_inv[2] = {nullptr, nullptr};     // (N, Klead) e^{+i}
+  std::vector<void*> owned;
+  void release() { for (void* p : owned) hipFree(p); owned.clear(); }
+};
+
+static int upload(Tables& t, const void* host, size_t bytes, void** dev) {
+  HIPCHK(hipMalloc(dev, bytes));
+  t.owned.push_back(*dev);
+  HIPCHK(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+  return FNO_OK;
+}
+
+static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int wl_stride, int norm) {
+  if (ndim != 2 && ndim != 3) return fail(FNO_EUNSUPPORTED, "ndim=%d (2 or 3 supported)", ndim);
+  g.ndim = ndim;
+  g.nlead = ndim - 1;
+  g.PW = 1;
+  for (int d = 0; d < ndim; ++d) {
+    g.dims[d] = dims[d];
+    g.modes[d] = modes[d];
+    if (dims[d] < 1 || modes[d] < 1) return fail(FNO_EINVAL, "dims/modes must be >= 1");
+    g.PW *= dims[d];
+  }
+  g.W = dims[ndim - 1];
+  g.P = g.PW / g.W;
+  g.Klast = modes[ndim - 1];
+  if (g.Klast > g.W / 2 + 1) return fail(FNO_EINVAL, "modes[last]=%d exceeds W/2+1=%d", g.Klast, g.W / 2 + 1);
+  g.Ktot = g.Klast;
+  for (int d = 0; d < g.nlead; ++d) {
+    if (2 * modes[d] > dims[d])
+      return fail(FNO_EUNSUPPORTED, "overlapping corners: 2*modes[%d]=%d > dims=%d", d, 2 * modes[d], dims[d]);
+    g.Klead[d] = 2 * modes[d];
+    g.Ktot *= g.Klead[d];
+  }
+  g.J = 2 * g.Klast;
+  g.NJ = (g.J + 15) / 16;
+  g.wl_stride = wl_stride > 0 ? wl_stride : g.Klast;
+  if (g.wl_stride < g.Klast) return fail(FNO_EINVAL, "weight_last_extent < modes[last]");
+  const double n = (double)g.PW;
+  if (norm == FNO_NORM_FORWARD) { g.s_f = 1.0 / n; g.s_i = 1.0; }
+  else if (norm == FNO_NORM_ORTHO) { g.s_f = 1.0 / std::sqrt(n); g.s_i = g.s_f; }
+  else if (norm == FNO_NORM_BACKWARD) { g.s_f = 1.0; g.s_i = 1.0 / n; }
+  else return fail(FNO_EINVAL, "norm=%d", norm);
+  return FNO_OK;
+}
+
+static int make_tables(const Geom& g, Tables& t) {
+  const double PI2 = 6.283185307179586476925286766559;
+  const int W = g.W, J = g.J;
+  std::vector<float> ff((size_t)16 * g.NJ * W, 0.f), fb((size_t)16 * g.NJ * W, 0.f);
+  std::vector<float> vf((size_t)J * W), vb((size_t)J * W);
+  for (int k2 = 0; k2 < g.Klast; ++k2) {
+    const double gamma = (k2 == 0 || (W % 2 == 0 && k2 == W / 2)) ? 1.0 : 2.0;
+    for (int w = 0; w < W; ++w) {
+      const double ang = PI2 * (double)((long long)k2 * w % W) / W;
+      const double c = std::cos(ang), s = std::sin(ang);
+      ff[(size_t)(2 * k2) * W + w] = (float)c;
+      ff[(size_t)(2 * k2 + 1) * W + w] = (float)(-s);
+      fb[(size_t)(2 * k2) * W + w] = (float)(gamma * c);
+      fb[(size_t)(2 * k2 + 1) * W + w] = (float)(-gamma * s);
+      vf[(size_t)(2 * k2) * W + w] = (float)(gamma * g.s_i * c);
+      vf[(size_t)(2 * k2 + 1) * W + w] = (float)(-gamma * g.s_i * s);
+      vb[(size_t)(2 * k2) * W + w] = (float)(g.s_f * c);
+      vb[(size_t)(2 * k2 + 1) * W + w] = (float)(-g.s_f * s);
+    }
+  }
+  int rc;
+  if ((rc = upload(t, ff.data(), ff.size() * 4, (void**)&t.tfwd_f))) return rc;
+  if ((rc = upload(t, fb.data(), fb.size() * 4, (void**)&t.tfwd_b))) return rc;
+  if ((rc = upload(t, vf.data(), vf.size() * 4, (void**)&t.tinv_f))) return rc;
+  if ((rc = upload(t, vb.data(), vb.size() * 4, (void**)&t.tinv_b))) return rc;
+  for (int d = 0; d < g.nlead; ++d) {
+    const int N = g.dims[d], K = g.Klead[d], m = g.modes[d];
+    std::vector<float2> a((size_t)K * N), b((size_t)K * N), inv((size_t)N * K);
+    for (int r = 0; r < K; ++r) {
+      const int freq = r < m ? r : N - 2 * m + r;
+      for (int n = 0; n < N; ++n) {
+        const double ang = PI2 * (double)((long long)freq * n % N) / N;
+        const double c = std::cos(ang), s = std::sin(ang);
+        const double sa = d == 0 ? g.s_f : 1.0, sb = d == 0 ? g.s_i : 1.0;
+        a[(size_t)r * N + n] = make_float2((float)(sa * c), (float)(-sa * s));
+        b[(size_t)r * N + n] = make_float2((float)(sb * c), (float)(-sb * s));
+        inv[(size_t)n * K + r] = make_float2((float)c, (float)s);
+      }
+    }
+    if ((rc = upload(t, a.data(), a.size() * 8, (void**)&t.tw_fwd_sf[d]))) return rc;
+    if ((rc = upload(t, b.data(), b.size() * 8, (void**)&t.tw_fwd_si[d]))) return rc;
+    if ((rc = upload(t, inv.data(), inv.size() * 8, (void**)&t.tw_inv[d]))) return rc;
+  }
+  return FNO_OK;
+}
+
+// workspace bump allocator (256-B aligned pieces)
+struct Carver {
+  char* base; size_t cap, off = 0; bool ok = true;
+  Carver(void* b, size_t c) : base((char*)b), cap(c) {}
+  template <typename T> T* take(size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (!base || off + bytes > cap) { ok = false; off += bytes; return nullptr; }
+    T* p = (T*)(base + off);
+    off += bytes;
+    return p;
+  }
+};
+
+static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
+  ModeMap mm;
+  mm.nlead = g.nlead;
+  for (int d = 0; d < 3; ++d) { mm.K[d] = 1; mm.m[d] = 1; }
+  for (int d = 0; d < g.nlead; ++d) { mm.K[d] = g.Klead[d]; mm.m[d] = g.modes[d]; }
+  mm.K[g.nlead] = g.Klast;
+  mm.m[g.nlead] = g.Klast;
+  mm.wl_stride = g.wl_stride;
+  mm.Cin = Cin; mm.Cout = Cout; mm.Ktot = g.Ktot;
+  return mm;
+}
+
+
+static int axis_pass(hipStream_t st, const float* in, float* out, const float2* tw, int outer, int n_in, int n_out,
+                     int inner) {
+  if (outer > 65535 || n_out > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d,%d)", outer, n_out);
+  dim3 grid((inner + 255) / 256, n_out, outer);
+  return launch("k_axis_pass", k_axis_pass, grid, dim3(256), 0, st, (const float2*)in, (float2*)out, tw, n_in, n_out,
+                inner);
+}
+
+// forward-direction passes over the leading dims: x1 [B][lead..][Klast][C] -> hat [B][K..][Klast][C]
+static int lead_forward(hipStream_t st, const Geom& g, const Tables& t, bool grad_dir, int B, int C, const float* x1,
+                        float* tmp, float* hat) {
+  const float2* tw0 = grad_dir ? t.tw_fwd_si[0] : t.tw_fwd_sf[0];
+  if (g.nlead == 1) return axis_pass(st, x1, hat, tw0, B, g.dims[0], g.Klead[0], g.Klast * C);
+  LAUNCHCHK(axis_pass(st, x1, tmp, t.tw_fwd_sf[1], B * g.dims[0], g.dims[1], g.Klead[1], g.Klast * C));
+  return axis_pass(st, tmp, hat, tw0, B, g.dims[0], g.Klead[0], g.Klead[1] * g.Klast * C);
+}
+// inverse passes: hat [B][K..][Klast][C] -> z [B][lead..][Klast][C]
+static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, int C, const float* hat, float* tmp,
+                        float* z) {
+  if (g.nlead == 1) return axis_pass(st, hat, z, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klast * C);
+  LAUNCHCHK(axis_pass(st, hat, tmp, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klead[1] * g.Klast * C));
+  return axis_pass(st, tmp, z, t.tw_inv[1], B * g.dims[0], g.Klead[1], g.dims[1], g.Klast * C);
+}
+
+static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
+                     int conj_w) {
+  if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  const int nb = 256 / Cout;
+  dim3 grid(Ktot, (B + nb - 1) / nb);
+  return launch("k_mode_gemm", k_mode_gemm, grid, dim3(256), 0, st, (const float2*)x, (const float2*)w, (float2*)out, B,
+                Ktot, Cin, Cout, conj_w);
+}
+static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout) {
+  if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  const int ni = 256 / Cout;
+  dim3 grid(Ktot, (Cin + ni - 1) / ni);
+  return launch("k_mode_gemm_dw", k_mode_gemm_dw, grid, dim3(256), 0, st, (const float2*)x, (const float2*)g,
+                (float2*)dw, B, Ktot, Cin, Cout);
+}
+static int pack_w(hipStream_t st, const Geom& g, int Cin, int Cout, const float* const* corners, float* wp, float* wpt) {
+  CornerPtrs cp;
+  for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (const float2*)corners[c] : nullptr;
+  const ModeMap mm = make_modemap(g, Cin, Cout);
+  const size_t n = (size_t)g.Ktot * Cin * Cout;
+  return launch("k_pack_w", k_pack_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cp, (float2*)wp,
+                (float2*)wpt, mm);
+}
+static int unpack_dw(hipStream_t st, const Geom& g, int Cin, int Cout, const float* dwp, float* const* dcorners) {
+  CornerPtrsMut cp;
+  for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (float2*)dcorners[c] : nullptr;
+  const ModeMap mm = make_modemap(g, Cin, Cout);
+  size_t per = (size_t)g.modes[0] * g.wl_stride;
+  if (g.nlead == 2) per *= g.modes[1];
+  const size_t n = (size_t)(1 << g.nlead) * Cin * Cout * per;
+  return launch("k_unpack_dw", k_unpack_dw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float2*)dwp,
+                cp, mm);
+}
+static int reduce_slabs(hipStream_t st, const float* part, float* out, int nslab, int rows, int ncols, int ld_in,
+                        int ld_out) {
+  const int n = rows * ncols;
+  return launch("k_reduce_slabs", k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, st, part, out, nslab, n,
+                ld_out, ncols, ld_in);
+}
+
+// ==========================================================================
+// standalone spectral convolution
+// ==========================================================================
+struct FnoSpecPlan {
+  FnoSpecDesc d;
+  Geom g;
+  Tables t;
+};
+
+extern "C" int fno_spec_plan_create(const FnoSpecDesc* d, FnoSpecPlan** out) {
+  if (!d || !out) return fail(FNO_EINVAL, "null argument");
+  FnoSpecPlan* p = new FnoSpecPlan();
+  p->d = *d;
+  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, d->weight_last_extent, d->norm);
+  if (rc == FNO_OK && (d->Cin < 1 || d->Cout < 1 || d->Cin > 256 || d->Cout > 256))
+    rc = fail(FNO_EUNSUPPORTED, "channels must be in [1, 256]");
+  if (rc == FNO_OK) {
+    const size_t lds1 = (size_t)std::max(d->Cin, d->Cout) * (p->g.W + 1) * 4;
+    if (lds1 > 160 * 1024) rc = fail(FNO_EUNSUPPORTED, "row tile C*(W+1)*4=%zu exceeds LDS", lds1);
+  }
+  if (rc == FNO_OK) rc = make_tables(p->g, p->t);
+  if (rc != FNO_OK) { p->t.release(); delete p; return rc; }
+  *out = p;
+  return FNO_OK;
+}
+extern "C" void fno_spec_plan_destroy(FnoSpecPlan* p) {
+  if (!p) return;
+  p->t.release();
+  delete p;
+}
+
+struct SpecWs {
+  float *x1, *tmp, *hat_in, *hat_out, *z, *wp, *wpt, *dwp, *dbpart;
+  size_t total;
+};
+static SpecWs carve_spec(const FnoSpecPlan* p, int B, void* ws, size_t cap, bool* ok) {
+  const Geom& g = p->g;
+  const int Cm = std::max(p->d.Cin, p->d.Cout);
+  Carver c(ws, cap);
+  SpecWs w;
+  const size_t n_x1 = (size_t)B * g.P * g.Klast * Cm * 2;
+  const size_t n_hat = (size_t)B * g.Ktot * Cm * 2;
+  const size_t n_tmp = g.nlead == 2 ? (size_t)B * g.dims[0] * g.Klead[1] * g.Klast * Cm * 2 : 1;
+  const size_t n_wp = (size_t)g.Ktot * p->d.Cin * p->d.Cout * 2;
+  w.x1 = c.take<float>(n_x1);
+  w.tmp = c.take<float>(n_tmp);
+  w.hat_in = c.take<float>(n_hat);
+  w.hat_out = c.take<float>(n_hat);
+  w.z = c.take<float>(n_x1);
+  w.wp = c.take<float>(n_wp);
+  w.wpt = c.take<float>(n_wp);
+  w.dwp = c.take<float>(n_wp);
+  w.dbpart = c.take<float>((size_t)64 * Cm);
+  w.total = c.off;
+  if (ok) *ok = c.ok;
+  return w;
+}
+extern "C" size_t fno_spec_workspace_bytes(const FnoSpecPlan* p, int B) {
+  return carve_spec(p, B, nullptr, 0, nullptr).total;
+}
+extern "C" size_t fno_spec_xhat_bytes(const FnoSpecPlan* p, int B) {
+  return (size_t)B * p->g.Ktot * p->d.Cin * 2 * sizeof(float);
+}
+
+extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, const float* const* wc, const float* bias,
+                                float* y, float* xhat_save, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !x || !wc || !y || B < 1) return fail(FNO_EINVAL, "fno_spec_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const int Cin = p->d.Cin, Cout = p->d.Cout;
+  bool ok;
+  SpecWs w = carve_spec(p, B, ws, ws_bytes, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  float* hat = xhat_save ? xhat_save : w.hat_in;
+  LAUNCHCHK(launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)Cin * (g.W + 1) * 4, st, x,
+                   (float2*)w.x1, (const float*)p->t.tfwd_f, Cin, g.P, g.W, g.Klast));
+  LAUNCHCHK(lead_forward(st, g, p->t, false, B, Cin, w.x1, w.tmp, hat));
+  LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
+  LAUNCHCHK(mode_gemm(st, hat, w.wp, w.hat_out, B, g.Ktot, Cin, Cout, 0));
+  LAUNCHCHK(lead_inverse(st, g, p->t, B, Cout, w.hat_out, w.tmp, w.z));
+  LAUNCHCHK(launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * Cout * 8, st,
+                   (const float2*)w.z, y, (const float*)p->t.tinv_f, bias, Cout, g.P, g.W, g.Klast));
+  return FNO_OK;
+}
+
+extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, const float* xhat, const float* const* wc,
+                                 float* dx, float* const* dwc, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !dy || B < 1) return fail(FNO_EINVAL, "fno_spec_backward: bad argument");
+  if (dwc && !xhat) return fail(FNO_EINVAL, "weight gradients need the saved spectrum");
+  if (dx && !wc) return fail(FNO_EINVAL, "input gradient needs the weights");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const int Cin = p->d.Cin, Cout = p->d.Cout;
+  bool ok;
+  SpecWs w = carve_spec(p, B, ws, ws_bytes, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  if (dbias) {
+    LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, Cout), dim3(256), 0, st, dy, w.dbpart, B, Cout, g.PW));
+    LAUNCHCHK(reduce_slabs(st, w.dbpart, dbias, 64, 1, Cout, Cout, Cout));
+  }
+  if (!dx && !dwc) return FNO_OK;
+  LAUNCHCHK(launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)Cout * (g.W + 1) * 4, st, dy,
+                   (float2*)w.x1, (const float*)p->t.tfwd_b, Cout, g.P, g.W, g.Klast));
+  LAUNCHCHK(lead_forward(st, g, p->t, true, B, Cout, w.x1, w.tmp, w.hat_out));   // G
+  if (dwc) {
+    LAUNCHCHK(mode_gemm_dw(st, xhat, w.hat_out, w.dwp, B, g.Ktot, Cin, Cout));
+    LAUNCHCHK(unpack_dw(st, g, Cin, Cout, w.dwp, dwc));
+  }
+  if (dx) {
+    LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
+    LAUNCHCHK(mode_gemm(st, w.hat_out, w.wpt, w.hat_in, B, g.Ktot, Cout, Cin, 1));   // GX
+    LAUNCHCHK(lead_inverse(st, g, p->t, B, Cin, w.hat_in, w.tmp, w.z));
+    LAUNCHCHK(launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * Cin * 8, st,
+                     (const float2*)w.z, dx, (const float*)p->t.tinv_b, (const float*)nullptr, Cin, g.P, g.W, g.Klast));
+  }
+  return FNO_OK;
+}
+
+// ==========================================================================
+// fused FNO model
+// ==========================================================================
+struct FnoModelPlan {
+  FnoModelDesc d;
+  Geom g;
+  Tables t;
+  int NPX;      // pixels per workgroup tile (128 or 256)
+  int ncu;      // compute units of the device the plan was made on
+};
+
+static const int kHID = 256;
+
+extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) {
+  if (!d || !out) return fail(FNO_EINVAL, "null argument");
+  if (d->n_layers < 1 || d->n_layers > FNO_MAX_LAYERS) return fail(FNO_EINVAL, "n_layers=%d", d->n_layers);
+  if (d->C != 32 && d->C != 64) return fail(FNO_EUNSUPPORTED, "fused path supports hidden width 32 or 64 (got %d)", d->C);
+  if (d->Cin < 1 || d->Cin > 4) return fail(FNO_EUNSUPPORTED, "fused path supports 1..4 input channels (got %d)", d->Cin);
+  if (d->Cout < 1 || d->Cout > PROJ_MAXCO) return fail(FNO_EUNSUPPORTED, "fused path supports 1..%d output channels", PROJ_MAXCO);
+  if (d->hidden_proj != kHID) return fail(FNO_EUNSUPPORTED, "fused path supports projection_channels=256 (got %d)", d->hidden_proj);
+  FnoModelPlan* p = new FnoModelPlan();
+  p->d = *d;
+  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, 0, d->norm);
+  if (rc == FNO_OK) {
+    const int W = p->g.W;
+    if (W % 32 != 0 || W > 256) rc = fail(FNO_EUNSUPPORTED, "fused path needs last dim %% 32 == 0 and <= 256 (got %d)", W);
+    else {
+      p->NPX = W > 128 ? 256 : 128;
+      if (p->NPX % W != 0 || p->g.PW % p->NPX != 0)
+        rc = fail(FNO_EUNSUPPORTED, "plane of %d pixels (W=%d) does not tile by %d", p->g.PW, W, p->NPX);
+    }
+    if (rc == FNO_OK && p->g.NJ > 4) rc = fail(FNO_EUNSUPPORTED, "too many last-dim modes (%d)", p->g.Klast);
+  }
+  if (rc == FNO_OK) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      rc = fail(FNO_EHIP, "no HIP device");
+    else p->ncu = prop.multiProcessorCount;
+  }
+  if (rc == FNO_OK) rc = make_tables(p->g, p->t);
+  if (rc != FNO_OK) { p->t.release(); delete p; return rc; }
+  *out = p;
+  return FNO_OK;
+}
+extern "C" void fno_model_plan_destroy(FnoModelPlan* p) {
+  if (!p) return;
+  p->t.release();
+  delete p;
+}
+
+struct ModelSizes {
+  size_t n_act, n_x1, n_tmp, n_hat, n_wp;
+  int ntiles, tiles_per_plane, grid;
+};
+static ModelSizes model_sizes(const FnoModelPlan* p, int B) {
+  const Geom& g = p->g;
+  const int C = p->d.C;
+  ModelSizes s;
+  s.n_act = (size_t)B * C * g.PW;
+  s.n_x1 = (size_t)B * g.P * g.Klast * C * 2;
+  s.n_tmp = g.nlead == 2 ? (size_t)B * g.dims[0] * g.Klead[1] * g.Klast * C * 2 : 1;
+  s.n_hat = (size_t)B * g.Ktot * C * 2;
+  s.n_wp = (size_t)g.Ktot * C * C * 2;
+  s.tiles_per_plane = g.PW / p->NPX;
+  s.ntiles = B * s.tiles_per_plane;
+  s.grid = std::min(s.ntiles, 2 * p->ncu);
+  return s;
+}
+
+struct ModelWs {
+  float *x1, *tmp, *hat, *ohat, *z, *wp, *wpt, *w1p;
+  // backward only
+  float *ga, *gb, *dwp, *dw_part, *db_part, *dwl_part, *dw1_part, *db1_part, *dw2_part, *db2_part;
+  size_t total;
+};
+static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, bool backward, bool* ok) {
+  const ModelSizes s = model_sizes(p, B);
+  const int C = p->d.C;
+  Carver c(ws, cap);
+  ModelWs w;
+  memset(&w, 0, sizeof(w));
+  w.x1 = c.take<float>(s.n_x1);
+  w.tmp = c.take<float>(s.n_tmp);
+  w.hat = c.take<float>(s.n_hat);
+  w.ohat = c.take<float>(s.n_hat);
+  w.z = c.take<float>(s.n_x1);
+  w.wp = c.take<float>(s.n_wp);
+  w.wpt = c.take<float>(s.n_wp);
+  w.w1p = c.take<float>((size_t)kHID * C);
+  if (backward) {
+    w.ga = c.take<float>(s.n_act);
+    w.gb = c.take<float>(s.n_act);
+    w.dwp = c.take<float>(s.n_wp);
+    w.dw_part = c.take<float>((size_t)s.grid * 8 * C * C);
+    w.db_part = c.take<float>((size_t)s.grid * C);
+    w.dwl_part = c.take<float>((size_t)s.grid * C * 16);
+    w.dw1_part = c.take<float>((size_t)s.grid * 8 * kHID * C);
+    w.db1_part = c.take<float>((size_t)s.grid * kHID);
+    w.dw2_part = c.take<float>((size_t)s.grid * PROJ_MAXCO * kHID);
+    w.db2_part = c.take<float>((size_t)64 * PROJ_MAXCO);
+  }
+  w.total = c.off;
+  if (ok) *ok = c.ok;
+  return w;
+}
+extern "C" size_t fno_model_workspace_bytes(const FnoModelPlan* p, int B) {
+  return carve_model(p, B, nullptr, 0, true, nullptr).total;
+}
+extern "C" size_t fno_model_saved_bytes(const FnoModelPlan* p, int B) {
+  const ModelSizes s = model_sizes(p, B);
+  return ((size_t)(p->d.n_layers + 1) * s.n_act + (size_t)p->d.n_layers * s.n_hat) * sizeof(float);
+}
+
+// ---- templated launch dispatch ---------------------------------------------
+template <int CIN, int COUT>
+static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  const size_t rows = std::max((CIN + 1) & ~1, COUT);
+  if (p->NPX == 128)
+    return launch("k_pw_fwd", k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3(256), rows * 132 * 4, st, a);
+  return launch("k_pw_fwd", k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3(512), rows * 260 * 4, st, a);
+}
+static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  const int C = p->d.C;
+  switch (p->d.Cin * 100 + C) {
+    case 132: return launch_pw<1, 32>(p, st, grid, a);
+    case 232: return launch_pw<2, 32>(p, st, grid, a);
+    case 332: return launch_pw<3, 32>(p, st, grid, a);
+    case 432: return launch_pw<4, 32>(p, st, grid, a);
+    case 164: return launch_pw<1, 64>(p, st, grid, a);
+    case 264: return launch_pw<2, 64>(p, st, grid, a);
+    case 364: return launch_pw<3, 64>(p, st, grid, a);
+    case 464: return launch_pw<4, 64>(p, st, grid, a);
+  }
+  return fail(FNO_EUNSUPPORTED, "lifting %d -> %d", p->d.Cin, C);
+}
+static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a);
+  return launch_pw<64, 64>(p, st, grid, a);
+}
+template <int C>
+static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
+  if (p->NPX == 128)
+    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(256), (size_t)(2 * C + 8) * 132 * 4, st, a);
+  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(512), (size_t)(2 * C + 8) * 260 * 4, st, a);
+}
+static int launch_bbwd(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
+  return p->d.C == 32 ? launch_bbwd_c<32>(p, st, grid, a) : launch_bbwd_c<64>(p, st, grid, a);
+}
+static int bbwd_ksplit(const FnoModelPlan* p) {
+  const int nw = p->NPX / 32, tiles = (p->d.C / 32) * (p->d.C / 32);
+  return nw >= tiles ? nw / tiles : 1;
+}
+template <int C>
+static int launch_pfwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
+  const size_t extra = (size_t)(kHID + PROJ_MAXCO * kHID) * 4;
+  if (p->NPX == 128)
+    return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128>, dim3(grid), dim3(256), (size_t)C * 132 * 4 + extra, st, a);
+  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 256>, dim3(grid), dim3(512), (size_t)C * 260 * 4 + extra, st, a);
+}
+template <int C>
+static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  const size_t extra = (size_t)(kHID + PROJ_MAXCO * kHID) * 4;
+  if (p->NPX == 128)
+    return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128>, dim3(grid), dim3(256),
+                  (size_t)(C + 64) * 132 * 4 + PROJ_MAXCO * 128 * 4 + extra, st, a);
+  return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256>, dim3(grid), dim3(512),
+                (size_t)(C + 64) * 260 * 4 + PROJ_MAXCO * 256 * 4 + extra, st, a);
+}
+static int pbwd_ksplit(const FnoModelPlan* p) {
+  const int nw = p->NPX / 32, tiles = 2 * (p->d.C / 32);
+  return nw >= tiles ? nw / tiles : 1;
+}
+
+// spectral middle of one block: x1 -> (hat) -> ohat -> z
+static int spectral_mid_fwd(const FnoModelPlan* p, hipStream_t st, int B, const ModelWs& w, const float* const* corners,
+                            float* hat) {
+  const Geom& g = p->g;
+  const int C = p->d.C;
+  LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));
+  LAUNCHCHK(pack_w(st, g, C, C, corners, w.wp, w.wpt));
+  LAUNCHCHK(mode_gemm(st, hat, w.wp, w.ohat, B, g.Ktot, C, C, 0));
+  return lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z);
+}
+
+extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x, float* y,
+                                 void* saved, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !prm || !x || !y || B < 1) return fail(FNO_EINVAL, "fno_model_forward: bad argument");
+  if (!saved) return fail(FNO_EINVAL, "fno_model_forward: `saved` buffer required (fno_model_saved_bytes)");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const FnoModelDesc& d = p->d;
+  const int C = d.C, L = d.n_layers;
+  const ModelSizes s = model_sizes(p, B);
+  bool ok;
+  ModelWs w = carve_model(p, B, ws, ws_bytes, false, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  float* u = (float*)saved;                                 // u[l] = u + l * n_act
+  float* hats = u + (size_t)(L + 1) * s.n_act;              // hats[l] = hats + l * n_hat
+
+  // lifting (tfno.py:19-20) + row DFT of its output
+  PwFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
+  a.u = u; a.x1 = w.x1; a.tfwd = p->t.tfwd_f;
+  a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
+  a.act_in = 0; a.act_out = 0;
+  a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+  LAUNCHCHK(launch_lift(p, st, s.grid, a));
+
+  for (int l = 0; l < L; ++l) {
+    LAUNCHCHK(spectral_mid_fwd(p, st, B, w, prm->spec_w[l], hats + (size_t)l * s.n_hat));
+    memset(&a, 0, sizeof(a));
+    a.x = u + (size_t)l * s.n_act;
+    a.w = prm->skip_w[l];
+    a.bias = prm->spec_bias ? prm->spec_bias + (size_t)l * C : nullptr;
+    a.z = w.z; a.tinv = p->t.tinv_f;
+    a.u = u + (size_t)(l + 1) * s.n_act;
+    a.x1 = (l + 1 < L) ? w.x1 : nullptr;
+    a.tfwd = p->t.tfwd_f;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
+    a.act_out = (d.gelu_mask >> l) & 1u;
+    a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    LAUNCHCHK(launch_block(p, st, s.grid, a));
+  }
+
+  // projection (tfno.py:34-38)
+  LAUNCHCHK(launch("k_pack_w1", k_pack_w1, dim3((kHID * C + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.w1p, kHID, C));
+  ProjFwdArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.x = u + (size_t)L * s.n_act; pa.w1p = w.w1p; pa.b1 = prm->proj_b1; pa.w2 = prm->proj_w2; pa.b2 = prm->proj_b2;
+  pa.y = y; pa.PW = g.PW; pa.CO = d.Cout; pa.act_in = (d.gelu_mask >> (L - 1)) & 1u;
+  pa.tiles_per_plane = s.tiles_per_plane; pa.ntiles = s.ntiles;
+  if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, s.grid, pa));
+  else LAUNCHCHK(launch_pfwd_c<64>(p, st, s.grid, pa));
+  return FNO_OK;
+}
+
+extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                                  const float* dy, const void* saved, const FnoModelGrads* gr, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (!p || !prm || !x || !dy || !saved || !gr || B < 1) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const FnoModelDesc& d = p->d;
+  const int C = d.C, L = d.n_layers;
+  const ModelSizes s = model_sizes(p, B);
+  bool ok;
+  ModelWs w = carve_model(p, B, ws, ws_bytes, true, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  const float* u = (const float*)saved;
+  const float* hats = u + (size_t)(L + 1) * s.n_act;
+
+  // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
+  LAUNCHCHK(launch("k_pack_w1", k_pack_w1, dim3((kHID * C + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.w1p, kHID, C));
+  ProjBwdArgs pb;
+  memset(&pb, 0, sizeof(pb));
+  pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.w1p = w.w1p; pb.b1 = prm->proj_b1;
+  pb.w2 = prm->proj_w2; pb.gout = w.ga; pb.x1g = w.x1; pb.tfwd = p->t.tfwd_b;
+  pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;
+  pb.PW = g.PW; pb.W = g.W; pb.P = g.P; pb.K2out = g.Klast; pb.NJ = g.NJ; pb.CO = d.Cout;
+  pb.act_in = (d.gelu_mask >> (L - 1)) & 1u;
+  pb.tiles_per_plane = s.tiles_per_plane; pb.ntiles = s.ntiles;
+  if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
+  else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
+  const int ks1 = pbwd_ksplit(p);
+  LAUNCHCHK(reduce_slabs(st, w.dw1_part, gr->proj_w1, s.grid * ks1, kHID, C, C, C));
+  LAUNCHCHK(reduce_slabs(st, w.db1_part, gr->proj_b1, s.grid, 1, kHID, kHID, kHID));
+  LAUNCHCHK(reduce_slabs(st, w.dw2_part, gr->proj_w2, s.grid, d.Cout, kHID, kHID, kHID));
+  LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
+  LAUNCHCHK(reduce_slabs(st, w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout));
+
+  float* gcur = w.ga;   // dL/du_{l+1}
+  float* gnext = w.gb;
+  const int ks = bbwd_ksplit(p);
+  for (int l = L - 1; l >= 0; --l) {
+    // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
+    LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
+    LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, w.ohat, w.dwp, B, g.Ktot, C, C));
+    LAUNCHCHK(unpack_dw(st, g, C, C, w.dwp, gr->spec_w[l]));
+    LAUNCHCHK(pack_w(st, g, C, C, prm->spec_w[l], w.wp, w.wpt));
+    LAUNCHCHK(mode_gemm(st, w.ohat, w.wpt, w.hat, B, g.Ktot, C, C, 1));
+    LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
+
+    BlkBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = gcur; a.uin = u + (size_t)l * s.n_act; a.w = prm->skip_w[l];
+    a.zg = w.z; a.tinv = p->t.tinv_b;
+    a.gout = (l > 0) ? gnext : nullptr;
+    a.x1g = (l > 0) ? w.x1 : nullptr;
+    a.tfwd = p->t.tfwd_b;
+    a.dw_part = w.dw_part; a.db_part = w.db_part;
+    a.xin = (l == 0) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
+    a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
+    LAUNCHCHK(reduce_slabs(st, w.dw_part, gr->skip_w[l], s.grid * ks, C, C, C, C));
+    if (gr->spec_bias)
+      LAUNCHCHK(reduce_slabs(st, w.db_part, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C));
+    if (l == 0) {
+      LAUNCHCHK(reduce_slabs(st, w.dwl_part, gr->lift_w, s.grid, C, d.Cin, 16, d.Cin));
+      LAUNCHCHK(reduce_slabs(st, w.dwl_part + d.Cin, gr->lift_b, s.grid, C, 1, 16, 1));
+    }
+    float* t = gcur; gcur = gnext; gnext = t;
+  }
+  return FNO_OK;
+}

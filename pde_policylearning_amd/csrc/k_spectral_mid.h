@@ -1,0 +1,226 @@
+// The "spectral middle": everything that happens on the truncated spectrum.
+// All tensors here are O(kept modes) small (<= ~10 % of one activation), complex
+// interleaved (float2), batch-major:  [B][K1][(K2)][Klast][C].
+//
+//   k_axis_pass        truncated DFT / inverse DFT along one leading axis, as a
+//                      table-driven complex mat-vec: out[o][r][q] = sum_n tw[r][n] in[o][n][q]
+//   k_pack_w / k_unpack_dw   reference corner-weight layout (Cin,Cout,m..) <-> mode-major [K][Cin][Cout]
+//   k_mode_gemm_*      the complex contraction 'bixy,ioxy->boxy' over kept modes and its two adjoints
+//                      (neuralop/models/spectral_convolution.py:15-36, rno.py:51-58, basics.py:14-24)
+//   k_rowdft_generic / k_rowidft_generic   last-dim passes for shapes the fused MFMA
+//                      kernels do not cover (W not a multiple of 32, odd channel counts)
+#pragma once
+#include "fno_dev.h"
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_axis_pass(const float2* __restrict__ in, float2* __restrict__ out,
+                                                   const float2* __restrict__ tw, int n_in, int n_out, int inner) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y, o = blockIdx.z;
+  if (q >= inner) return;
+  const float2* src = in + (size_t)o * n_in * inner + q;
+  const float2* t = tw + (size_t)r * n_in;
+  float sr = 0.f, si = 0.f;
+#pragma unroll 4
+  for (int n = 0; n < n_in; ++n) {
+    const float2 v = src[(size_t)n * inner];
+    const float2 w = t[n];
+    sr = fmaf(w.x, v.x, sr); sr = fmaf(-w.y, v.y, sr);
+    si = fmaf(w.x, v.y, si); si = fmaf(w.y, v.x, si);
+  }
+  out[((size_t)o * n_out + r) * inner + q] = make_float2(sr, si);
+}
+
+// ---------------------------------------------------------------------------
+struct ModeMap {
+  int nlead;         // number of leading (two-sided) dims: 1 (2-D) or 2 (3-D)
+  int K[3];          // kept extent per dim: 2*m for leading dims, m_last for the last
+  int m[3];          // per-corner extent per dim
+  int wl_stride;     // last-dim extent of the stored corner weight (>= m[last]; dialect C 3-D: modes3)
+  int Cin, Cout, Ktot;
+};
+
+struct CornerPtrs { const float2* p[4]; };
+struct CornerPtrsMut { float2* p[4]; };
+
+__device__ __forceinline__ void mode_decompose(const ModeMap& mm, int k, int& corner, size_t& loc) {
+  // k = (k1 * K[1] + k2) * K[2] + k3 (3-D) or k1 * K[1] + klast (2-D)
+  int kl, k1, k2 = 0;
+  if (mm.nlead == 2) { kl = k % mm.K[2]; k2 = (k / mm.K[2]) % mm.K[1]; k1 = k / (mm.K[2] * mm.K[1]); }
+  else { kl = k % mm.K[1]; k1 = k / mm.K[1]; }
+  const int h1 = k1 >= mm.m[0];
+  const int l1 = k1 - h1 * mm.m[0];
+  if (mm.nlead == 2) {
+    const int h2 = k2 >= mm.m[1];
+    const int l2 = k2 - h2 * mm.m[1];
+    corner = 2 * h1 + h2;
+    loc = ((size_t)l1 * mm.m[1] + l2) * mm.wl_stride + kl;
+  } else {
+    corner = h1;
+    loc = (size_t)l1 * mm.wl_stride + kl;
+  }
+}
+
+// Wp[k][i][o] and Wpt[k][o][i] from corner tensors (Cin, Cout, m1, [m2], wl_stride)
+__global__ void k_pack_w(CornerPtrs cw, float2* __restrict__ wp, float2* __restrict__ wpt, ModeMap mm) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)mm.Ktot * mm.Cin * mm.Cout;
+  if (e >= n) return;
+  const int o = e % mm.Cout;
+  const int i = (e / mm.Cout) % mm.Cin;
+  const int k = e / ((size_t)mm.Cout * mm.Cin);
+  int corner; size_t loc;
+  mode_decompose(mm, k, corner, loc);
+  size_t per = (size_t)mm.m[0] * mm.wl_stride;
+  if (mm.nlead == 2) per *= mm.m[1];
+  const float2 v = cw.p[corner][((size_t)i * mm.Cout + o) * per + loc];
+  wp[e] = v;
+  wpt[((size_t)k * mm.Cout + o) * mm.Cin + i] = v;
+}
+
+// corner-layout gradients from mode-major dWp[k][i][o]; entries of the stored
+// weight outside the kept last-dim range get zero gradient
+__global__ void k_unpack_dw(const float2* __restrict__ dwp, CornerPtrsMut gw, ModeMap mm) {
+  size_t per_c = (size_t)mm.m[0] * mm.wl_stride;
+  if (mm.nlead == 2) per_c *= mm.m[1];
+  const int ncorner = 1 << mm.nlead;
+  const size_t n = (size_t)ncorner * mm.Cin * mm.Cout * per_c;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const size_t loc = e % per_c;
+  const int o = (e / per_c) % mm.Cout;
+  const int i = (e / (per_c * mm.Cout)) % mm.Cin;
+  const int corner = e / (per_c * mm.Cout * mm.Cin);
+  const int kl = loc % mm.wl_stride;
+  float2 v = make_float2(0.f, 0.f);
+  const int klast_kept = mm.K[mm.nlead];
+  if (kl < klast_kept) {
+    int k;
+    if (mm.nlead == 2) {
+      const int l2 = (loc / mm.wl_stride) % mm.m[1];
+      const int l1 = loc / ((size_t)mm.wl_stride * mm.m[1]);
+      const int k1 = l1 + (corner >> 1) * mm.m[0], k2 = l2 + (corner & 1) * mm.m[1];
+      k = (k1 * mm.K[1] + k2) * mm.K[2] + kl;
+    } else {
+      const int l1 = loc / mm.wl_stride;
+      k = (l1 + corner * mm.m[0]) * mm.K[1] + kl;
+    }
+    v = dwp[((size_t)k * mm.Cin + i) * mm.Cout + o];
+  }
+  gw.p[corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
+}
+
+// ---------------------------------------------------------------------------
+// O[b][k][o] = sum_i X[b][k][i] * W[k][i][o]          (conj_w: use conj(W), for the adjoint
+// with wpt[k][o][i] passed as w and Cin/Cout swapped)
+__global__ void __launch_bounds__(256) k_mode_gemm(const float2* __restrict__ x, const float2* __restrict__ w,
+                                                   float2* __restrict__ out, int B, int Ktot, int Cin, int Cout,
+                                                   int conj_w) {
+  const int o = threadIdx.x % Cout;
+  const int bs = threadIdx.x / Cout;
+  const int nb = blockDim.x / Cout;
+  const int k = blockIdx.x;
+  const int b = blockIdx.y * nb + bs;
+  if (b >= B || bs >= nb) return;
+  const float2* xr = x + ((size_t)b * Ktot + k) * Cin;
+  const float2* wr = w + (size_t)k * Cin * Cout + o;
+  float sr = 0.f, si = 0.f;
+  const float sg = conj_w ? -1.f : 1.f;
+#pragma unroll 4
+  for (int i = 0; i < Cin; ++i) {
+    const float2 a = xr[i];
+    float2 ww = wr[(size_t)i * Cout];
+    ww.y *= sg;
+    sr = fmaf(a.x, ww.x, sr); sr = fmaf(-a.y, ww.y, sr);
+    si = fmaf(a.x, ww.y, si); si = fmaf(a.y, ww.x, si);
+  }
+  out[((size_t)b * Ktot + k) * Cout + o] = make_float2(sr, si);
+}
+
+// dW[k][i][o] = sum_b conj(X[b][k][i]) * G[b][k][o]
+__global__ void __launch_bounds__(256) k_mode_gemm_dw(const float2* __restrict__ x, const float2* __restrict__ g,
+                                                      float2* __restrict__ dw, int B, int Ktot, int Cin, int Cout) {
+  const int o = threadIdx.x % Cout;
+  const int is = threadIdx.x / Cout;
+  const int ni = blockDim.x / Cout;
+  const int k = blockIdx.x;
+  const int i = blockIdx.y * ni + is;
+  if (i >= Cin || is >= ni) return;
+  float sr = 0.f, si = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float2 a = x[((size_t)b * Ktot + k) * Cin + i];
+    const float2 gg = g[((size_t)b * Ktot + k) * Cout + o];
+    // conj(a) * g
+    sr = fmaf(a.x, gg.x, sr); sr = fmaf(a.y, gg.y, sr);
+    si = fmaf(a.x, gg.y, si); si = fmaf(-a.y, gg.x, si);
+  }
+  dw[((size_t)k * Cin + i) * Cout + o] = make_float2(sr, si);
+}
+
+// ---------------------------------------------------------------------------
+// generic last-dim passes (any W, any C): one workgroup per (b, plane-row)
+// x (B, C, P, W) -> x1 (B, P, K2, C, 2);  tfwd (>= 2*K2 rows, W)
+__global__ void __launch_bounds__(256) k_rowdft_generic(const float* __restrict__ x, float2* __restrict__ x1,
+                                                        const float* __restrict__ tfwd, int C, int P, int W, int K2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // C x (W+1)
+  const int row = blockIdx.x;  // b * P + p
+  const int b = row / P, p = row % P;
+  const int pitch = W + 1;
+  for (int idx = threadIdx.x; idx < C * W; idx += blockDim.x) {
+    const int c = idx / W, w = idx % W;
+    smem[c * pitch + w] = x[(((size_t)b * C + c) * P + p) * W + w];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C * K2; idx += blockDim.x) {
+    const int c = idx % C, k2 = idx / C;
+    const float* tr = tfwd + (size_t)(2 * k2) * W;
+    const float* ti = tr + W;
+    float sr = 0.f, si = 0.f;
+    for (int w = 0; w < W; ++w) {
+      const float v = smem[c * pitch + w];
+      sr = fmaf(v, tr[w], sr);
+      si = fmaf(v, ti[w], si);
+    }
+    x1[((size_t)row * K2 + k2) * C + c] = make_float2(sr, si);
+  }
+}
+
+// z (B, P, K2, C, 2) -> y (B, C, P, W) (+ bias[c]);  tinv (2*K2, W)
+__global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restrict__ z, float* __restrict__ y,
+                                                         const float* __restrict__ tinv,
+                                                         const float* __restrict__ bias, int C, int P, int W,
+                                                         int K2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // K2 x C x 2
+  const int row = blockIdx.x;
+  const int b = row / P, p = row % P;
+  const float* zr = reinterpret_cast<const float*>(z + (size_t)row * K2 * C);
+  for (int idx = threadIdx.x; idx < K2 * C * 2; idx += blockDim.x) smem[idx] = zr[idx];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C * W; idx += blockDim.x) {
+    const int c = idx / W, w = idx % W;
+    float s = bias ? bias[c] : 0.f;
+    for (int k2 = 0; k2 < K2; ++k2) {
+      s = fmaf(smem[(k2 * C + c) * 2], tinv[(size_t)(2 * k2) * W + w], s);
+      s = fmaf(smem[(k2 * C + c) * 2 + 1], tinv[(size_t)(2 * k2 + 1) * W + w], s);
+    }
+    y[(((size_t)b * C + c) * P + p) * W + w] = s;
+  }
+}
+
+// dbias[c] partials: sum over (b, pixels) of dy (B, C, PW) -> part[blk][c]
+__global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ dy, float* __restrict__ part, int B,
+                                                      int C, int PW) {
+  // grid = (nchunk, C); block sums its chunk of (b, px) for channel c
+  const int c = blockIdx.y;
+  const size_t n = (size_t)B * PW;
+  float s = 0.f;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = e / PW, p = e % PW;
+    s += dy[(b * C + c) * PW + p];
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)blockIdx.x * C + c] = sh[0] + sh[1] + sh[2] + sh[3];
+}

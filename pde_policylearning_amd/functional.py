@@ -1,0 +1,230 @@
+"""torch.autograd bridges onto the fnoengine C ABI.
+
+PyTorch is plumbing here: it owns device memory (inputs, outputs, workspace, the
+forward->backward stash) and the stream; all arithmetic happens in the HIP library.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_spec_plans = {}
+_model_plans = {}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"fnoengine: `{name}` must live on the GPU (got {t.device}); "
+                           "the engine has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"fnoengine: `{name}` must be float32 (got {t.dtype})")
+
+
+def _bytes(n, device):
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------
+# standalone spectral convolution
+# ----------------------------------------------------------------------------
+def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device):
+    key = (ndim, cin, cout, tuple(dims), tuple(modes), weight_last_extent, norm, device.index)
+    plan = _spec_plans.get(key)
+    if plan is None:
+        d = _lib.FnoSpecDesc()
+        d.ndim, d.Cin, d.Cout = ndim, cin, cout
+        for i in range(ndim):
+            d.dims[i], d.modes[i] = int(dims[i]), int(modes[i])
+        d.weight_last_extent = int(weight_last_extent)
+        d.norm = _lib.NORM_CODES[norm]
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().fno_spec_plan_create(C.byref(d), C.byref(h)), "spec_plan_create")
+        plan = h
+        _spec_plans[key] = plan
+    return plan
+
+
+class _SpectralConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, modes, norm, weight_last_extent, *weights):
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        ws_list = [w.contiguous() for w in weights]          # real views (.., 2)
+        for w in ws_list:
+            _require_cuda(w, "weight")
+        B, cin = x.shape[0], x.shape[1]
+        dims = tuple(x.shape[2:])
+        ndim = len(dims)
+        cout = ws_list[0].shape[1]
+        L = _lib.lib()
+        plan = spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, x.device)
+        y = torch.empty((B, cout) + dims, dtype=torch.float32, device=x.device)
+        xhat = _bytes(L.fno_spec_xhat_bytes(plan, B), x.device)
+        nws = L.fno_spec_workspace_bytes(plan, B)
+        ws = _bytes(nws, x.device)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_list] + [0] * (4 - len(ws_list)))
+        b = bias.contiguous() if bias is not None else None
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_spec_forward(plan, B, _ptr(x), wp, _ptr(b), _ptr(y), _ptr(xhat), _ptr(ws), nws,
+                                          _stream()), "spec_forward")
+        ctx.plan, ctx.B, ctx.has_bias = plan, B, bias is not None
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(xhat, *ws_list)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, *ws_list = ctx.saved_tensors
+        dy = dy.contiguous()
+        L = _lib.lib()
+        need_dx = ctx.needs_input_grad[0]
+        need_db = ctx.has_bias and ctx.needs_input_grad[1]
+        need_dw = any(ctx.needs_input_grad[5:])
+        dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy.device) if need_dx else None
+        dws = [torch.empty_like(w) for w in ws_list] if need_dw else None
+        db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device) if need_db else None
+        nws = L.fno_spec_workspace_bytes(ctx.plan, ctx.B)
+        ws = _bytes(nws, dy.device)
+        wp = (C.c_void_p * 4)(*[w.data_ptr() for w in ws_list] + [0] * (4 - len(ws_list)))
+        dwp = (C.c_void_p * 4)(*[w.data_ptr() for w in dws] + [0] * (4 - len(dws))) if need_dw else None
+        with torch.cuda.device(dy.device):
+            _lib.check(L.fno_spec_backward(ctx.plan, ctx.B, _ptr(dy), _ptr(xhat), wp, _ptr(dx),
+                                           dwp, _ptr(db), _ptr(ws), nws, _stream()), "spec_backward")
+        return (dx, db, None, None, None) + (tuple(dws) if need_dw else (None,) * len(ws_list))
+
+
+def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=None):
+    """y = irfftn(pad(W_c . rfftn(x)[corner_c]), s=x.shape[2:]) (+ bias[None, :, None..]).
+
+    weights: corner tensors in canonical order, real (Cin, Cout, m.., 2) or complex.
+    modes:   kept extent per corner along each dim.
+    """
+    ws = [torch.view_as_real(w) if w.is_complex() else w for w in weights]
+    wle = int(weight_last_extent) if weight_last_extent is not None else int(ws[0].shape[-2])
+    b = bias.reshape(-1) if bias is not None else None
+    return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, *ws)
+
+
+# ----------------------------------------------------------------------------
+# fused FNO model
+# ----------------------------------------------------------------------------
+def model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gelu_mask, device):
+    key = (ndim, cin, c, cout, hidden_proj, n_layers, tuple(dims), tuple(modes), norm, gelu_mask, device.index)
+    plan = _model_plans.get(key)
+    if plan is None:
+        d = _lib.FnoModelDesc()
+        d.ndim, d.Cin, d.C, d.Cout = ndim, cin, c, cout
+        d.hidden_proj, d.n_layers = hidden_proj, n_layers
+        for i in range(ndim):
+            d.dims[i], d.modes[i] = int(dims[i]), int(modes[i])
+        d.norm = _lib.NORM_CODES[norm]
+        d.gelu_mask = gelu_mask
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().fno_model_plan_create(C.byref(d), C.byref(h)), "model_plan_create")
+        plan = h
+        _model_plans[key] = plan
+    return plan
+
+
+def _fill_params(struct, n_layers, ncorner, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2):
+    struct.lift_w, struct.lift_b = lift_w.data_ptr(), lift_b.data_ptr()
+    for l in range(n_layers):
+        struct.skip_w[l] = skip_ws[l].data_ptr()
+        for c in range(ncorner):
+            struct.spec_w[l][c] = spec_ws[l * ncorner + c].data_ptr()
+    struct.spec_bias = spec_bias.data_ptr() if spec_bias is not None else 0
+    struct.proj_w1, struct.proj_b1 = w1.data_ptr(), b1.data_ptr()
+    struct.proj_w2, struct.proj_b2 = w2.data_ptr(), b2.data_ptr()
+
+
+class _FNOModelFn(torch.autograd.Function):
+    """Whole FNO forward/backward in the HIP engine.  Tensor arguments, in order:
+    x, lift_w, lift_b, spec_bias (or None), w1, b1, w2, b2, skip_w[0..L), spec_w[0..L*ncorner)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *rest):
+        n_layers, modes, norm, gelu_mask = cfg
+        _require_cuda(x, "x")
+        if x.requires_grad:
+            raise RuntimeError("fnoengine fused FNO: gradient w.r.t. the input field is not produced "
+                               "(parameter gradients only); detach the input")
+        x = x.contiguous()
+        dims = tuple(x.shape[2:])
+        ndim = len(dims)
+        ncorner = 2 ** (ndim - 1)
+        skip_ws = [t.contiguous() for t in rest[:n_layers]]
+        spec_ws = [t.contiguous() for t in rest[n_layers:]]
+        assert len(spec_ws) == n_layers * ncorner
+        tensors = [lift_w, lift_b, w1, b1, w2, b2] + skip_ws + spec_ws + ([spec_bias] if spec_bias is not None else [])
+        for t in tensors:
+            _require_cuda(t, "parameter")
+        lift_w, lift_b, w1, b1, w2, b2 = [t.contiguous() for t in (lift_w, lift_b, w1, b1, w2, b2)]
+        sb = spec_bias.contiguous() if spec_bias is not None else None
+        B, cin = x.shape[0], x.shape[1]
+        c, cout, hid = lift_w.shape[0], w2.shape[0], w1.shape[0]
+        L = _lib.lib()
+        plan = model_plan(ndim, cin, c, cout, hid, n_layers, dims, modes, norm, gelu_mask, x.device)
+        prm = _lib.FnoModelParams()
+        _fill_params(prm, n_layers, ncorner, lift_w, lift_b, skip_ws, spec_ws, sb, w1, b1, w2, b2)
+        y = torch.empty((B, cout) + dims, dtype=torch.float32, device=x.device)
+        saved = _bytes(L.fno_model_saved_bytes(plan, B), x.device)
+        nws = L.fno_model_workspace_bytes(plan, B)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_model_forward(plan, B, C.byref(prm), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), nws,
+                                           _stream()), "model_forward")
+        ctx.plan, ctx.B, ctx.n_layers, ctx.ncorner = plan, B, n_layers, ncorner
+        ctx.has_sb = sb is not None
+        ctx.save_for_backward(x, saved, lift_w, lift_b, w1, b1, w2, b2, *skip_ws, *spec_ws,
+                              *([sb] if sb is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv = ctx.saved_tensors
+        x, saved, lift_w, lift_b, w1, b1, w2, b2 = sv[:8]
+        nl, nc = ctx.n_layers, ctx.ncorner
+        skip_ws = list(sv[8:8 + nl])
+        spec_ws = list(sv[8 + nl:8 + nl + nl * nc])
+        sb = sv[8 + nl + nl * nc] if ctx.has_sb else None
+        dy = dy.contiguous()
+        L = _lib.lib()
+        prm = _lib.FnoModelParams()
+        _fill_params(prm, nl, nc, lift_w, lift_b, skip_ws, spec_ws, sb, w1, b1, w2, b2)
+        g = [torch.empty_like(t) for t in (lift_w, lift_b, w1, b1, w2, b2)]
+        g_skip = [torch.empty_like(t) for t in skip_ws]
+        g_spec = [torch.empty_like(t) for t in spec_ws]
+        g_sb = torch.empty_like(sb) if sb is not None else None
+        grd = _lib.FnoModelGrads()
+        _fill_params(grd, nl, nc, g[0], g[1], g_skip, g_spec, g_sb, g[2], g[3], g[4], g[5])
+        nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
+        ws = _bytes(nws, dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(L.fno_model_backward(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                            C.byref(grd), _ptr(ws), nws, _stream()), "model_backward")
+        return (None, None, g[0], g[1], g_sb, g[2], g[3], g[4], g[5]) + tuple(g_skip) + tuple(g_spec)
+
+
+def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, modes, norm="forward",
+              gelu_mask=None):
+    """Fused neuralop.models.FNO forward (default configuration).  `modes` = kept per
+    corner per dim (n_modes // 2); `spec_ws` real-view corner weights, layer-major."""
+    n_layers = len(skip_ws)
+    if gelu_mask is None:
+        gelu_mask = 0
+        for l in range(n_layers):
+            if l < n_layers - l:                 # fno_block.py:149
+                gelu_mask |= 1 << l
+    cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask))
+    return _FNOModelFn.apply(cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *skip_ws, *spec_ws)
