@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FNO2d forward+backward fields/sec (BASELINE.json).
+
+Workload (config 2): FNO2d(n_modes 12x12, width 64, in 3, out 1) on 128x128 fields,
+batch 64 PER GPU (weak scaling), fp32, synthetic N(0,1) inputs/targets, default init.
+One step = the reference training step (run_pde_observers.py:185-193): zero_grad ->
+forward -> LpLoss(sum) -> backward -> [N>1: one RCCL all-reduce(SUM) of the flat gradient
+bucket] -> Adam.  All arithmetic of forward/backward runs in the HIP engine.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`)
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PEAK_MFMA_F32_TFLOPS = 157.3  # dense fp32 MFMA (v_mfma_f32_32x32x2_f32), same guide
+
+CONFIGS = {
+    # name: (ctor args, input shape per GPU)
+    "fno2d_128x128_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(128, 128)),
+    "fno2d_64x64_w32_m8_b4": dict(kind="2d", modes=(8, 8), width=32, batch=4, size=(64, 64)),
+    "fno3d_64_w32_m8_b16": dict(kind="3d", modes=(8, 8, 8), width=32, batch=16, size=(64, 64, 64)),
+}
+
+
+def kernel_model(cfg):
+    """Algorithmic FLOPs and HBM bytes PER LAUNCH of each hot kernel."""
+    B, C = cfg["batch"], cfg["width"]
+    PW = 1
+    for s in cfg["size"]:
+        PW *= s
+    HID, CO, CIN = 256, 1, 3
+    act = 4.0 * B * C * PW                       # bytes of one (B, C, ...) activation
+    gemm = 2.0 * B * PW * C * C                  # one 1x1 conv
+    proj = 2.0 * B * PW * (C * HID + HID * CO)
+    return {
+        "k_pw_fwd_lift": dict(bytes=4.0 * B * CIN * PW + act, flops=2.0 * B * PW * CIN * C),
+        "k_pw_fwd_block": dict(bytes=2 * act, flops=gemm),
+        "k_proj_fwd": dict(bytes=act + 4.0 * B * CO * PW, flops=proj),
+        "k_proj_bwd": dict(bytes=2 * act + 4.0 * B * CO * PW, flops=2 * proj),
+        "k_block_bwd": dict(bytes=3 * act, flops=2 * gemm),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="fno2d_128x128_w64_m12_b64", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pde_policylearning_amd import _lib
+    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
+    from pde_policylearning_amd.trainer import FlatGradBucket, LpLoss, broadcast_parameters, train_step
+
+    cfg = CONFIGS[args.config]
+    torch.manual_seed(0)                       # run_pde_observers.py:25
+    ctor = FNO2d if cfg["kind"] == "2d" else FNO3d
+    model = ctor(*cfg["modes"], cfg["width"], in_channels=3, out_channels=1).to(dev)
+    broadcast_parameters(model)
+    B = cfg["batch"]
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
+    tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    loss_fn = LpLoss(size_average=False)
+
+    def step():
+        return train_step(model, bucket, opt, (x,), tgt, loss_fn)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(loss).all(), "non-finite loss"
+    fields_per_s = B * world * args.steps / dt
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate profiled steps) ----
+    roofline = None
+    kernels = []
+    if rank == 0 and args.profile_steps > 0:
+        L = _lib.lib()
+        L.fno_profile_reset()
+        L.fno_profile_enable(1)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        L.fno_profile_enable(0)
+        prof = _lib.profile_summary()
+        L.fno_profile_reset()
+        km = kernel_model(cfg)
+        tot = sum(ms for _, ms, _ in prof)
+        for name, ms, n in sorted(prof, key=lambda r: -r[1]):
+            avg = ms / n
+            rec = dict(name=name, launches_per_step=n / args.profile_steps, avg_ms=round(avg, 4),
+                       share=round(ms / tot, 3))
+            if name in km:
+                rec["GBps"] = round(km[name]["bytes"] / avg / 1e6, 1)
+                rec["TFLOPs"] = round(km[name]["flops"] / avg / 1e9, 2)
+            kernels.append(rec)
+        dom = next((k for k in kernels if k["name"] in km), None)
+        if dom is not None:
+            f_h = dom["GBps"] / PEAK_HBM_GBS
+            f_m = dom["TFLOPs"] / PEAK_MFMA_F32_TFLOPS
+            if f_m >= f_h:
+                roofline = dict(kernel=dom["name"], bound="mfma", achieved=dom["TFLOPs"],
+                                peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s", frac=round(f_m, 4), traffic=None)
+            else:
+                roofline = dict(kernel=dom["name"], bound="hbm", achieved=dom["GBps"], peak=PEAK_HBM_GBS,
+                                unit="GB/s", frac=round(f_h, 4), traffic=None)
+            roofline["avg_launch_ms"] = dom["avg_ms"]
+            roofline["measured"] = f"HIP events on the launch stream, {args.profile_steps} profiled steps after the timed region"
+
+    # ---- CPU baseline: the oracle (validated restatement of the reference) on the host cores ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import fno_oracle as O
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        bs = 4 if cfg["kind"] == "2d" else 1
+        bs = min(bs, B)
+        pc = {}
+        for k, v in model.state_dict().items():
+            pc[k] = v.detach().cpu().clone().requires_grad_(True)
+        xs, ts = x[:bs].cpu(), tgt[:bs].cpu()
+
+        def cpu_step():
+            for v in pc.values():
+                v.grad = None
+            y = O.fno_forward(pc, xs, cfg["modes"])
+            O.lp_loss_rel_sum(y, ts).backward()
+
+        cpu_step()
+        n_it, t_c0 = 0, time.perf_counter()
+        while True:
+            cpu_step()
+            n_it += 1
+            el = time.perf_counter() - t_c0
+            if el > 12.0 or n_it >= 8:
+                break
+        cpu_baseline = dict(value=round(bs * n_it / el, 3), unit="fields/s", cores=ncores, kind="port",
+                            sample=f"oracle fwd+loss+bwd on {bs} fields of the same shape, {n_it} iters, "
+                                   f"{el:.1f}s, torch {torch.get_num_threads()} threads")
+
+    if rank == 0:
+        out = {
+            "metric": "FNO2d fwd+bwd fields/sec" if cfg["kind"] == "2d" else "FNO3d fwd+bwd fields/sec",
+            "value": round(fields_per_s, 2),
+            "unit": "fields/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
+                       "step": "zero_grad+fwd+LpLoss(sum)+bwd" + ("+allreduce(sum)" if world > 1 else "") + "+Adam",
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -541,29 +541,29 @@ extern "C" size_t fno_model_saved_bytes(const FnoModelPlan* p, int B) {
 
 // ---- templated launch dispatch ---------------------------------------------
 template <int CIN, int COUT>
-static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a, const char* name) {
   const size_t rows = std::max((CIN + 1) & ~1, COUT);
   if (p->NPX == 128)
-    return launch("k_pw_fwd", k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3(256), rows * 132 * 4, st, a);
-  return launch("k_pw_fwd", k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3(512), rows * 260 * 4, st, a);
+    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3(256), rows * 132 * 4, st, a);
+  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3(512), rows * 260 * 4, st, a);
 }
 static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const int C = p->d.C;
   switch (p->d.Cin * 100 + C) {
-    case 132: return launch_pw<1, 32>(p, st, grid, a);
-    case 232: return launch_pw<2, 32>(p, st, grid, a);
-    case 332: return launch_pw<3, 32>(p, st, grid, a);
-    case 432: return launch_pw<4, 32>(p, st, grid, a);
-    case 164: return launch_pw<1, 64>(p, st, grid, a);
-    case 264: return launch_pw<2, 64>(p, st, grid, a);
-    case 364: return launch_pw<3, 64>(p, st, grid, a);
-    case 464: return launch_pw<4, 64>(p, st, grid, a);
+    case 132: return launch_pw<1, 32>(p, st, grid, a, "k_pw_fwd_lift");
+    case 232: return launch_pw<2, 32>(p, st, grid, a, "k_pw_fwd_lift");
+    case 332: return launch_pw<3, 32>(p, st, grid, a, "k_pw_fwd_lift");
+    case 432: return launch_pw<4, 32>(p, st, grid, a, "k_pw_fwd_lift");
+    case 164: return launch_pw<1, 64>(p, st, grid, a, "k_pw_fwd_lift");
+    case 264: return launch_pw<2, 64>(p, st, grid, a, "k_pw_fwd_lift");
+    case 364: return launch_pw<3, 64>(p, st, grid, a, "k_pw_fwd_lift");
+    case 464: return launch_pw<4, 64>(p, st, grid, a, "k_pw_fwd_lift");
   }
   return fail(FNO_EUNSUPPORTED, "lifting %d -> %d", p->d.Cin, C);
 }
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
-  if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a);
-  return launch_pw<64, 64>(p, st, grid, a);
+  if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a, "k_pw_fwd_block");
+  return launch_pw<64, 64>(p, st, grid, a, "k_pw_fwd_block");
 }
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {

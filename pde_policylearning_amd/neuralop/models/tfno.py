@@ -1,0 +1,125 @@
+"""FNO / FNO2d / FNO3d with the reference constructor surface (neuralop/models/tfno.py:
+Lifting :11-20, Projection :23-38, FNO :107-211, FNO2d :342-458, FNO3d :467-580).
+forward() runs the whole model in the HIP engine (functional.fno_model)."""
+import torch.nn.functional as TF
+from torch import nn
+
+from ... import functional as F
+from .fno_block import FNOBlocks
+from .spectral_convolution import SpectralConv, _unsupported
+
+
+class Lifting(nn.Module):
+    def __init__(self, in_channels, out_channels, n_dim=2):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.fc = getattr(nn, f'Conv{n_dim}d')(in_channels, out_channels, 1)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class Projection(nn.Module):
+    def __init__(self, in_channels, out_channels, hidden_channels=None, n_dim=2, non_linearity=TF.gelu):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.hidden_channels = in_channels if hidden_channels is None else hidden_channels
+        self.non_linearity = non_linearity
+        Conv = getattr(nn, f'Conv{n_dim}d')
+        self.fc1 = Conv(in_channels, hidden_channels, 1)
+        self.fc2 = Conv(hidden_channels, out_channels, 1)
+
+    def forward(self, x):
+        return self.fc2(self.non_linearity(self.fc1(x)))
+
+
+class FNO(nn.Module):
+    def __init__(self, n_modes, hidden_channels, in_channels=3, out_channels=1, lifting_channels=256,
+                 projection_channels=256, n_layers=4, output_scaling_factor=None,
+                 incremental_n_modes=None, use_mlp=False, mlp_dropout=0, mlp_expansion=0.5,
+                 non_linearity=TF.gelu, norm=None, preactivation=False, fno_skip='linear',
+                 mlp_skip='soft-gating', separable=False, factorization=None, rank=1.0,
+                 joint_factorization=False, fixed_rank_modes=False, implementation='factorized',
+                 decomposition_kwargs=dict(), domain_padding=None, domain_padding_mode='one-sided',
+                 fft_norm='forward', SpectralConv=SpectralConv, **kwargs):
+        super().__init__()
+        if domain_padding is not None and domain_padding > 0:
+            _unsupported("domain_padding")
+        self.n_dim = len(n_modes)
+        self.n_modes = tuple(n_modes)
+        self.hidden_channels = hidden_channels
+        self.lifting_channels = lifting_channels        # stored, unused (tfno.py:191)
+        self.projection_channels = projection_channels
+        self.in_channels, self.out_channels, self.n_layers = in_channels, out_channels, n_layers
+        self.fft_norm = fft_norm
+        self.non_linearity = non_linearity
+        self.fno_blocks = FNOBlocks(
+            in_channels=hidden_channels, out_channels=hidden_channels, n_modes=self.n_modes,
+            output_scaling_factor=output_scaling_factor, use_mlp=use_mlp, mlp_dropout=mlp_dropout,
+            mlp_expansion=mlp_expansion, non_linearity=non_linearity, norm=norm,
+            preactivation=preactivation, fno_skip=fno_skip, mlp_skip=mlp_skip,
+            incremental_n_modes=incremental_n_modes, rank=rank, fft_norm=fft_norm,
+            fixed_rank_modes=fixed_rank_modes, implementation=implementation, separable=separable,
+            factorization=factorization, decomposition_kwargs=decomposition_kwargs,
+            joint_factorization=joint_factorization, SpectralConv=SpectralConv, n_layers=n_layers)
+        self.lifting = Lifting(in_channels, hidden_channels, n_dim=self.n_dim)
+        self.projection = Projection(hidden_channels, out_channels, hidden_channels=projection_channels,
+                                     non_linearity=non_linearity, n_dim=self.n_dim)
+
+    def engine_args(self):
+        blk = self.fno_blocks
+        L = self.n_layers
+        skip_ws = [blk.fno_skips[l].weight for l in range(L)]
+        spec_ws = [w.tensor for w in blk.convs.weight]
+        return dict(lift_w=self.lifting.fc.weight, lift_b=self.lifting.fc.bias, skip_ws=skip_ws,
+                    spec_ws=spec_ws, spec_bias=blk.convs.bias,
+                    w1=self.projection.fc1.weight, b1=self.projection.fc1.bias,
+                    w2=self.projection.fc2.weight, b2=self.projection.fc2.bias,
+                    modes=blk.convs.half_n_modes, norm=self.fft_norm)
+
+    def forward(self, x):
+        return F.fno_model(x, **self.engine_args())
+
+
+class FNO2d(FNO):
+    def __init__(self, n_modes_height, n_modes_width, hidden_channels, in_channels=3, out_channels=1,
+                 lifting_channels=256, projection_channels=256, n_layers=4, output_scaling_factor=None,
+                 incremental_n_modes=None, non_linearity=TF.gelu, use_mlp=False, mlp_dropout=0,
+                 mlp_expansion=0.5, norm=None, skip='soft-gating', separable=False, preactivation=False,
+                 factorization=None, rank=1.0, joint_factorization=False, fixed_rank_modes=False,
+                 implementation='factorized', decomposition_kwargs=dict(), domain_padding=None,
+                 domain_padding_mode='one-sided', fft_norm='forward', **kwargs):
+        # `skip` is accepted and ignored exactly as in the reference (tfno.py:449 -> **kwargs :131)
+        super().__init__(
+            n_modes=(n_modes_height, n_modes_width), hidden_channels=hidden_channels,
+            in_channels=in_channels, out_channels=out_channels, lifting_channels=lifting_channels,
+            projection_channels=projection_channels, n_layers=n_layers, output_scaling_factor=None,
+            non_linearity=non_linearity, use_mlp=use_mlp, mlp_dropout=mlp_dropout,
+            mlp_expansion=mlp_expansion, incremental_n_modes=incremental_n_modes, norm=norm,
+            separable=separable, preactivation=preactivation, factorization=factorization, rank=rank,
+            joint_factorization=joint_factorization, fixed_rank_modes=fixed_rank_modes,
+            implementation=implementation, decomposition_kwargs=decomposition_kwargs,
+            domain_padding=domain_padding, domain_padding_mode=domain_padding_mode, fft_norm=fft_norm)
+        self.n_modes_height, self.n_modes_width = n_modes_height, n_modes_width
+
+
+class FNO3d(FNO):
+    def __init__(self, n_modes_height, n_modes_width, n_modes_depth, hidden_channels, in_channels=3,
+                 out_channels=1, lifting_channels=256, projection_channels=256, n_layers=4,
+                 output_scaling_factor=None, incremental_n_modes=None, non_linearity=TF.gelu,
+                 use_mlp=False, mlp_dropout=0, mlp_expansion=0.5, norm=None, skip='soft-gating',
+                 separable=False, preactivation=False, factorization=None, rank=1.0,
+                 joint_factorization=False, fixed_rank_modes=False, implementation='factorized',
+                 decomposition_kwargs=dict(), domain_padding=None, domain_padding_mode='one-sided',
+                 fft_norm='forward', **kwargs):
+        super().__init__(
+            n_modes=(n_modes_height, n_modes_width, n_modes_depth), hidden_channels=hidden_channels,
+            in_channels=in_channels, out_channels=out_channels, lifting_channels=lifting_channels,
+            projection_channels=projection_channels, n_layers=n_layers, output_scaling_factor=None,
+            non_linearity=non_linearity, use_mlp=use_mlp, mlp_dropout=mlp_dropout,
+            mlp_expansion=mlp_expansion, incremental_n_modes=incremental_n_modes, norm=norm,
+            separable=separable, preactivation=preactivation, factorization=factorization, rank=rank,
+            joint_factorization=joint_factorization, fixed_rank_modes=fixed_rank_modes,
+            implementation=implementation, decomposition_kwargs=decomposition_kwargs,
+            domain_padding=domain_padding, domain_padding_mode=domain_padding_mode, fft_norm=fft_norm)
+        self.n_modes_height, self.n_modes_width, self.n_modes_depth = n_modes_height, n_modes_width, n_modes_depth
