@@ -29,7 +29,7 @@ def build(force=False, verbose=True):
     if not force and up_to_date():
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result", "-o", OUT, SRC]
+           "-Wno-unused-value", "-Wno-unused-result"] + os.environ.get("FNO_EXTRA_FLAGS", "").split() + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -303,7 +303,7 @@ static int unpack_dw(hipStream_t st, const Geom& g, int Cin, int Cout, const flo
 static int reduce_slabs(hipStream_t st, const float* part, float* out, int nslab, int rows, int ncols, int ld_in,
                         int ld_out) {
   const int n = rows * ncols;
-  return launch("k_reduce_slabs", k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, st, part, out, nslab, n,
+  return launch("k_reduce_slabs", k_reduce_slabs, dim3((n + 63) / 64), dim3(64, 16), 0, st, part, out, nslab, n,
                 ld_out, ncols, ld_in);
 }
 
@@ -522,7 +522,7 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
     w.dw_part = c.take<float>((size_t)s.grid * 8 * C * C);
     w.db_part = c.take<float>((size_t)s.grid * C);
     w.dwl_part = c.take<float>((size_t)s.grid * C * 16);
-    w.dw1_part = c.take<float>((size_t)s.grid * 8 * kHID * C);
+    w.dw1_part = c.take<float>((size_t)s.grid * kHID * C);
     w.db1_part = c.take<float>((size_t)s.grid * kHID);
     w.dw2_part = c.take<float>((size_t)s.grid * PROJ_MAXCO * kHID);
     w.db2_part = c.take<float>((size_t)64 * PROJ_MAXCO);
@@ -544,8 +544,8 @@ template <int CIN, int COUT>
 static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a, const char* name) {
   const size_t rows = std::max((CIN + 1) & ~1, COUT);
   if (p->NPX == 128)
-    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3(256), rows * 132 * 4, st, a);
-  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3(512), rows * 260 * 4, st, a);
+    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3((COUT / 32) * 4 * 64), rows * 132 * 4, st, a);
+  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3((COUT / 32) * 8 * 64), rows * 260 * 4, st, a);
 }
 static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const int C = p->d.C;
@@ -568,35 +568,45 @@ static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const P
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   if (p->NPX == 128)
-    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(256), (size_t)(2 * C + 8) * 132 * 4, st, a);
-  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(512), (size_t)(2 * C + 8) * 260 * 4, st, a);
+    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+                  (size_t)(2 * C + 8) * 132 * 4, st, a);
+  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64),
+                (size_t)(2 * C + 8) * 260 * 4, st, a);
 }
 static int launch_bbwd(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   return p->d.C == 32 ? launch_bbwd_c<32>(p, st, grid, a) : launch_bbwd_c<64>(p, st, grid, a);
 }
 static int bbwd_ksplit(const FnoModelPlan* p) {
-  const int nw = p->NPX / 32, tiles = (p->d.C / 32) * (p->d.C / 32);
-  return nw >= tiles ? nw / tiles : 1;
+  const int ntn = p->NPX / 32, mt = p->d.C / 32;
+  return ntn / mt;
+}
+template <int C, int NCO>
+static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
+  if (p->NPX == 128)
+    return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512),
+                  (size_t)C * 132 * 4 + (size_t)(kHID + NCO * kHID + NCO * 128) * 4, st, a);
+  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024),
+                (size_t)C * 260 * 4 + (size_t)(kHID + NCO * kHID + NCO * 256) * 4, st, a);
 }
 template <int C>
 static int launch_pfwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
-  const size_t extra = (size_t)(kHID + PROJ_MAXCO * kHID) * 4;
+  return a.CO == 1 ? launch_pfwd_cn<C, 1>(p, st, grid, a) : launch_pfwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
+}
+template <int C, int NCO>
+static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  // LDS: tile + chunk buffer + dy rows + b1 + W2; the final thread-sum reduction reuses the
+  // front of it (NW x HID x (1+NCO) floats) and must fit
+  const int nw = p->NPX / 16;
+  const int pitch = p->NPX + 4;
+  size_t lds = (size_t)(C + 64) * pitch * 4 + (size_t)(NCO * p->NPX + kHID + NCO * kHID) * 4;
+  lds = std::max(lds, (size_t)nw * kHID * (1 + NCO) * 4);
   if (p->NPX == 128)
-    return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128>, dim3(grid), dim3(256), (size_t)C * 132 * 4 + extra, st, a);
-  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 256>, dim3(grid), dim3(512), (size_t)C * 260 * 4 + extra, st, a);
+    return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
 }
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
-  const size_t extra = (size_t)(kHID + PROJ_MAXCO * kHID) * 4;
-  if (p->NPX == 128)
-    return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128>, dim3(grid), dim3(256),
-                  (size_t)(C + 64) * 132 * 4 + PROJ_MAXCO * 128 * 4 + extra, st, a);
-  return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256>, dim3(grid), dim3(512),
-                (size_t)(C + 64) * 260 * 4 + PROJ_MAXCO * 256 * 4 + extra, st, a);
-}
-static int pbwd_ksplit(const FnoModelPlan* p) {
-  const int nw = p->NPX / 32, tiles = 2 * (p->d.C / 32);
-  return nw >= tiles ? nw / tiles : 1;
+  return a.CO == 1 ? launch_pbwd_cn<C, 1>(p, st, grid, a) : launch_pbwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
 }
 
 // spectral middle of one block: x1 -> (hat) -> ohat -> z
@@ -691,8 +701,7 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   pb.tiles_per_plane = s.tiles_per_plane; pb.ntiles = s.ntiles;
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
-  const int ks1 = pbwd_ksplit(p);
-  LAUNCHCHK(reduce_slabs(st, w.dw1_part, gr->proj_w1, s.grid * ks1, kHID, C, C, C));
+  LAUNCHCHK(reduce_slabs(st, w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C));
   LAUNCHCHK(reduce_slabs(st, w.db1_part, gr->proj_b1, s.grid, 1, kHID, kHID, kHID));
   LAUNCHCHK(reduce_slabs(st, w.dw2_part, gr->proj_w2, s.grid, d.Cout, kHID, kHID, kHID));
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));

@@ -8,14 +8,19 @@
 //   X1g        = truncated row DFT of gout  (MFMA 16x16x4)  -> feeds the spectral
 //                backward of block l-1;   or, for block 0, the lifting gradients
 //                dWl[c][i] = sum_px gout[c][px] x_in[i][px], dbl[c] = sum_px gout[c][px].
-// Weight/bias gradients are accumulated in registers across the persistent
-// tile loop and written once per workgroup as partial slabs (summed by
-// k_reduce_slabs: deterministic, no float atomics).
+// Wave (mt, nt) owns the 32x32 sub-tile (channels 32*mt.., pixels 32*nt..) of dx and one
+// (32x32 tile, pixel-range) job of dW.  Weight/bias gradients are accumulated in
+// registers across the persistent tile loop and written once per workgroup as partial
+// slabs (summed by k_reduce_slabs: deterministic, no float atomics).
 //
 // Reference semantics: autograd of fno_block.py:123-170 + spectral_convolution.py:303-347
 // (formulas: SURVEY.md Appendix A, oracle/fno_oracle.py::spectral_conv_A_backward).
 #pragma once
 #include "fno_dev.h"
+
+#ifndef FNO_OCC_BB
+#define FNO_OCC_BB 4
+#endif
 
 struct BlkBwdArgs {
   const float* g;      // (B, C, PW)
@@ -37,40 +42,48 @@ struct BlkBwdArgs {
 };
 
 template <int C, int NPX>
-__global__ void __launch_bounds__(NPX * 2) k_block_bwd(BlkBwdArgs a) {
-  constexpr int NW = NPX / 32;
+struct BlkBwdCfg {
+  static constexpr int NTN = NPX / 32;
+  static constexpr int MT = C / 32;
+  static constexpr int NW = MT * NTN;
+  static constexpr int TILES = MT * MT;
+  static constexpr int KSPLIT = NW / TILES;
+  static_assert(NW % TILES == 0 && KSPLIT >= 1, "C <= NPX required");
+};
+
+template <int C, int NPX>
+__global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_block_bwd(BlkBwdArgs a) {
+  using Cfg = BlkBwdCfg<C, NPX>;
+  constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
   constexpr int NT = NW * 64;
-  constexpr int MT = C / 32;
   constexpr int KS = C / 2;
   constexpr int PITCH = NPX + 4;
-  constexpr int TILES = MT * MT;                       // 32x32 tiles of dW
-  constexpr int KSPLIT = (NW >= TILES) ? NW / TILES : 1;
-  constexpr int TPW = (TILES + NW - 1) / NW;           // dW tiles per wave when NW < TILES
+  constexpr int DBPX = NPX / (NT / C);                 // pixels per thread in the dbias sums
+  static_assert(NT % C == 0 && DBPX % 4 == 0, "dbias thread mapping");
+  constexpr int PXK = NPX / KSPLIT;
   constexpr int LJ = (C / 16 + NW - 1) / NW;           // lifting-epilogue jobs per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* gs = smem;                 // C x PITCH
-  float* us = smem + C * PITCH;     // C x PITCH
-  float* xls = us + C * PITCH;      // 4 x PITCH (lifting input rows)
+  float* gs = smem;                 // C x PITCH : g, later the gout tile
+  float* us = smem + C * PITCH;     // C x PITCH : u_l, then a_l in place
+  float* xls = us + C * PITCH;      // 8 x PITCH : lifting input rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15, quad = lane >> 4;
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+  const int dtl = wave % TILES, dkp = wave / TILES;     // dW job
+  const int dmt = dtl / MT, dnt = dtl % MT;
 
   // A fragments of W^T: A[i][k = o] = W[o][i]
-  float afrag[MT][KS];
+  float afrag[KS];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) afrag[m][s] = a.w[(2 * s + half) * C + m * 32 + l31];
+  for (int s = 0; s < KS; ++s) afrag[s] = a.w[(2 * s + half) * C + mt * 32 + l31];
 
-  f32x16 dwacc[TPW];
+  f32x16 dwacc;
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.0f;
-  float dbacc[C / 8];
-#pragma unroll
-  for (int i = 0; i < C / 8; ++i) dbacc[i] = 0.0f;
+  for (int r = 0; r < 16; ++r) dwacc[r] = 0.0f;
+  float dbsum = 0.0f;                                  // thread (c = tid % C, part = tid / C)
   f32x4 dl[LJ];
 #pragma unroll
   for (int j = 0; j < LJ; ++j) dl[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -80,131 +93,89 @@ __global__ void __launch_bounds__(NPX * 2) k_block_bwd(BlkBwdArgs a) {
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     const float* gb = a.g + (size_t)b * C * a.PW + px0;
     const float* ub = a.uin + (size_t)b * C * a.PW + px0;
-#pragma unroll
-    for (int i = 0; i < C / 8; ++i) {
-      const int idx = tid + i * NT;
-      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
-      const float4 gv = ld4(gb + (size_t)c * a.PW + 4 * q);
-      const float4 uv = ld4(ub + (size_t)c * a.PW + 4 * q);
-      dbacc[i] += (gv.x + gv.y) + (gv.z + gv.w);
-      st4(gs + c * PITCH + 4 * q, gv);
-      st4(us + c * PITCH + 4 * q, uv);
-    }
-    if (a.xin) {
-      const float* xb = a.xin + (size_t)b * a.CL * a.PW + px0;
-      for (int idx = tid; idx < a.CL * (NPX / 4); idx += NT) {
-        const int c = idx / (NPX / 4), q = idx % (NPX / 4);
-        st4(xls + c * PITCH + 4 * q, ld4(xb + (size_t)c * a.PW + 4 * q));
-      }
-    }
+    stage_rows_t<NPX, NT, C>(gs, gb, a.PW, false, tid);
+    stage_rows_t<NPX, NT, C>(us, ub, a.PW, false, tid);
+    if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
     __syncthreads();
 
-    // ---- dx GEMM (+ row inverse DFT of the spectral gradient) -------------
-    f32x16 acc[MT];
+    {  // dbias[c] partial: this thread's TPX pixels of row c
+      const float* gr = gs + (tid % C) * PITCH + (tid / C) * DBPX;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-    const int n0 = wave * 32;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float bf = gs[(2 * s + half) * PITCH + n0 + l31];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = mfma32(afrag[m][s], bf, acc[m]);
+      for (int j = 0; j < DBPX / 4; ++j) {
+        const float4 gv = ld4(gr + 4 * j);
+        dbsum += (gv.x + gv.y) + (gv.z + gv.w);
+      }
     }
+    // ---- dx GEMM (+ row inverse DFT of the spectral gradient) -------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = mfma32(afrag[s], gs[(2 * s + half) * PITCH + n0 + l31], acc);
     if (a.zg) {
       const int prow = (px0 + n0) / a.W;
       const int wcol = (px0 + n0) % a.W + l31;
-      const float* zr = a.zg + ((size_t)b * a.P + prow) * a.K2in * C * 2;
-      for (int s = 0; s < a.K2in; ++s) {
-        const float bf = a.tinv[(2 * s + half) * a.W + wcol];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float af = zr[(s * C + m * 32 + l31) * 2 + half];
-          acc[m] = mfma32(af, bf, acc[m]);
-        }
-      }
+      const float* zr = a.zg + (((size_t)b * a.P + prow) * a.K2in * C + mt * 32 + l31) * 2 + half;
+      const float* tv = a.tinv + (size_t)half * a.W + wcol;
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[(size_t)s * C * 2], tv[(size_t)2 * s * a.W], acc);
     }
     // ---- activation derivative; us becomes a_l = act(u_l) in place --------
     // (each (i, px) element of us is touched only by the lane that owns it)
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
+    {
+      float* up = us + (mt * 32 + 4 * half) * PITCH + n0 + l31;
+      float* gp = a.gout ? a.gout + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = m * 32 + acc_row32(r, half);
-        float v = acc[m][r];
+        const int ro = (r & 3) + 8 * (r >> 2);          // acc_row32(r, half) - 4 * half
+        float v = acc[r];
         if (a.act_in) {
-          const float uu = us[i * PITCH + n0 + l31];
-          v *= gelu_grad_f(uu);
-          us[i * PITCH + n0 + l31] = gelu_f(uu);
+          float gl, dg;
+          gelu_both(up[ro * PITCH], gl, dg);
+          v *= dg;
+          up[ro * PITCH] = gl;
         }
-        acc[m][r] = v;
-        if (a.gout) a.gout[((size_t)b * C + i) * a.PW + px0 + n0 + l31] = v;
+        acc[r] = v;
+        if (gp) gp[(size_t)ro * a.PW] = v;
       }
+    }
     __syncthreads();
 
     // ---- dW[o][i] += sum_px g[o][px] a[i][px] ------------------------------
     // k index of MFMA #t in group q: lane-half h <-> pixel 8q + 4h + t (one b128 per 4 MFMAs)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int job = wave + t * NW;
-      const int tl = job % TILES, kp = (job / TILES) % KSPLIT;
-      if (TPW > 1 && job >= TILES) break;
-      const int mt = tl / MT, nt = tl % MT;
-      constexpr int PXK = NPX / KSPLIT;
-      const float* ga = gs + (mt * 32 + l31) * PITCH + kp * PXK + 4 * half;
-      const float* ab = us + (nt * 32 + l31) * PITCH + kp * PXK + 4 * half;
-#pragma unroll 4
+    {
+      const float* ga = gs + (dmt * 32 + l31) * PITCH + dkp * PXK + 4 * half;
+      const float* ab = us + (dnt * 32 + l31) * PITCH + dkp * PXK + 4 * half;
+#pragma unroll 2
       for (int q = 0; q < PXK / 8; ++q) {
         const float4 av = ld4(ga + 8 * q);
         const float4 bv = ld4(ab + 8 * q);
-        dwacc[t] = mfma32(av.x, bv.x, dwacc[t]);
-        dwacc[t] = mfma32(av.y, bv.y, dwacc[t]);
-        dwacc[t] = mfma32(av.z, bv.z, dwacc[t]);
-        dwacc[t] = mfma32(av.w, bv.w, dwacc[t]);
+        dwacc = mfma32(av.x, bv.x, dwacc);
+        dwacc = mfma32(av.y, bv.y, dwacc);
+        dwacc = mfma32(av.z, bv.z, dwacc);
+        dwacc = mfma32(av.w, bv.w, dwacc);
       }
     }
 
     if (a.x1g || a.xin) {
       __syncthreads();  // dW GEMM done with gs
+      {
+        float* gq = gs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          gs[(m * 32 + acc_row32(r, half)) * PITCH + n0 + l31] = acc[m][r];
-      __syncthreads();
-      if (a.x1g) {
-        const int R = NPX / a.W;
-        const int njobs = (C / 16) * R * a.NJ;
-        for (int job = wave; job < njobs; job += NW) {
-          const int nt = job % (C / 16);
-          const int rr = (job / (C / 16)) % R;
-          const int jt = job / ((C / 16) * R);
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          const float* tf = a.tfwd + (size_t)(jt * 16 + l15) * a.W + quad;
-          const float* xr = gs + (nt * 16 + l15) * PITCH + rr * a.W + quad;
-          for (int s = 0; s < a.W / 4; ++s) d = mfma16(tf[4 * s], xr[4 * s], d);
-          const int prow = px0 / a.W + rr;
-          const int o = nt * 16 + l15;
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const int k2 = jt * 8 + quad * 2 + pr;
-            if (k2 < a.K2out)
-              *reinterpret_cast<float2*>(a.x1g + ((((size_t)b * a.P + prow) * a.K2out + k2) * C + o) * 2) =
-                  make_float2(d[2 * pr], d[2 * pr + 1]);
-          }
-        }
+        for (int r = 0; r < 16; ++r) gq[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
       }
+      __syncthreads();
+      if (a.x1g) row_dft_epilogue<C, NPX, NW>(gs, a.tfwd, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
       if (a.xin) {
         // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]
 #pragma unroll
         for (int j = 0; j < LJ; ++j) {
-          const int mt = wave + j * NW;
-          if (mt < C / 16) {
-            const float* ar = gs + (mt * 16 + l15) * PITCH + quad;
-            const float* br = xls + l15 * PITCH + quad;
+          const int jm = wave + j * NW;
+          if (jm < C / 16) {
+            const float* ar = gs + (jm * 16 + l15) * PITCH + quad;
+            const float* br = xls + (l15 < a.CL ? l15 : 0) * PITCH + quad;
+            const float cst = l15 == a.CL ? 1.0f : 0.0f;
             for (int s = 0; s < NPX / 4; ++s) {
-              const float bf = (l15 < a.CL) ? br[4 * s] : (l15 == a.CL ? 1.0f : 0.0f);
+              const float bf = (l15 < a.CL) ? br[4 * s] : cst;
               dl[j] = mfma16(ar[4 * s], bf, dl[j]);
             }
           }
@@ -215,46 +186,52 @@ __global__ void __launch_bounds__(NPX * 2) k_block_bwd(BlkBwdArgs a) {
   }
 
   // ---- write partial slabs ---------------------------------------------------
+  {
+    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPLIT + dkp) * C * C;
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int job = wave + t * NW;
-    if (TPW > 1 && job >= TILES) break;
-    const int tl = job % TILES, kp = (job / TILES) % KSPLIT;
-    const int mt = tl / MT, nt = tl % MT;
-    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPLIT + kp) * C * C;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      dst[(mt * 32 + acc_row32(r, half)) * C + nt * 32 + l31] = dwacc[t][r];
+    for (int r = 0; r < 16; ++r) dst[(dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dwacc[r];
   }
-#pragma unroll
-  for (int i = 0; i < C / 8; ++i) {
-    float v = dbacc[i];
-    for (int off = (NPX / 4) / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    const int c = (tid + i * NT) / (NPX / 4);
-    if ((tid % (NPX / 4)) == 0) a.db_part[(size_t)blockIdx.x * C + c] = v;
+  __syncthreads();
+  smem[tid] = dbsum;                         // [part][c]
+  __syncthreads();
+  if (tid < C) {
+    float v = 0.f;
+    for (int k = 0; k < NT / C; ++k) v += smem[k * C + tid];
+    a.db_part[(size_t)blockIdx.x * C + tid] = v;
   }
   if (a.xin) {
 #pragma unroll
     for (int j = 0; j < LJ; ++j) {
-      const int mt = wave + j * NW;
-      if (mt < C / 16) {
+      const int jm = wave + j * NW;
+      if (jm < C / 16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          a.dwl_part[((size_t)blockIdx.x * C + mt * 16 + quad * 4 + r) * 16 + l15] = dl[j][r];
+          a.dwl_part[((size_t)blockIdx.x * C + jm * 16 + quad * 4 + r) * 16 + l15] = dl[j][r];
       }
     }
   }
 }
 
-// out[e] = sum_s part[s*n + e]   (deterministic slab reduction; optionally accumulates)
-__global__ void k_reduce_slabs(const float* __restrict__ part, float* __restrict__ out, int nslab, int n,
-                               int ld_out, int ncols, int ld_in) {
-  // element e = (row, col) with col < ncols; input row stride ld_in, output row stride ld_out
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int row = e / ncols, col = e % ncols;
+// out[row][col] = sum_s part[s][row][col]: deterministic two-level slab reduction.
+// block = (64 elements, 16 slab lanes); element e = (row, col), col < ncols.
+__global__ void __launch_bounds__(1024) k_reduce_slabs(const float* __restrict__ part, float* __restrict__ out,
+                                                       int nslab, int n, int ld_out, int ncols, int ld_in) {
+  __shared__ float sh[16][65];
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  const int sy = threadIdx.y;
   float s = 0.f;
-  const size_t slab = (size_t)(n / ncols) * ld_in;
-  for (int k = 0; k < nslab; ++k) s += part[k * slab + (size_t)row * ld_in + col];
-  out[(size_t)row * ld_out + col] = s;
+  if (e < n) {
+    const int row = e / ncols, col = e % ncols;
+    const size_t slab = (size_t)(n / ncols) * ld_in;
+    const float* p = part + (size_t)row * ld_in + col;
+    for (int k = sy; k < nslab; k += 16) s += p[k * slab];
+  }
+  sh[sy][threadIdx.x] = s;
+  __syncthreads();
+  if (sy == 0 && e < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+    out[(size_t)(e / ncols) * ld_out + e % ncols] = t;
+  }
 }

@@ -1,7 +1,8 @@
 // Fused pointwise (1x1 conv) + truncated-spectrum row passes, forward direction.
 //
 // One workgroup owns a tile of NPX consecutive pixels of one sample's (P x W)
-// plane, for ALL channels.  Per tile (persistent grid-stride loop):
+// plane, for ALL channels; wave (mt, nt) owns the 32x32 output sub-tile
+// (channels 32*mt.., pixels 32*nt..).  Per tile (persistent grid-stride loop):
 //   1. stage x[b, 0:CIN, tile] HBM -> LDS (16 B/lane coalesced), applying the
 //      previous block's GELU on load when act_in (activations are stored
 //      PRE-activation so that backward never needs a second copy);
@@ -21,6 +22,10 @@
 #pragma once
 #include "fno_dev.h"
 
+#ifndef FNO_OCC_PW
+#define FNO_OCC_PW 4
+#endif
+
 struct PwFwdArgs {
   const float* x;     // (B, CIN, PW) pre-activation input, or null (no conv part)
   const float* w;     // (COUT, CIN) row-major
@@ -36,11 +41,12 @@ struct PwFwdArgs {
 };
 
 template <int CIN, int COUT, int NPX>
-__global__ void __launch_bounds__(NPX * 2) k_pw_fwd(PwFwdArgs a) {
-  constexpr int NW = NPX / 32;
+__global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
+  constexpr int NTN = NPX / 32;          // pixel sub-tiles
+  constexpr int MT = COUT / 32;          // channel sub-tiles
+  constexpr int NW = MT * NTN;
   constexpr int NT = NW * 64;
   constexpr int CINP = (CIN + 1) & ~1;
-  constexpr int MT = COUT / 32;
   constexpr int KS = CINP / 2;
   constexpr int PITCH = NPX + 4;
   static_assert(COUT % 32 == 0 && NPX % 32 == 0, "tile shape");
@@ -49,108 +55,62 @@ __global__ void __launch_bounds__(NPX * 2) k_pw_fwd(PwFwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int l15 = lane & 15, quad = lane >> 4;
-  const bool has_conv = (CIN > 0) && (a.x != nullptr);
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+  const bool has_conv = a.x != nullptr;
 
   // weight fragments: A[i = o][k = c], constant over all tiles of this workgroup
-  float afrag[MT][KS > 0 ? KS : 1];
-  if (has_conv) {
+  float afrag[KS];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int c = 2 * s + half;
-        afrag[m][s] = (c < CIN) ? a.w[(m * 32 + l31) * CIN + c] : 0.0f;
-      }
+  for (int s = 0; s < KS; ++s) {
+    const int c = 2 * s + half;
+    afrag[s] = (has_conv && c < CIN) ? a.w[(mt * 32 + l31) * CIN + c] : 0.0f;
   }
-  float bias_r[MT][16];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      bias_r[m][r] = a.bias ? a.bias[m * 32 + acc_row32(r, half)] : 0.0f;
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
 
     if (has_conv) {
-      const float* xb = a.x + (size_t)b * CIN * a.PW + px0;
-      for (int idx = tid; idx < CINP * (NPX / 4); idx += NT) {
-        const int c = idx / (NPX / 4), q = idx % (NPX / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < CIN) {
-          v = ld4(xb + (size_t)c * a.PW + 4 * q);
-          if (a.act_in) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
-        }
-        st4(xs + c * PITCH + 4 * q, v);
-      }
+      if (CIN == CINP)
+        stage_rows_t<NPX, NT, CINP>(xs, a.x + (size_t)b * CIN * a.PW + px0, a.PW, a.act_in != 0, tid);
+      else
+        stage_rows<NPX, NT>(xs, a.x + (size_t)b * CIN * a.PW + px0, a.PW, CIN, CINP, a.act_in != 0, tid);
     }
     __syncthreads();
 
-    f32x16 acc[MT];
+    f32x16 acc;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-    const int n0 = wave * 32;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     if (has_conv) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const float bf = xs[(2 * s + half) * PITCH + n0 + l31];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = mfma32(afrag[m][s], bf, acc[m]);
-      }
+      for (int s = 0; s < KS; ++s) acc = mfma32(afrag[s], xs[(2 * s + half) * PITCH + n0 + l31], acc);
     }
     if (a.z) {
       const int prow = (px0 + n0) / a.W;
       const int wcol = (px0 + n0) % a.W + l31;
-      const float* zr = a.z + ((size_t)b * a.P + prow) * a.K2in * COUT * 2;
-      for (int s = 0; s < a.K2in; ++s) {
-        const float bf = a.tinv[(2 * s + half) * a.W + wcol];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float af = zr[(s * COUT + m * 32 + l31) * 2 + half];
-          acc[m] = mfma32(af, bf, acc[m]);
-        }
-      }
+      const float* zr = a.z + (((size_t)b * a.P + prow) * a.K2in * COUT + mt * 32 + l31) * 2 + half;
+      const float* tv = a.tinv + (size_t)half * a.W + wcol;
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[(size_t)s * COUT * 2], tv[(size_t)2 * s * a.W], acc);
     }
     __syncthreads();  // all waves are done reading the staged input
 
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
+    {
+      // one base pointer + small row offsets (keeps 16 x 64-bit addresses out of registers)
+      float* up = a.u ? a.u + ((size_t)b * COUT + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
+      float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
+      const float* bp = a.bias ? a.bias + mt * 32 + 4 * half : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = m * 32 + acc_row32(r, half);
-        const float v = acc[m][r] + bias_r[m][r];
-        if (a.u) a.u[((size_t)b * COUT + o) * a.PW + px0 + n0 + l31] = v;
-        if (a.x1) xs[o * PITCH + n0 + l31] = a.act_out ? gelu_f(v) : v;
+        const int ro = (r & 3) + 8 * (r >> 2);          // acc_row32(r, half) - 4 * half
+        const float v = acc[r] + (bp ? bp[ro] : 0.0f);
+        if (up) up[(size_t)ro * a.PW] = v;
+        if (a.x1) xp[ro * PITCH] = a.act_out ? gelu_f(v) : v;
       }
-
+    }
     if (a.x1) {
       __syncthreads();
-      const int R = NPX / a.W;
-      const int njobs = (COUT / 16) * R * a.NJ;
-      for (int job = wave; job < njobs; job += NW) {
-        const int nt = job % (COUT / 16);
-        const int rr = (job / (COUT / 16)) % R;
-        const int jt = job / ((COUT / 16) * R);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        const float* tf = a.tfwd + (size_t)(jt * 16 + l15) * a.W + quad;
-        const float* xr = xs + (nt * 16 + l15) * PITCH + rr * a.W + quad;
-        for (int s = 0; s < a.W / 4; ++s) d = mfma16(tf[4 * s], xr[4 * s], d);
-        // D[row = j_local][col = o_local]: lane holds j = jt*16 + quad*4 + r, o = nt*16 + l15
-        const int prow = px0 / a.W + rr;
-        const int o = nt * 16 + l15;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const int k2 = jt * 8 + quad * 2 + pr;
-          if (k2 < a.K2out) {
-            float2 v2 = make_float2(d[2 * pr], d[2 * pr + 1]);
-            *reinterpret_cast<float2*>(a.x1 + ((((size_t)b * a.P + prow) * a.K2out + k2) * COUT + o) * 2) = v2;
-          }
-        }
-      }
+      row_dft_epilogue<COUT, NPX, NW>(xs, a.tfwd, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
   }
