@@ -162,7 +162,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import fno_oracle as O
         ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
         bs = 4 if cfg["kind"] == "2d" else 1
         bs = min(bs, B)
         pc = {}
@@ -176,17 +175,29 @@ def main():
             y = O.fno_forward(pc, xs, cfg["modes"])
             O.lp_loss_rel_sum(y, ts).backward()
 
-        cpu_step()
-        n_it, t_c0 = 0, time.perf_counter()
-        while True:
-            cpu_step()
-            n_it += 1
-            el = time.perf_counter() - t_c0
-            if el > 12.0 or n_it >= 8:
-                break
-        cpu_baseline = dict(value=round(bs * n_it / el, 3), unit="fields/s", cores=ncores, kind="port",
-                            sample=f"oracle fwd+loss+bwd on {bs} fields of the same shape, {n_it} iters, "
-                                   f"{el:.1f}s, torch {torch.get_num_threads()} threads")
+        # torch's CPU FFT/einsum stop scaling (and then degrade badly) long before a many-core
+        # host is full: measured on the 256-core GPU box, 8 threads 22.9 fields/s, 64 threads
+        # 6.7, 256 threads 0.02.  Time a short sweep and keep the best; `cores` reports the
+        # thread count actually used for the quoted number.
+        best = None
+        for nthr in [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]:
+            torch.set_num_threads(nthr)
+            cpu_step()                                   # warm-up at this thread count
+            n_it, t_c0 = 0, time.perf_counter()
+            while True:
+                cpu_step()
+                n_it += 1
+                el = time.perf_counter() - t_c0
+                if el > 3.0 or n_it >= 12:
+                    break
+            rate = bs * n_it / el
+            if best is None or rate > best[0]:
+                best = (rate, nthr, n_it, el)
+        rate, nthr, n_it, el = best
+        cpu_baseline = dict(value=round(rate, 3), unit="fields/s", cores=nthr, kind="port",
+                            sample=f"oracle (CPU restatement of the reference, torch ops) zero_grad+fwd+LpLoss+bwd on "
+                                   f"{bs} fields of the same shape; best of a 4/8/16/32-thread sweep on a "
+                                   f"{ncores}-core host: {nthr} threads, {n_it} iters in {el:.1f}s")
 
     if rank == 0:
         out = {

@@ -123,7 +123,7 @@ struct Tables {
   float* tfwd_b = nullptr;   // same, gamma-weighted (transform of gradients)
   float* tinv_f = nullptr;   // (J, W) gamma * s_i * (cos, -sin)
   float* tinv_b = nullptr;   // (J, W) s_f * (cos, -sin)
-  float2* tw_fwd_sf[2] = {nullptr, nullptr};  // leading dim d: (Klead, N) e^{-i}, d==0 scaled by s_f
+  float2* tw_fwd_sf[2] = {nullptr, nullptr};  // leading dim d: TRANSPOSED (N, Klead) e^{-i}, d==0 scaled by s_f
   float2* tw_fwd_si[2] = {nullptr, nullptr};  // d==0 scaled by s_i (gradient direction)
   float2* tw_inv[2] = {nullptr, nullptr};     // (N, Klead) e^{+i}
   std::vector<void*> owned;
@@ -205,8 +205,8 @@ static int make_tables(const Geom& g, Tables& t) {
         const double ang = PI2 * (double)((long long)freq * n % N) / N;
         const double c = std::cos(ang), s = std::sin(ang);
         const double sa = d == 0 ? g.s_f : 1.0, sb = d == 0 ? g.s_i : 1.0;
-        a[(size_t)r * N + n] = make_float2((float)(sa * c), (float)(-sa * s));
-        b[(size_t)r * N + n] = make_float2((float)(sb * c), (float)(-sb * s));
+        a[(size_t)n * K + r] = make_float2((float)(sa * c), (float)(-sa * s));
+        b[(size_t)n * K + r] = make_float2((float)(sb * c), (float)(-sb * s));
         inv[(size_t)n * K + r] = make_float2((float)c, (float)s);
       }
     }
@@ -243,11 +243,17 @@ static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
 }
 
 
-static int axis_pass(hipStream_t st, const float* in, float* out, const float2* tw, int outer, int n_in, int n_out,
-                     int inner) {
-  if (outer > 65535 || n_out > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d,%d)", outer, n_out);
-  dim3 grid((inner + 255) / 256, n_out, outer);
-  return launch("k_axis_pass", k_axis_pass, grid, dim3(256), 0, st, (const float2*)in, (float2*)out, tw, n_in, n_out,
+// many -> few (twT transposed (n_in, n_out)) or few -> many (tw (n_out, n_in))
+static int axis_pass(hipStream_t st, bool truncating, const float* in, float* out, const float2* tw, int outer,
+                     int n_in, int n_out, int inner) {
+  if (outer > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d)", outer);
+  if (truncating) {
+    dim3 grid((inner + 63) / 64, outer, (n_out + 7) / 8);
+    return launch("k_axis_fwd", k_axis_fwd, grid, dim3(64, 8), 0, st, (const float2*)in, (float2*)out, tw, n_in,
+                  n_out, inner);
+  }
+  dim3 grid((inner + 63) / 64, outer);
+  return launch("k_axis_inv", k_axis_inv, grid, dim3(64, 16), 0, st, (const float2*)in, (float2*)out, tw, n_in, n_out,
                 inner);
 }
 
@@ -255,16 +261,16 @@ static int axis_pass(hipStream_t st, const float* in, float* out, const float2* 
 static int lead_forward(hipStream_t st, const Geom& g, const Tables& t, bool grad_dir, int B, int C, const float* x1,
                         float* tmp, float* hat) {
   const float2* tw0 = grad_dir ? t.tw_fwd_si[0] : t.tw_fwd_sf[0];
-  if (g.nlead == 1) return axis_pass(st, x1, hat, tw0, B, g.dims[0], g.Klead[0], g.Klast * C);
-  LAUNCHCHK(axis_pass(st, x1, tmp, t.tw_fwd_sf[1], B * g.dims[0], g.dims[1], g.Klead[1], g.Klast * C));
-  return axis_pass(st, tmp, hat, tw0, B, g.dims[0], g.Klead[0], g.Klead[1] * g.Klast * C);
+  if (g.nlead == 1) return axis_pass(st, true, x1, hat, tw0, B, g.dims[0], g.Klead[0], g.Klast * C);
+  LAUNCHCHK(axis_pass(st, true, x1, tmp, t.tw_fwd_sf[1], B * g.dims[0], g.dims[1], g.Klead[1], g.Klast * C));
+  return axis_pass(st, true, tmp, hat, tw0, B, g.dims[0], g.Klead[0], g.Klead[1] * g.Klast * C);
 }
 // inverse passes: hat [B][K..][Klast][C] -> z [B][lead..][Klast][C]
 static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, int C, const float* hat, float* tmp,
                         float* z) {
-  if (g.nlead == 1) return axis_pass(st, hat, z, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klast * C);
-  LAUNCHCHK(axis_pass(st, hat, tmp, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klead[1] * g.Klast * C));
-  return axis_pass(st, tmp, z, t.tw_inv[1], B * g.dims[0], g.Klead[1], g.dims[1], g.Klast * C);
+  if (g.nlead == 1) return axis_pass(st, false, hat, z, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klast * C);
+  LAUNCHCHK(axis_pass(st, false, hat, tmp, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klead[1] * g.Klast * C));
+  return axis_pass(st, false, tmp, z, t.tw_inv[1], B * g.dims[0], g.Klead[1], g.dims[1], g.Klast * C);
 }
 
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
@@ -542,10 +548,10 @@ extern "C" size_t fno_model_saved_bytes(const FnoModelPlan* p, int B) {
 // ---- templated launch dispatch ---------------------------------------------
 template <int CIN, int COUT>
 static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a, const char* name) {
-  const size_t rows = std::max((CIN + 1) & ~1, COUT);
+  const size_t lds = pw_fwd_lds_bytes(CIN, COUT, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   if (p->NPX == 128)
-    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3((COUT / 32) * 4 * 64), rows * 132 * 4, st, a);
-  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3((COUT / 32) * 8 * 64), rows * 260 * 4, st, a);
+    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3((COUT / 32) * 4 * 64), lds, st, a);
+  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3((COUT / 32) * 8 * 64), lds, st, a);
 }
 static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const int C = p->d.C;
@@ -567,11 +573,12 @@ static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const P
 }
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
+  const size_t pitch = p->NPX + 4;
+  const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
+                      (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0)) * 4;
   if (p->NPX == 128)
-    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
-                  (size_t)(2 * C + 8) * 132 * 4, st, a);
-  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64),
-                (size_t)(2 * C + 8) * 260 * 4, st, a);
+    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
+  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);
 }
 static int launch_bbwd(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   return p->d.C == 32 ? launch_bbwd_c<32>(p, st, grid, a) : launch_bbwd_c<64>(p, st, grid, a);

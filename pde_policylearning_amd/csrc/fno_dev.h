@@ -107,6 +107,7 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
     const float* tf = tfwd + (size_t)(jt * 16 + l15) * W + quad;
     const float* xr = tile + (nt * 16 + l15) * PITCH + rr * W + quad;
+#pragma unroll 4
     for (int s = 0; s < W / 4; s += 2) {       // two independent accumulation chains
       d0 = mfma16(tf[4 * s], xr[4 * s], d0);
       d1 = mfma16(tf[4 * s + 4], xr[4 * s + 4], d1);
@@ -122,3 +123,31 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
     }
   }
 }
+
+// Register-staged prefetch of a tile's rows: issue() starts the HBM loads for the NEXT tile,
+// commit() (one iteration later) applies the optional GELU and writes them to LDS.
+template <int NPX, int NT, int NROWS, int NROWS_PAD>
+struct TilePrefetch {
+  static constexpr int PITCH = NPX + 4;
+  static constexpr int TOTAL = NROWS_PAD * (NPX / 4);
+  static constexpr int ITER = (TOTAL + NT - 1) / NT;
+  float4 v[ITER];
+  FNO_DEV void issue(const float* src, size_t row_stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
+      v[i] = (idx < TOTAL && c < NROWS) ? ld4(src + (size_t)c * row_stride + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  FNO_DEV void commit(float* dst, bool act, int tid) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
+      float4 t = v[i];
+      if (act) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
+      if (idx < TOTAL) st4(dst + c * PITCH + 4 * q, t);
+    }
+  }
+};

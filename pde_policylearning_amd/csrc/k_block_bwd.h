@@ -19,7 +19,7 @@
 #include "fno_dev.h"
 
 #ifndef FNO_OCC_BB
-#define FNO_OCC_BB 4
+#define FNO_OCC_BB 2   // measured: 2 (no spills, 1 workgroup/CU) beats 4 (spills) on MI355X
 #endif
 
 struct BlkBwdArgs {
@@ -65,7 +65,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gs = smem;                 // C x PITCH : g, later the gout tile
   float* us = smem + C * PITCH;     // C x PITCH : u_l, then a_l in place
-  float* xls = us + C * PITCH;      // 8 x PITCH : lifting input rows
+  float* xls = us + C * PITCH;      // 8 x PITCH : lifting input rows (block 0 only)
+  float* tinv_s = xls + (a.xin ? 8 * PITCH : 0);   // 2*K2in x W : row inverse table (if zg)
+  const int R = NPX / a.W;
+  float* zs = tinv_s + (a.zg ? 2 * a.K2in * a.W : 0);   // R x K2in x C x 2 : this tile's spectral gradient rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -74,6 +77,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   const int n0 = nt * 32;
   const int dtl = wave % TILES, dkp = wave / TILES;     // dW job
   const int dmt = dtl / MT, dnt = dtl % MT;
+
+  if (a.zg)
+    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
+  const int zcount4 = a.zg ? R * a.K2in * C / 2 : 0;
 
   // A fragments of W^T: A[i][k = o] = W[o][i]
   float afrag[KS];
@@ -93,8 +100,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     const float* gb = a.g + (size_t)b * C * a.PW + px0;
     const float* ub = a.uin + (size_t)b * C * a.PW + px0;
+    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
     stage_rows_t<NPX, NT, C>(gs, gb, a.PW, false, tid);
     stage_rows_t<NPX, NT, C>(us, ub, a.PW, false, tid);
+    if (tid < zcount4) st4(zs + 4 * tid, zv);
     if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
     __syncthreads();
 
@@ -113,29 +123,29 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 #pragma unroll
     for (int s = 0; s < KS; ++s) acc = mfma32(afrag[s], gs[(2 * s + half) * PITCH + n0 + l31], acc);
     if (a.zg) {
-      const int prow = (px0 + n0) / a.W;
-      const int wcol = (px0 + n0) % a.W + l31;
-      const float* zr = a.zg + (((size_t)b * a.P + prow) * a.K2in * C + mt * 32 + l31) * 2 + half;
-      const float* tv = a.tinv + (size_t)half * a.W + wcol;
-      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[(size_t)s * C * 2], tv[(size_t)2 * s * a.W], acc);
+      const float* zr = zs + (((n0 / a.W) * a.K2in) * C + mt * 32 + l31) * 2 + half;
+      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+#pragma unroll 2
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
     }
     // ---- activation derivative; us becomes a_l = act(u_l) in place --------
     // (each (i, px) element of us is touched only by the lane that owns it)
     {
       float* up = us + (mt * 32 + 4 * half) * PITCH + n0 + l31;
       float* gp = a.gout ? a.gout + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
+      if (a.act_in) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = (r & 3) + 8 * (r >> 2);          // acc_row32(r, half) - 4 * half
-        float v = acc[r];
-        if (a.act_in) {
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);          // acc_row32(r, half) - 4 * half
           float gl, dg;
           gelu_both(up[ro * PITCH], gl, dg);
-          v *= dg;
+          acc[r] *= dg;
           up[ro * PITCH] = gl;
         }
-        acc[r] = v;
-        if (gp) gp[(size_t)ro * a.PW] = v;
+      }
+      if (gp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gp[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[r];
       }
     }
     __syncthreads();

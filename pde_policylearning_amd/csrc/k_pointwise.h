@@ -2,9 +2,10 @@
 //
 // One workgroup owns a tile of NPX consecutive pixels of one sample's (P x W)
 // plane, for ALL channels; wave (mt, nt) owns the 32x32 output sub-tile
-// (channels 32*mt.., pixels 32*nt..).  Per tile (persistent grid-stride loop):
-//   1. stage x[b, 0:CIN, tile] HBM -> LDS (16 B/lane coalesced), applying the
-//      previous block's GELU on load when act_in (activations are stored
+// (channels 32*mt.., pixels 32*nt..).  Per tile (persistent grid-stride loop, the
+// NEXT tile's HBM loads are in flight while the current one is computed):
+//   1. stage x[b, 0:CIN, tile] HBM -> registers -> LDS (16 B/lane coalesced), applying
+//      the previous block's GELU on the way when act_in (activations are stored
 //      PRE-activation so that backward never needs a second copy);
 //   2. D[o][px] = sum_c W[o][c] a[c][px]                      (fp32 MFMA 32x32x2)
 //               + sum_j Z[b,row,j,o] * Tinv[j][w]             (row inverse DFT folded in
@@ -13,7 +14,8 @@
 //   3. u = D is written to HBM; act_out(u) goes back to LDS;
 //   4. row forward DFT of the tile, truncated to the kept bins, on fp32 MFMA
 //      16x16x4:  X1[b,row,k2,o] = sum_w a[o][w] * Tfwd[j][w]   -> HBM (small).
-// So a whole FNO block costs one read and one write of the activation.
+// So a whole FNO block costs one read and one write of the activation.  Twiddle
+// tables live in LDS for the lifetime of the workgroup.
 //
 // Replaces, for the reference's default FNO path: Lifting (tfno.py:19-20), the
 // skip conv + residual add + GELU of FNOBlocks.forward (fno_block.py:131,147-150),
@@ -40,6 +42,15 @@ struct PwFwdArgs {
   int tiles_per_plane, ntiles;
 };
 
+// dynamic LDS bytes needed by k_pw_fwd<CIN, COUT, NPX>
+static inline size_t pw_fwd_lds_bytes(int cin, int cout, int npx, int W, int K2in, int NJ, bool has_z, bool has_x1) {
+  const int rows = ((cin + 1) & ~1) > cout ? ((cin + 1) & ~1) : cout;
+  size_t fl = (size_t)rows * (npx + 4);
+  if (has_z) fl += (size_t)2 * K2in * W + (size_t)(npx / W) * K2in * cout * 2;
+  if (has_x1) fl += (size_t)16 * NJ * W;
+  return fl * 4;
+}
+
 template <int CIN, int COUT, int NPX>
 __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;          // pixel sub-tiles
@@ -49,15 +60,25 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
   constexpr int CINP = (CIN + 1) & ~1;
   constexpr int KS = CINP / 2;
   constexpr int PITCH = NPX + 4;
+  constexpr int ROWS = CINP > COUT ? CINP : COUT;
   static_assert(COUT % 32 == 0 && NPX % 32 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;  // max(CINP, COUT) rows of PITCH floats
+  float* xs = smem;                                   // ROWS x PITCH
+  float* tinv_s = xs + ROWS * PITCH;                  // 2*K2in x W          (if z)
+  const int R = NPX / a.W;
+  float* zs = tinv_s + (a.z ? 2 * a.K2in * a.W : 0);  // R x K2in x COUT x 2 (if z)
+  float* tfwd_s = zs + (a.z ? R * a.K2in * COUT * 2 : 0);   // 16*NJ x W     (if x1)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int mt = wave / NTN, nt = wave % NTN;
   const int n0 = nt * 32;
   const bool has_conv = a.x != nullptr;
+
+  if (a.z)
+    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
+  if (a.x1)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[i] = a.tfwd[i];
 
   // weight fragments: A[i = o][k = c], constant over all tiles of this workgroup
   float afrag[KS];
@@ -67,17 +88,25 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
     afrag[s] = (has_conv && c < CIN) ? a.w[(mt * 32 + l31) * CIN + c] : 0.0f;
   }
 
+  const int zcount4 = a.z ? R * a.K2in * COUT / 2 : 0;   // float4 pieces of one tile's Z rows
+  TilePrefetch<NPX, NT, CIN, CINP> pf;
+  float4 zpf = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto issue = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    if (has_conv) pf.issue(a.x + (size_t)b * CIN * a.PW + px0, a.PW, tid);
+    if (tid < zcount4) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * COUT * 2 + 4 * tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
 
-    if (has_conv) {
-      if (CIN == CINP)
-        stage_rows_t<NPX, NT, CINP>(xs, a.x + (size_t)b * CIN * a.PW + px0, a.PW, a.act_in != 0, tid);
-      else
-        stage_rows<NPX, NT>(xs, a.x + (size_t)b * CIN * a.PW + px0, a.PW, CIN, CINP, a.act_in != 0, tid);
-    }
+    if (has_conv) pf.commit(xs, a.act_in != 0, tid);
+    if (tid < zcount4) st4(zs + 4 * tid, zpf);
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);   // overlaps everything below
 
     f32x16 acc;
 #pragma unroll
@@ -87,11 +116,11 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
       for (int s = 0; s < KS; ++s) acc = mfma32(afrag[s], xs[(2 * s + half) * PITCH + n0 + l31], acc);
     }
     if (a.z) {
-      const int prow = (px0 + n0) / a.W;
-      const int wcol = (px0 + n0) % a.W + l31;
-      const float* zr = a.z + (((size_t)b * a.P + prow) * a.K2in * COUT + mt * 32 + l31) * 2 + half;
-      const float* tv = a.tinv + (size_t)half * a.W + wcol;
-      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[(size_t)s * COUT * 2], tv[(size_t)2 * s * a.W], acc);
+      const int rr = n0 / a.W;
+      const float* zr = zs + ((rr * a.K2in) * COUT + mt * 32 + l31) * 2 + half;
+      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+#pragma unroll 2
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * COUT * 2], tv[2 * s * a.W], acc);
     }
     __syncthreads();  // all waves are done reading the staged input
 
@@ -100,17 +129,27 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
       float* up = a.u ? a.u + ((size_t)b * COUT + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
       float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
       const float* bp = a.bias ? a.bias + mt * 32 + 4 * half : nullptr;
+      if (bp) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = (r & 3) + 8 * (r >> 2);          // acc_row32(r, half) - 4 * half
-        const float v = acc[r] + (bp ? bp[ro] : 0.0f);
-        if (up) up[(size_t)ro * a.PW] = v;
-        if (a.x1) xp[ro * PITCH] = a.act_out ? gelu_f(v) : v;
+        for (int r = 0; r < 16; ++r) acc[r] += bp[(r & 3) + 8 * (r >> 2)];   // row acc_row32(r, half)
+      }
+      if (up) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[r];
+      }
+      if (a.x1) {
+        if (a.act_out) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = gelu_f(acc[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
+        }
       }
     }
     if (a.x1) {
       __syncthreads();
-      row_dft_epilogue<COUT, NPX, NW>(xs, a.tfwd, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
   }

@@ -9,7 +9,7 @@
 #define FNO_OCC_PF 4
 #endif
 #ifndef FNO_OCC_PB
-#define FNO_OCC_PB 4
+#define FNO_OCC_PB 2   // measured: 2 (no spills, 1 workgroup/CU) beats 4 (spills) on MI355X
 #endif
 
 // W1 (HID, C) row-major -> MFMA A-fragment order so that a wave reads its

@@ -13,22 +13,92 @@
 #include "fno_dev.h"
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_axis_pass(const float2* __restrict__ in, float2* __restrict__ out,
-                                                   const float2* __restrict__ tw, int n_in, int n_out, int inner) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y, o = blockIdx.z;
-  if (q >= inner) return;
-  const float2* src = in + (size_t)o * n_in * inner + q;
-  const float2* t = tw + (size_t)r * n_in;
-  float sr = 0.f, si = 0.f;
-#pragma unroll 4
-  for (int n = 0; n < n_in; ++n) {
-    const float2 v = src[(size_t)n * inner];
-    const float2 w = t[n];
-    sr = fmaf(w.x, v.x, sr); sr = fmaf(-w.y, v.y, sr);
-    si = fmaf(w.x, v.y, si); si = fmaf(w.y, v.x, si);
+// Truncating pass (many -> few):  out[o][r][q] = sum_n twT[n][r] * in[o][n][q],  n_out small.
+// Each thread keeps up to 8 complex outputs of one column q in registers; the n range is
+// split over 8 waves (loads of one wave are all in flight together) and combined through
+// LDS.  twT is wave-uniform -> scalar loads.
+//   block (64, 8), grid (ceil(inner/64), outer, ceil(n_out/8))
+__global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
+                                                  const float2* __restrict__ twT, int n_in, int n_out, int inner) {
+  __shared__ float2 sh[8][8][64];
+  const int ql = threadIdx.x, seg = threadIdx.y;
+  const int q = blockIdx.x * 64 + ql;
+  const int o = blockIdx.y;
+  const int r0 = blockIdx.z * 8;
+  const int nr = min(8, n_out - r0);
+  float2 acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = make_float2(0.f, 0.f);
+  if (q < inner) {
+    const float2* src = in + (size_t)o * n_in * inner + q;
+    for (int nb = seg; nb < n_in; nb += 64) {
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = nb + 8 * j;
+        v[j] = (n < n_in) ? src[(size_t)n * inner] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = nb + 8 * j;
+        if (n < n_in) {
+          const float2* t = twT + (size_t)n * n_out + r0;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if (r < nr) {
+              const float2 w = t[r];
+              acc[r].x = fmaf(w.x, v[j].x, acc[r].x); acc[r].x = fmaf(-w.y, v[j].y, acc[r].x);
+              acc[r].y = fmaf(w.x, v[j].y, acc[r].y); acc[r].y = fmaf(w.y, v[j].x, acc[r].y);
+            }
+          }
+        }
+      }
+    }
   }
-  out[((size_t)o * n_out + r) * inner + q] = make_float2(sr, si);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) sh[seg][r][ql] = acc[r];
+  __syncthreads();
+  if (q < inner && seg < nr) {
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sx += sh[k][seg][ql].x; sy += sh[k][seg][ql].y; }
+    out[((size_t)o * n_out + r0 + seg) * inner + q] = make_float2(sx, sy);
+  }
+}
+
+// Expanding pass (few -> many):  out[o][r][q] = sum_k tw[r][k] * in[o][k][q],  n_in small.
+// Each thread holds its column's (<= 16 per chunk) inputs in registers and sweeps its share
+// of r (16 waves per block share the sweep).
+//   block (64, 16), grid (ceil(inner/64), outer)
+__global__ void __launch_bounds__(1024) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
+                                                   const float2* __restrict__ tw, int n_in, int n_out, int inner) {
+  const int ql = threadIdx.x, seg = threadIdx.y;
+  const int q = blockIdx.x * 64 + ql;
+  const int o = blockIdx.y;
+  if (q >= inner) return;
+  for (int k0 = 0; k0 < n_in; k0 += 16) {
+    const int nk = min(16, n_in - k0);
+    float2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      v[k] = (k < nk) ? in[((size_t)o * n_in + k0 + k) * inner + q] : make_float2(0.f, 0.f);
+#pragma unroll 2
+    for (int r = seg; r < n_out; r += 16) {
+      const float2* t = tw + (size_t)r * n_in + k0;
+      float sr = 0.f, si = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < nk) {
+          const float2 w = t[k];
+          sr = fmaf(w.x, v[k].x, sr); sr = fmaf(-w.y, v[k].y, sr);
+          si = fmaf(w.x, v[k].y, si); si = fmaf(w.y, v[k].x, si);
+        }
+      }
+      float2* dst = out + ((size_t)o * n_out + r) * inner + q;
+      if (k0 > 0) { const float2 p = *dst; sr += p.x; si += p.y; }
+      *dst = make_float2(sr, si);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

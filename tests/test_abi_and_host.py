@@ -1,0 +1,99 @@
+"""CPU-side checks (no GPU): the C-ABI library builds/loads and exports every symbol
+include/fnoengine.h declares; the host modules mirror the reference surface; the product
+path refuses to run without a GPU instead of silently falling back."""
+import ctypes
+import io
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pde_policylearning_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "fnoengine.h")).read()
+    declared = set(re.findall(r"\b(fno_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    from pde_policylearning_amd import _lib
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fno_version() >= 100
+
+
+def test_struct_layout_matches_header(lib):
+    from pde_policylearning_amd import _lib
+    # FnoSpecDesc: 3 + 3 + 3 + 2 ints ; FnoModelDesc: 6 + 3 + 3 + 2 ints
+    assert ctypes.sizeof(_lib.FnoSpecDesc) == 11 * 4
+    assert ctypes.sizeof(_lib.FnoModelDesc) == 14 * 4
+    assert ctypes.sizeof(_lib.FnoModelParams) == 8 * (2 + 16 + 64 + 1 + 4)
+
+
+def test_plan_rejects_bad_arguments_without_gpu(lib):
+    from pde_policylearning_amd import _lib
+    d = _lib.FnoSpecDesc()
+    d.ndim, d.Cin, d.Cout = 4, 2, 2          # unsupported ndim: refused before any HIP call
+    h = ctypes.c_void_p()
+    rc = lib.fno_spec_plan_create(ctypes.byref(d), ctypes.byref(h))
+    assert rc < 0 and b"ndim" in lib.fno_last_error()
+    d.ndim = 2
+    d.dims[0], d.dims[1] = 8, 8
+    d.modes[0], d.modes[1] = 5, 3            # 2*5 > 8: overlapping corners
+    rc = lib.fno_spec_plan_create(ctypes.byref(d), ctypes.byref(h))
+    assert rc < 0 and b"overlapping" in lib.fno_last_error()
+
+
+def test_fno2d_surface_matches_reference():
+    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
+    m = FNO2d(12, 12, 64, in_channels=3, out_channels=1)
+    # parameter count of the reference model
+    assert sum(p.numel() for p in m.parameters()) == 2393089
+    keys = set(m.state_dict())
+    assert {"lifting.fc.weight", "lifting.fc.bias", "fno_blocks.convs.bias",
+            "fno_blocks.fno_skips.0.weight", "fno_blocks.convs.weight.7.tensor",
+            "projection.fc1.weight", "projection.fc2.bias"} <= keys
+    assert m.fno_blocks.convs.weight[0].tensor.shape == (64, 64, 6, 6, 2)   # n_modes // 2 per dim
+    assert [m.fno_blocks.gelu_after(l) for l in range(4)] == [True, True, False, False]
+    assert sum(p.numel() for p in FNO3d(8, 8, 8, 32).parameters()) == 2110209
+    # torch.save(model) round trip (run_pde_observers.py:313-314)
+    buf = io.BytesIO()
+    pickle.dump(m, buf)
+    m2 = pickle.loads(buf.getvalue())
+    assert torch.equal(m2.lifting.fc.weight, m.lifting.fc.weight)
+
+
+def test_unsupported_configurations_fail_loudly():
+    from pde_policylearning_amd.neuralop.models import FNO, SpectralConv
+    with pytest.raises(NotImplementedError):
+        SpectralConv(4, 4, (8, 8), factorization="tucker")
+    with pytest.raises(NotImplementedError):
+        FNO((8, 8), 32, use_mlp=True)
+    with pytest.raises(NotImplementedError):
+        FNO((8, 8), 32, norm="group_norm")
+
+
+def test_no_cpu_fallback():
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    m = FNO2d(8, 8, 32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_observer_grid_matches_reference_definition():
+    from pde_policylearning_amd.libs.models.fno_models import FNO2dObserver
+    import numpy as np
+    ob = FNO2dObserver(8, 8, 32)
+    g = ob.get_grid((2, 5, 7, 1), torch.device("cpu"))
+    assert g.shape == (2, 5, 7, 2)
+    assert np.allclose(g[0, :, 0, 0].numpy(), np.linspace(0, 1, 5).astype(np.float32))
+    assert np.allclose(g[1, 0, :, 1].numpy(), np.linspace(0, 1, 7).astype(np.float32))

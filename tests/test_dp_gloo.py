@@ -1,0 +1,123 @@
+"""Data-parallel path on CPU (gloo, world_size 2): the flat-bucket all-reduce(SUM) makes
+N-rank training identical to single-process training on the concatenated batch, for the
+sum-reduced loss of run_pde_observers.py:138.  The model evaluated here is the CPU oracle
+(the HIP engine cannot run without a GPU); what is under test is the DP wrapper."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleFNO(nn.Module):
+    """nn.Module facade over oracle.fno_oracle.fno_forward with reference parameter names."""
+
+    def __init__(self, C=8, L=2, modes=(4, 4)):
+        super().__init__()
+        from oracle.detfill import fill_named
+        self.modes, self.L = modes, L
+        half = [m // 2 for m in modes]
+        shapes = {"lifting.fc.weight": (C, 3, 1, 1), "lifting.fc.bias": (C,),
+                  "fno_blocks.convs.bias": (L, C, 1, 1),
+                  "projection.fc1.weight": (16, C, 1, 1), "projection.fc1.bias": (16,),
+                  "projection.fc2.weight": (1, 16, 1, 1), "projection.fc2.bias": (1,)}
+        for l in range(L):
+            shapes[f"fno_blocks.fno_skips.{l}.weight"] = (C, C, 1, 1)
+        for i in range(2 * L):
+            shapes[f"fno_blocks.convs.weight.{i}.tensor"] = (C, C, *half, 2)
+        self.names = list(shapes)
+        self.ps = nn.ParameterList([nn.Parameter(torch.from_numpy(fill_named(k, s, 0.3))) for k, s in shapes.items()])
+
+    def forward(self, x):
+        from oracle import fno_oracle as O
+        return O.fno_forward(dict(zip(self.names, self.ps)), x, self.modes, n_layers=self.L)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.detfill import fill_named
+    from pde_policylearning_amd.trainer import (FlatGradBucket, LpLoss, broadcast_parameters, shard_batch,
+                                                train_step)
+    torch.manual_seed(100 + rank)          # different init per rank: broadcast must fix it
+    model = OracleFNO()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * rank)
+    broadcast_parameters(model)
+    xg = torch.from_numpy(fill_named("dp.x", (4, 3, 16, 16), 1.0))
+    tg = torch.from_numpy(fill_named("dp.t", (4, 1, 16, 16), 1.0))
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    losses = []
+    for _ in range(3):
+        l = train_step(model, bucket, opt, (shard_batch(xg, rank, world),), shard_batch(tg, rank, world),
+                       LpLoss(size_average=False))
+        t = l.clone()
+        dist.all_reduce(t)
+        losses.append(float(t))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    q.put((rank, losses, flat.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_equals_single_process():
+    sys.path.insert(0, ROOT)
+    from oracle.detfill import fill_named
+    from pde_policylearning_amd.trainer import FlatGradBucket, LpLoss, train_step
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch (rank-0 initial parameters)
+    torch.manual_seed(100)
+    model = OracleFNO()
+    xg = torch.from_numpy(fill_named("dp.x", (4, 3, 16, 16), 1.0))
+    tg = torch.from_numpy(fill_named("dp.t", (4, 1, 16, 16), 1.0))
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    ref_losses = [float(train_step(model, bucket, opt, (xg,), tg, LpLoss(size_average=False))) for _ in range(3)]
+    ref_flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()
+    import numpy as np
+    for rank, losses, flat in res:
+        assert np.allclose(losses, ref_losses, rtol=1e-5), (losses, ref_losses)
+        assert np.abs(flat - ref_flat).max() < 2e-6 * max(1.0, np.abs(ref_flat).max())
+    assert np.array_equal(res[0][2], res[1][2])       # replicas stay bit-identical
+
+
+def test_flat_bucket_views_and_single_message():
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    m = nn.Sequential(nn.Linear(3, 4), nn.Linear(4, 2))
+    b = FlatGradBucket(m.parameters())
+    assert b.flat.numel() == sum(p.numel() for p in m.parameters())
+    m(torch.ones(5, 3)).sum().backward()
+    b.check_views()
+    off = 0
+    for p in m.parameters():
+        assert p.grad.data_ptr() == b.flat[off:].data_ptr()
+        off += p.numel()
+    assert float(b.flat.abs().sum()) > 0
+    b.zero()
+    assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
