@@ -48,5 +48,5 @@ def fill_named(name, shape, scale, dtype=np.float32, complex_=False):
         re = unit_fill(shape, name_seed(name + "#re"))
         im = unit_fill(shape, name_seed(name + "#im"))
         out = (re + 1j * im) * scale
-        return out.astype(np.complex64 if dtype == np.float32 else np.complex128)
-    return (unit_fill(shape, name_seed(name)) * scale).astype(dtype)
+        return np.asarray(out, dtype=np.complex64 if dtype == np.float32 else np.complex128).reshape(shape)
+    return np.asarray(unit_fill(shape, name_seed(name)) * scale, dtype=dtype).reshape(shape)

@@ -132,7 +132,7 @@ def refill_parameters(model, std_override=None):
                 v = fill_named(name, tuple(prm.shape), scale, complex_=True)
             else:
                 v = fill_named(name, tuple(prm.shape), scale)
-            prm.copy_(torch.from_numpy(v))
+            prm.copy_(torch.from_numpy(np.asarray(v)).reshape(prm.shape))
     return scales
 
 
@@ -300,6 +300,66 @@ def gen_observer_adam(outdir):
          mean=mean, std=std, y0=y0, losses=np.array(losses), scales=scales)
 
 
+
+
+# ----------------------------------------------------------------------------
+# RNO2d (neuralop/models/rno.py) and the PINO observers (libs/models/pino_models)
+# ----------------------------------------------------------------------------
+def gen_rno(outdir):
+    from neuralop.models import RNO2d
+    cfgs = {"rno2d_small": dict(args=(4, 4, 8, 1), kw=dict(layer_num=2), shp=(2, 2, 16, 16, 1)),
+            "rno2d_shipped": dict(args=(12, 12, 34, 0), kw=dict(layer_num=1), shp=(2, 1, 32, 32, 1))}
+    for cname, c in cfgs.items():
+        torch.manual_seed(0)
+        model = RNO2d(*c["args"], **c["kw"]).eval()       # eval: dropout off (rno.py:89,98,317)
+        scales = refill_parameters(model)
+        x = input_fill(cname + ".x", c["shp"])
+        y = model(x)
+        tgt = input_fill(cname + ".t", tuple(y.shape))
+        loss = _lp_rel_sum(y, tgt)
+        loss.backward()
+        g = grads_of(model)
+        gnorm = {k: np.array([np.sqrt((v.astype(np.float64) ** 2).sum())]) for k, v in g.items()}
+        g = {k: (v if v.size <= 20000 else v.reshape(-1)[:2048].copy()) for k, v in g.items()}
+        save(os.path.join(outdir, f"{cname}.npz"), x=x, target=tgt, y=y, loss=np.array([float(loss.detach())]),
+             grads=g, gnorm=gnorm, scales=scales,
+             shapes={k: np.array(v.shape) for k, v in model.state_dict().items()})
+
+
+def gen_pino(outdir):
+    from libs.models.pino_models.pinobserver import PINObserver2d, PINObserverFullField
+    # PINObserverFullField as run_pde_observers.py:201-207 feeds it: x (B,X,Y,T,1), re (B,1)
+    torch.manual_seed(0)
+    m = PINObserverFullField(plane_num=3, modes1=[4] * 4, modes2=[4] * 4, modes3=[4] * 4, fc_dim=16,
+                             layers=[8] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625])
+    scales = refill_parameters(m)
+    x = input_fill("pinoff.x", (2, 16, 16, 1, 1))
+    re = torch.from_numpy(np.array([[180.0], [395.0]], dtype=np.float32))
+    y = m(x, re)
+    tgt = input_fill("pinoff.t", tuple(y.shape))
+    loss = _lp_rel_sum(y, tgt)
+    loss.backward()
+    g = grads_of(m)
+    save(os.path.join(outdir, "pino_fullfield_small.npz"), x=x, re=re, target=tgt, y=y,
+         loss=np.array([float(loss.detach())]), grads=g, scales=scales,
+         shapes={k: np.array(v.shape) for k, v in m.state_dict().items()})
+    # PINObserver2d as train_pino.py:154-160 builds it (T padded by round(T * 0.0625))
+    torch.manual_seed(0)
+    m = PINObserver2d(modes1=[3] * 4, modes2=[3] * 4, modes3=[3] * 4, fc_dim=16, layers=[8] * 5, in_dim=4,
+                      out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625])
+    scales = refill_parameters(m)
+    x = input_fill("pino2d.x", (2, 12, 12, 16, 4))
+    re = torch.from_numpy(np.array([[0.4], [0.9]], dtype=np.float32))
+    y = m(x, re)
+    tgt = input_fill("pino2d.t", tuple(y.shape))
+    loss = _lp_rel_sum(y, tgt)
+    loss.backward()
+    g = grads_of(m)
+    save(os.path.join(outdir, "pino2d_small.npz"), x=x, re=re, target=tgt, y=y,
+         loss=np.array([float(loss.detach())]), grads=g, scales=scales,
+         shapes={k: np.array(v.shape) for k, v in m.state_dict().items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -310,7 +370,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

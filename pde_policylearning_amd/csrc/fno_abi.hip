@@ -443,6 +443,16 @@ struct FnoModelPlan {
 };
 
 static const int kHID = 256;
+// persistent-grid size per CU of the forward kernels (= workgroups that fit: registers / LDS)
+#ifndef FNO_GRID_LIFT
+#define FNO_GRID_LIFT 3
+#endif
+#ifndef FNO_GRID_PW
+#define FNO_GRID_PW 2
+#endif
+#ifndef FNO_GRID_PF
+#define FNO_GRID_PF 4
+#endif
 
 extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) {
   if (!d || !out) return fail(FNO_EINVAL, "null argument");
@@ -529,8 +539,8 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
     w.db_part = c.take<float>((size_t)s.grid * C);
     w.dwl_part = c.take<float>((size_t)s.grid * C * 16);
     w.dw1_part = c.take<float>((size_t)s.grid * kHID * C);
-    w.db1_part = c.take<float>((size_t)s.grid * kHID);
-    w.dw2_part = c.take<float>((size_t)s.grid * PROJ_MAXCO * kHID);
+    w.db1_part = c.take<float>((size_t)s.grid * 8 * kHID);
+    w.dw2_part = c.take<float>((size_t)s.grid * 8 * PROJ_MAXCO * kHID);
     w.db2_part = c.take<float>((size_t)64 * PROJ_MAXCO);
   }
   w.total = c.off;
@@ -603,10 +613,10 @@ template <int C, int NCO>
 static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
   // LDS: tile + chunk buffer + dy rows + b1 + W2; the final thread-sum reduction reuses the
   // front of it (NW x HID x (1+NCO) floats) and must fit
-  const int nw = p->NPX / 16;
   const int pitch = p->NPX + 4;
-  size_t lds = (size_t)(C + 64) * pitch * 4 + (size_t)(NCO * p->NPX + kHID + NCO * kHID) * 4;
-  lds = std::max(lds, (size_t)nw * kHID * (1 + NCO) * 4);
+  const size_t small = (size_t)(NCO * p->NPX + kHID + NCO * kHID) * 4;
+  size_t lds = (size_t)(C + 128) * pitch * 4 + small;           // double-buffered dP1 chunk
+  if (lds > 160 * 1024) lds = (size_t)(C + 64) * pitch * 4 + small;
   if (p->NPX == 128)
     return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
@@ -650,7 +660,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
   a.act_in = 0; a.act_out = 0;
   a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-  LAUNCHCHK(launch_lift(p, st, s.grid, a));
+  LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
 
   for (int l = 0; l < L; ++l) {
     LAUNCHCHK(spectral_mid_fwd(p, st, B, w, prm->spec_w[l], hats + (size_t)l * s.n_hat));
@@ -666,7 +676,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.act_out = (d.gelu_mask >> l) & 1u;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    LAUNCHCHK(launch_block(p, st, s.grid, a));
+    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, FNO_GRID_PW * p->ncu), a));
   }
 
   // projection (tfno.py:34-38)
@@ -676,8 +686,9 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   pa.x = u + (size_t)L * s.n_act; pa.w1p = w.w1p; pa.b1 = prm->proj_b1; pa.w2 = prm->proj_w2; pa.b2 = prm->proj_b2;
   pa.y = y; pa.PW = g.PW; pa.CO = d.Cout; pa.act_in = (d.gelu_mask >> (L - 1)) & 1u;
   pa.tiles_per_plane = s.tiles_per_plane; pa.ntiles = s.ntiles;
-  if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, s.grid, pa));
-  else LAUNCHCHK(launch_pfwd_c<64>(p, st, s.grid, pa));
+  const int pgrid = std::min(s.ntiles, FNO_GRID_PF * p->ncu);
+  if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, pgrid, pa));
+  else LAUNCHCHK(launch_pfwd_c<64>(p, st, pgrid, pa));
   return FNO_OK;
 }
 
@@ -709,8 +720,8 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
   LAUNCHCHK(reduce_slabs(st, w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C));
-  LAUNCHCHK(reduce_slabs(st, w.db1_part, gr->proj_b1, s.grid, 1, kHID, kHID, kHID));
-  LAUNCHCHK(reduce_slabs(st, w.dw2_part, gr->proj_w2, s.grid, d.Cout, kHID, kHID, kHID));
+  LAUNCHCHK(reduce_slabs(st, w.db1_part, gr->proj_b1, s.grid * (p->NPX / 32), 1, kHID, kHID, kHID));
+  LAUNCHCHK(reduce_slabs(st, w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID));
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
   LAUNCHCHK(reduce_slabs(st, w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout));
 

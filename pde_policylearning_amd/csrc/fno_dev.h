@@ -42,6 +42,27 @@ FNO_DEV void gelu_both(float x, float& g, float& dg) {
 FNO_DEV float gelu_f(float x) { float g, d; gelu_both(x, g, d); return g; }
 FNO_DEV float gelu_grad_f(float x) { float g, d; gelu_both(x, g, d); return d; }
 
+// sum over the 32 lanes of each wave half (lanes 0-31 / 32-63); every lane gets its half's sum.
+// 4 DPP adds (quad xor 1, quad xor 2, row_half_mirror, row_mirror) + one cross-row exchange.
+FNO_DEV float dpp_add_(float v, const int ctrl_sel) {
+  int t;
+  const int iv = __builtin_bit_cast(int, v);
+  switch (ctrl_sel) {
+    case 0: t = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true); break;    // quad_perm [1,0,3,2]
+    case 1: t = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true); break;    // quad_perm [2,3,0,1]
+    case 2: t = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xf, 0xf, true); break;   // row_half_mirror
+    default: t = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xf, 0xf, true); break;  // row_mirror
+  }
+  return v + __builtin_bit_cast(float, t);
+}
+FNO_DEV float half_reduce_sum(float v) {
+  v = dpp_add_(v, 0);
+  v = dpp_add_(v, 1);
+  v = dpp_add_(v, 2);
+  v = dpp_add_(v, 3);
+  return v + __shfl_xor(v, 16, 64);
+}
+
 FNO_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 FNO_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -64,8 +64,12 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a)
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     stage_rows_t<NPX, NT, C>(xs, a.x + (size_t)b * C * a.PW + px0, a.PW, a.act_in != 0, tid);
     __syncthreads();
-    const float* w1p_t = a.w1p;
-    asm volatile("" : "+s"(w1p_t));   // keep the fragment loads inside the tile loop (L2-resident)
+    // an opaque zero offset keeps the (L2-resident) fragment loads inside the tile loop without
+    // hiding the pointer's global address space (a laundered pointer would become FLAT loads,
+    // which also count on lgkmcnt and serialise behind the LDS reads)
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    const float* w1p_t = a.w1p + opq;
     float ysum[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
@@ -114,8 +118,8 @@ struct ProjBwdArgs {
   float* x1g;         // (B, P, K2out, C, 2) or null
   const float* tfwd;  // (16*NJ, W)
   float* dw1_part;    // (gridDim, HID, C)
-  float* db1_part;    // (gridDim, HID)
-  float* dw2_part;    // (gridDim, CO, HID)
+  float* db1_part;    // (gridDim * NPX/32, HID)
+  float* dw2_part;    // (gridDim * NPX/32, CO, HID)
   int PW, W, P, K2out, NJ, CO, act_in, tiles_per_plane, ntiles;
 };
 
@@ -132,34 +136,38 @@ struct ProjBwdCfg {
   static_assert(NW % TILES == 0 && G >= 1 && NCH % G == 0, "projection backward tiling");
 };
 
-// wave (hm, nt) as in k_proj_fwd.  Per 64-row hidden chunk:
-//   A1  recompute P1 (MFMA), gl = gelu(P1) -> LDS, dP1 = gelu'(P1) * (W2^T dy) in registers
-//   A2  dW2 += sum_px gl * dy                      (thread sums over the LDS tile)
-//   A3  dP1 -> LDS;  dx += W1^T dP1, dP1 fed to the MFMA straight from the accumulator
-//       registers (its row index is the k index of this product)
-//   B   db1 += sum_px dP1 (thread sums);  dW1[chunk] += dP1 . a^T  (MFMA, K = pixels) by the
-//       wave group that owns this chunk
+// wave (hm, nt) as in k_proj_fwd.  Per 64-row hidden chunk (ONE barrier per chunk, the dP1
+// chunk is double-buffered in LDS so wave groups run up to a chunk apart):
+//   A1  recompute P1 (MFMA 32x32x2)
+//   E   gl = gelu(P1), dP1 = gelu'(P1) * (W2^T dy); dW2 / db1 contributions are reduced over
+//       the 32 pixels of the wave with DPP adds (no LDS round trip); dP1 -> LDS
+//   A3  dx += W1^T dP1, dP1 fed to the MFMA straight from the accumulator registers (its row
+//       index is the k index of this product)
+//   --- barrier ---
+//   B   dW1[chunk] += dP1 . a^T  (MFMA, K = pixels) by the wave group that owns this chunk,
+//       while the other group already recomputes the next chunk
 template <int C, int HID, int NPX, int NCO>
 __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a) {
+  // the dP1 chunk is double-buffered when two 64 x PITCH buffers fit beside the tile
+  constexpr bool DBUF = ((C + 128) * (NPX + 4) + NCO * NPX + HID + NCO * HID) * 4 <= 160 * 1024;
   using Cfg = ProjBwdCfg<C, HID, NPX>;
   constexpr int NTN = Cfg::NTN, NW = Cfg::NW, MT = Cfg::MT, NCH = Cfg::NCH, TILES = Cfg::TILES, G = Cfg::G,
                 CPW = Cfg::CPW;
   constexpr int NT = NW * 64;
   constexpr int KS = C / 2;
   constexpr int PITCH = NPX + 4;
-  constexpr int TPX = NPX / NW;             // pixels per thread-sum group
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                        // C x PITCH   : a = act(u_L); later the gout tile
-  float* dps = xs + C * PITCH;             // 64 x PITCH  : gelu(P1) then dP1 of the current chunk;
-                                           //               after the chunk loop: dx partials of hm = 1
-  float* douts = dps + 64 * PITCH;         // MAXCO x NPX
-  float* b1s = douts + NCO * NPX;   // HID
-  float* w2s = b1s + HID;                  // MAXCO x HID
+  float* xs = smem;                        // C x PITCH        : a = act(u_L); later the gout tile
+  float* dps = xs + C * PITCH;             // 2 x 64 x PITCH   : dP1 chunks (double-buffered);
+                                           //                    after the chunk loop: dx partials of hm = 1
+  float* douts = dps + (DBUF ? 2 : 1) * 64 * PITCH;     // NCO x NPX
+  float* b1s = douts + NCO * NPX;          // HID
+  float* w2s = b1s + HID;                  // NCO x HID
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15;
   const int hm = wave / NTN, nt = wave % NTN;
   const int n0 = nt * 32;
-  const int hl = tid & 63, qt = tid >> 6;   // thread-sum mapping: hidden row, pixel group
   const int dgrp = wave / TILES, dtl = wave % TILES;
   const int dmt = dtl / MT, dnt = dtl % MT;  // dW1 tile: hidden 32-block, channel 32-block
 
@@ -171,6 +179,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
   for (int k = 0; k < CPW; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dw1acc[k][r] = 0.f;
+  // lane (l15, half) accumulates hidden row  ch*64 + hm*32 + acc_row32(l15, half)  of every chunk
   float sdb1[NCH], sdw2[NCH][NCO];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -191,9 +200,10 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     float dyl[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) dyl[co] = douts[co * NPX + n0 + l31];
-    const float* w1p_t = a.w1p;
-    const float* w1_t = a.w1;
-    asm volatile("" : "+s"(w1p_t), "+s"(w1_t));   // keep weight loads inside the tile loop
+    int opq = 0;
+    asm volatile("" : "+s"(opq));                  // keep weight loads inside the tile loop (see k_proj_fwd)
+    const float* w1p_t = a.w1p + opq;
+    const float* w1_t = a.w1 + opq;
 
     f32x16 acc2[MT];
 #pragma unroll
@@ -203,6 +213,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
+      float* dpb = dps + (DBUF ? (ch & 1) : 0) * 64 * PITCH;
       // ---- A1 ------------------------------------------------------------
       f32x16 acc;
 #pragma unroll
@@ -210,10 +221,14 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
       const float* wp = w1p_t + ((size_t)(ch * 2 + hm) * KS) * 64 + lane;
 #pragma unroll 8
       for (int s = 0; s < KS; ++s) acc = mfma32(wp[s * 64], xs[(2 * s + half) * PITCH + n0 + l31], acc);
+      // ---- E ---------------------------------------------------------------
       {
-        float* dpp = dps + (hm * 32 + 4 * half) * PITCH + n0 + l31;
+        float* dpp = dpb + (hm * 32 + 4 * half) * PITCH + n0 + l31;
         const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
         const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
+        float rdb = 0.f, rdw[NCO];
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) rdw[co] = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = (r & 3) + 8 * (r >> 2);
@@ -222,81 +237,59 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
           for (int co = 0; co < NCO; ++co) t = fmaf(w2p[co * HID + ro], dyl[co], t);
           float gl, dg;
           gelu_both(acc[r] + b1p[ro], gl, dg);
-          dpp[ro * PITCH] = gl;
-          acc[r] = dg * t;
-        }
-      }
-      __syncthreads();
-      // ---- A2: dW2[co][hid] += sum_px gl[hid][px] * dy[co][px] -----------
-      {
-        const float* gr = dps + hl * PITCH + qt * TPX;
-        float t2[NCO];
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) t2[co] = 0.f;
-#pragma unroll
-        for (int j = 0; j < TPX / 4; ++j) {
-          const float4 gv = ld4(gr + 4 * j);
+          const float dp = dg * t;
+          acc[r] = dp;
+          dpp[ro * PITCH] = dp;
+          const float sdp = half_reduce_sum(dp);
+          rdb = (l15 == r) ? sdp : rdb;
 #pragma unroll
           for (int co = 0; co < NCO; ++co) {
-            const float4 dv = ld4(douts + co * NPX + qt * TPX + 4 * j);
-            t2[co] += gv.x * dv.x + gv.y * dv.y + gv.z * dv.z + gv.w * dv.w;
+            const float sg = half_reduce_sum(gl * dyl[co]);
+            rdw[co] = (l15 == r) ? sg : rdw[co];
           }
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
           if (k == ch) {
+            sdb1[k] += rdb;
 #pragma unroll
-            for (int co = 0; co < NCO; ++co) sdw2[k][co] += t2[co];
+            for (int co = 0; co < NCO; ++co) sdw2[k][co] += rdw[co];
           }
       }
-      __syncthreads();
       // ---- A3 --------------------------------------------------------------
       {
-        float* dpp = dps + (hm * 32 + 4 * half) * PITCH + n0 + l31;
         const float* wr = w1_t + (size_t)(ch * 64 + hm * 32 + 4 * half) * C + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = (r & 3) + 8 * (r >> 2);
-          dpp[ro * PITCH] = acc[r];
 #pragma unroll
           for (int mc = 0; mc < MT; ++mc) acc2[mc] = mfma32(wr[ro * C + mc * 32], acc[r], acc2[mc]);
         }
       }
       __syncthreads();
       // ---- B -----------------------------------------------------------------
-      {
-        const float* gr = dps + hl * PITCH + qt * TPX;
-        float s = 0.f;
+      if (dgrp == ch % G) {
+        const float* ga = dpb + (dmt * 32 + l31) * PITCH + 4 * half;
+        const float* ab = xs + (dnt * 32 + l31) * PITCH + 4 * half;
 #pragma unroll
-        for (int j = 0; j < TPX / 4; ++j) {
-          const float4 gv = ld4(gr + 4 * j);
-          s += (gv.x + gv.y) + (gv.z + gv.w);
-        }
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-          if (k == ch) sdb1[k] += s;
-        if (dgrp == ch % G) {
-          const float* ga = dps + (dmt * 32 + l31) * PITCH + 4 * half;
-          const float* ab = xs + (dnt * 32 + l31) * PITCH + 4 * half;
-#pragma unroll
-          for (int k = 0; k < CPW; ++k)
-            if (k == ch / G) {
-              f32x16 dacc = dw1acc[k];
+        for (int k = 0; k < CPW; ++k)
+          if (k == ch / G) {
+            f32x16 dacc = dw1acc[k];
 #pragma unroll 2
-              for (int q = 0; q < NPX / 8; ++q) {
-                const float4 av = ld4(ga + 8 * q);
-                const float4 bv = ld4(ab + 8 * q);
-                dacc = mfma32(av.x, bv.x, dacc);
-                dacc = mfma32(av.y, bv.y, dacc);
-                dacc = mfma32(av.z, bv.z, dacc);
-                dacc = mfma32(av.w, bv.w, dacc);
-              }
-              dw1acc[k] = dacc;
+            for (int q = 0; q < NPX / 8; ++q) {
+              const float4 av = ld4(ga + 8 * q);
+              const float4 bv = ld4(ab + 8 * q);
+              dacc = mfma32(av.x, bv.x, dacc);
+              dacc = mfma32(av.y, bv.y, dacc);
+              dacc = mfma32(av.z, bv.z, dacc);
+              dacc = mfma32(av.w, bv.w, dacc);
             }
-        }
+            dw1acc[k] = dacc;
+          }
       }
-      __syncthreads();
+      if (!DBUF) __syncthreads();   // single buffer: the next chunk overwrites it
     }
+    __syncthreads();   // all dW1 GEMMs done with xs / dps
 
     // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
     if (hm == 1) {
@@ -339,30 +332,15 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     for (int r = 0; r < 16; ++r)
       dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
   }
-  // thread sums: reduce the NW pixel-group threads of each hidden row through LDS
-  __syncthreads();
-  float* red = smem;  // NW x HID x (1 + MAXCO)
+  if ((lane & 16) == 0) {      // lanes 16-31 / 48-63 hold duplicates
+    const size_t slab = (size_t)blockIdx.x * NTN + nt;
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    float* rp = red + ((size_t)(qt * HID + ch * 64 + hl)) * (1 + NCO);
-    rp[0] = sdb1[ch];
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int hid = ch * 64 + hm * 32 + acc_row32(l15, half);
+      a.db1_part[slab * HID + hid] = sdb1[ch];
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) rp[1 + co] = sdw2[ch][co];
-  }
-  __syncthreads();
-  for (int h = tid; h < HID; h += NT) {
-    float s1 = 0.f, s2[NCO];
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) s2[co] = 0.f;
-    for (int q = 0; q < NW; ++q) {
-      const float* rp = red + ((size_t)(q * HID + h)) * (1 + NCO);
-      s1 += rp[0];
-#pragma unroll
-      for (int co = 0; co < NCO; ++co) s2[co] += rp[1 + co];
+      for (int co = 0; co < NCO; ++co)
+        if (co < a.CO) a.dw2_part[(slab * a.CO + co) * HID + hid] = sdw2[ch][co];
     }
-    a.db1_part[(size_t)blockIdx.x * HID + h] = s1;
-#pragma unroll
-    for (int co = 0; co < NCO; ++co)
-      if (co < a.CO) a.dw2_part[((size_t)blockIdx.x * a.CO + co) * HID + h] = s2[co];
   }
 }

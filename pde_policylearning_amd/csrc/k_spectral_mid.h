@@ -21,7 +21,8 @@
 __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
                                                   const float2* __restrict__ twT, int n_in, int n_out, int inner) {
   __shared__ float2 sh[8][8][64];
-  const int ql = threadIdx.x, seg = threadIdx.y;
+  const int ql = threadIdx.x;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);   // one wave per seg: scalar table loads
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
   const int r0 = blockIdx.z * 8;
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in,
 //   block (64, 16), grid (ceil(inner/64), outer)
 __global__ void __launch_bounds__(1024) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int n_in, int n_out, int inner) {
-  const int ql = threadIdx.x, seg = threadIdx.y;
+  const int ql = threadIdx.x;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);   // one wave per seg: scalar table loads
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
   if (q >= inner) return;

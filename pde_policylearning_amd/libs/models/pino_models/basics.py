@@ -1,0 +1,42 @@
+"""Dialect-C spectral convolutions with the reference surface
+(libs/models/pino_models/basics.py:64-96 SpectralConv2d, :99-143 SpectralConv3d): complex64
+parameters weights1..N initialised scale * U[0,1), torch-default ('backward') FFT norm, no bias.
+forward() runs in the HIP engine."""
+import torch
+from torch import nn
+
+from .... import functional as F
+
+
+def _cweight(cin, cout, *modes):
+    return nn.Parameter((1.0 / (cin * cout)) * torch.rand(cin, cout, *modes, dtype=torch.cfloat))
+
+
+class SpectralConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, modes1, modes2):
+        super().__init__()
+        self.in_channels, self.out_channels, self.modes1, self.modes2 = in_channels, out_channels, modes1, modes2
+        self.scale = 1 / (in_channels * out_channels)
+        self.weights1 = _cweight(in_channels, out_channels, modes1, modes2)
+        self.weights2 = _cweight(in_channels, out_channels, modes1, modes2)
+
+    def forward(self, x):
+        return F.spectral_conv(x, [self.weights1, self.weights2], None, (self.modes1, self.modes2), "backward")
+
+
+class SpectralConv3d(nn.Module):
+    def __init__(self, in_channels, out_channels, modes1, modes2, modes3):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.modes1, self.modes2, self.modes3 = modes1, modes2, modes3
+        self.scale = 1 / (in_channels * out_channels)
+        for i in range(1, 5):
+            setattr(self, f"weights{i}", _cweight(in_channels, out_channels, modes1, modes2, modes3))
+
+    def forward(self, x):
+        # reference corner order: weights1 (lo,lo), weights2 (hi,lo), weights3 (lo,hi), weights4 (hi,hi)
+        # (basics.py:125-139); the engine takes (lo,lo), (lo,hi), (hi,lo), (hi,hi).  Only
+        # min(Nz/2+1, modes3) last-dim modes are live (:119,:125-126); the rest get zero gradient.
+        k3 = min(x.shape[-1] // 2 + 1, self.modes3)
+        return F.spectral_conv(x, [self.weights1, self.weights3, self.weights2, self.weights4], None,
+                               (self.modes1, self.modes2, k3), "backward", weight_last_extent=self.modes3)

@@ -1,0 +1,146 @@
+"""PINO observers with the reference surface (libs/models/pino_models/pinobserver.py:
+MultiplicativeNet :14-63, PINObserver2d :129-233, PlanePredHead :236-273,
+PINObserverFullField :276-375).  SpectralConv3d runs in the HIP engine; the channels-last
+Linear / Conv1d(k=1) glue is torch."""
+import math
+
+import torch
+import torch.nn.functional as TF
+from torch import nn
+from torch.nn import init
+
+from .basics import SpectralConv3d
+
+
+def _activation(name):
+    table = {"tanh": torch.tanh, "gelu": TF.gelu, "relu": TF.relu_, "elu": TF.elu_, "leaky_relu": TF.leaky_relu_}
+    if name not in table:
+        raise ValueError(f"{name} is not supported")
+    return table[name]
+
+
+def _pad_last(x, num_pad):
+    return TF.pad(x, (num_pad[0], num_pad[1]), "constant", 0) if max(num_pad) > 0 else x
+
+
+def _unpad_last(x, num_pad):
+    return x[..., num_pad[0]:-num_pad[1]] if max(num_pad) > 0 else x
+
+
+class MultiplicativeNet(nn.Module):
+    """out = B x1 + A x2 + bias, x1 (N, X, Y, T, in1) channels-last, x2 (N, in2) a per-sample code."""
+
+    def __init__(self, in1_features, in2_features, out_features, device=None, dtype=None):
+        super().__init__()
+        self.in1_features, self.in2_features, self.out_features = in1_features, in2_features, out_features
+        self.A = nn.Parameter(torch.empty(out_features, in2_features))
+        self.B = nn.Parameter(torch.empty(out_features, in1_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.A, a=math.sqrt(5))
+        init.kaiming_uniform_(self.B, a=math.sqrt(5))
+        bound = 1 / math.sqrt(self.in1_features)
+        init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input1, input2):
+        if input2.dim() < 2:
+            input2 = input2.unsqueeze(-1)
+        code = (input2 @ self.A.t())[:, None, None, None, :]
+        return input1 @ self.B.t() + code + self.bias
+
+
+class _SpectralStack(nn.Module):
+    """layers of  x <- act(SpectralConv3d(x) + Conv1d_{k=1}(x)), no activation after the last."""
+
+    def _build_stack(self, layers, modes1, modes2, modes3):
+        self.sp_convs = nn.ModuleList([SpectralConv3d(i, o, m1, m2, m3)
+                                       for i, o, m1, m2, m3 in zip(layers, layers[1:], modes1, modes2, modes3)])
+        self.ws = nn.ModuleList([nn.Conv1d(i, o, 1) for i, o in zip(layers, layers[1:])])
+
+    def _run_stack(self, x):
+        b = x.shape[0]
+        sx, sy, sz = x.shape[-3:]
+        last = len(self.ws) - 1
+        for i, (conv, w) in enumerate(zip(self.sp_convs, self.ws)):
+            x = conv(x) + w(x.reshape(b, self.layers[i], -1)).view(b, self.layers[i + 1], sx, sy, sz)
+            if i != last:
+                x = self.act(x)
+        return x
+
+
+def _pad_ratio(pad_ratio):
+    if isinstance(pad_ratio, float):
+        return [pad_ratio, pad_ratio]
+    assert len(pad_ratio) == 2, 'Cannot add padding in more than 2 directions.'
+    return pad_ratio
+
+
+class PINObserver2d(_SpectralStack):
+    def __init__(self, modes1, modes2, modes3, width=16, fc_dim=128, layers=None, in_dim=4, out_dim=1,
+                 act='gelu', pad_ratio=[0., 0.], use_fourier_layer=False):
+        super().__init__()
+        if use_fourier_layer:
+            raise NotImplementedError("use_fourier_layer=True is outside the accelerated hot path")
+        self.pad_ratio = _pad_ratio(pad_ratio)
+        self.modes1, self.modes2, self.modes3, self.in_dim = modes1, modes2, modes3, in_dim
+        self.layers = [width] * 4 if layers is None else layers
+        self.use_fourier_layer, self.fourier_layer1 = False, None
+        self.fc0 = nn.Linear(in_dim, self.layers[0])
+        self.multiplicative_net1 = MultiplicativeNet(self.layers[0], 1, self.layers[0])
+        self._build_stack(self.layers, modes1, modes2, modes3)
+        self.multiplicative_net2 = MultiplicativeNet(self.layers[-1], 1, self.layers[-1])
+        self.fc1 = nn.Linear(self.layers[-1], fc_dim)
+        self.fc2 = nn.Linear(fc_dim, out_dim)
+        self.act = _activation(act)
+
+    def forward(self, x, re):
+        re = re.float()
+        size_z = x.shape[-2]
+        num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
+        x = self.multiplicative_net1(self.fc0(x), re).permute(0, 4, 1, 2, 3)
+        x = self._run_stack(_pad_last(x, num_pad).contiguous())
+        x = _unpad_last(x, num_pad).permute(0, 2, 3, 4, 1)
+        x = self.multiplicative_net2(x, re)
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class PlanePredHead(_SpectralStack):
+    def __init__(self, layers, modes1, modes2, modes3, fc_dim, out_dim, act):
+        super().__init__()
+        self.layers, self.modes1, self.modes2, self.modes3 = layers, modes1, modes2, modes3
+        self._build_stack(layers, modes1, modes2, modes3)
+        self.fc1 = nn.Linear(layers[-1], fc_dim)
+        self.fc2 = nn.Linear(fc_dim, out_dim)
+        self.act = _activation(act)
+
+    def forward(self, x, num_pad, re, multiplicative_net2):
+        x = _unpad_last(self._run_stack(x), num_pad).permute(0, 2, 3, 4, 1)
+        x = multiplicative_net2(x, re)
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class PINObserverFullField(nn.Module):
+    def __init__(self, plane_num, modes1, modes2, modes3, width=16, fc_dim=128, layers=None, in_dim=4, out_dim=1,
+                 act='gelu', pad_ratio=[0., 0.], use_fourier_layer=False):
+        super().__init__()
+        if use_fourier_layer:
+            raise NotImplementedError("use_fourier_layer=True is outside the accelerated hot path")
+        self.plane_num, self.pad_ratio = plane_num, _pad_ratio(pad_ratio)
+        self.modes1, self.modes2, self.modes3 = modes1, modes2, modes3
+        self.max_re, self.in_dim = 1000, in_dim
+        self.layers = [width] * 4 if layers is None else layers
+        self.use_fourier_layer, self.fourier_layer1 = False, None
+        self.fc0 = nn.Linear(in_dim, self.layers[0])
+        self.multiplicative_net1 = MultiplicativeNet(self.layers[0], 1, self.layers[0])
+        self.multiplicative_net2 = MultiplicativeNet(self.layers[-1], 1, self.layers[-1])
+        self.observer_head = PlanePredHead(self.layers, modes1, modes2, modes3, fc_dim, out_dim * plane_num, act)
+
+    def forward(self, x, re):
+        re = re.float() / self.max_re
+        size_z = x.shape[-2]                  # the reference takes the pad size from dim -2 (:353)
+        num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
+        x = self.multiplicative_net1(self.fc0(x), re).permute(0, 4, 1, 2, 3)
+        pred = self.observer_head(_pad_last(x, num_pad).contiguous(), num_pad, re, self.multiplicative_net2)
+        return pred.permute(0, 4, 1, 2, 3)     # (B, planes, X, Y, T)

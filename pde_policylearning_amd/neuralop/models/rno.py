@@ -1,0 +1,196 @@
+"""Recurrent neural operator with the reference surface (neuralop/models/rno.py): dialect-B
+SpectralConv2d (:34-77), SpectralConvWithFC (:80-106), SpectralRegressor (:109-212),
+FourierLayer2d (:215-228), RNO_cell (:231-260), RNO_layer (:263-290), RNO2d (:293-392).
+
+Every spectral convolution runs in the HIP engine (functional.spectral_conv, norm 'ortho',
+full modes1 x modes2 per corner); the pointwise glue (Linear / Conv1d(k=1) / gates) is torch.
+Parameter names and shapes match the reference state_dict."""
+import numpy as np
+import torch
+import torch.nn.functional as TF
+from torch import nn
+
+from ... import functional as F
+
+
+class SpectralConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, modes1, modes2, norm='ortho'):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.modes1, self.modes2, self.norm = modes1, modes2, norm
+        self.fourier_weight = nn.ParameterList(
+            [nn.Parameter(torch.empty(in_channels, out_channels, modes1, modes2, 2)) for _ in range(2)])
+        gain = np.sqrt(in_channels + out_channels) / (in_channels * out_channels)     # rno.py:42-48
+        for w in self.fourier_weight:
+            nn.init.xavier_normal_(w, gain=gain)
+
+    def forward(self, x):
+        if x.shape[-1] != x.shape[-2]:
+            raise RuntimeError("rno.SpectralConv2d transforms with s=(n, n), n = x.shape[-1] (rno.py:66-67): "
+                               "square grids only")
+        return F.spectral_conv(x, list(self.fourier_weight), None, (self.modes1, self.modes2), self.norm)
+
+
+class SpectralConvWithFC(nn.Module):
+    """channels-last: act(spec_conv(dropout(x)) + Linear(x))  (rno.py:92-106)."""
+
+    def __init__(self, in_channels, out_channels, modes1, modes2, n_grid=None, dropout=0.1, norm='ortho',
+                 activation='silu', return_freq=False, debug=False):
+        super().__init__()
+        if return_freq:
+            raise RuntimeError("Not supported return freq")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.spec_conv = SpectralConv2d(in_channels, out_channels, modes1, modes2, norm)
+        self.linear = nn.Linear(in_channels, out_channels)
+        self.activation = nn.SiLU() if activation == 'silu' else nn.ReLU()
+        self.dropout = nn.Dropout(dropout)
+        self.return_freq = False
+
+    def forward(self, x):
+        res = self.linear(x)
+        y = self.spec_conv(self.dropout(x).permute(0, 3, 1, 2).contiguous())
+        return self.activation(y.permute(0, 2, 3, 1) + res)
+
+
+class SpectralRegressor(nn.Module):
+    def __init__(self, in_dim, n_hidden, freq_dim, out_dim, modes, num_spectral_layers=2, n_grid=None,
+                 dim_feedforward=None, spacial_fc=False, spacial_dim=2, return_freq=False,
+                 return_latent=False, normalizer=None, activation='silu', last_activation=True,
+                 dropout=0.1, debug=False):
+        super().__init__()
+        if spacial_dim != 2:
+            raise NotImplementedError("3D not implemented.")
+        if return_freq or return_latent or spacial_fc or normalizer is not None:
+            raise NotImplementedError("SpectralRegressor: only the configuration RNO2d uses is built")
+        activation = 'silu' if activation is None else activation
+        dropout = 0.1 if dropout is None else dropout
+        self.activation = nn.SiLU() if activation == 'silu' else nn.ReLU()
+        dims = [n_hidden] + [freq_dim] * num_spectral_layers
+        self.spectral_conv = nn.ModuleList([
+            SpectralConvWithFC(dims[i], dims[i + 1], modes, modes, n_grid=n_grid, dropout=dropout,
+                               activation=activation) for i in range(num_spectral_layers)])
+        if not last_activation:
+            self.spectral_conv[-1].activation = nn.Identity()
+        self.dim_feedforward = 2 * spacial_dim * freq_dim if dim_feedforward is None else dim_feedforward
+        self.regressor = nn.Sequential(nn.Linear(freq_dim, self.dim_feedforward), self.activation,
+                                       nn.Linear(self.dim_feedforward, out_dim))
+
+    def forward(self, x, edge=None, pos=None, grid=None):
+        for layer in self.spectral_conv:
+            x = layer(x)
+        return self.regressor(x)
+
+
+class FourierLayer2d(nn.Module):
+    def __init__(self, modes1, modes2, width):
+        super().__init__()
+        self.modes1, self.modes2, self.width = modes1, modes2, width
+        self.spec_conv = SpectralConv2d(width, width, modes1, modes2, norm='ortho')
+        self.norm_conv1d = nn.Conv1d(width, width, 1)
+
+    def forward(self, x):
+        b, c, n1, n2 = x.shape
+        return self.spec_conv(x) + self.norm_conv1d(x.reshape(b, c, n1 * n2)).view(b, self.width, n1, n2)
+
+
+class RNO_cell(nn.Module):
+    """GRU cell whose eight linear maps are Fourier layers (rno.py:254-260)."""
+
+    def __init__(self, in_dim, out_dim, modes1, modes2, width):
+        super().__init__()
+        self.modes1, self.modes2, self.width, self.in_dim, self.out_dim = modes1, modes2, width, in_dim, out_dim
+        for i in range(1, 9):
+            setattr(self, f"f{i}", FourierLayer2d(modes1, modes2, width))
+        for i in range(1, 5):
+            setattr(self, f"b{i}", nn.Parameter(torch.normal(torch.tensor(0.), torch.tensor(1.))))
+
+    def forward(self, x, h):
+        z = torch.sigmoid(self.f1(x) + self.f2(h) + self.b1)
+        z2 = torch.sigmoid(self.f7(x) + self.f8(h) + self.b4)
+        r = torch.sigmoid(self.f3(x) + self.f4(h) + self.b2)
+        h_hat = TF.selu(self.f5(x) + self.f6(r * h) + self.b3)
+        return (1. - z) * h + z2 * h_hat
+
+
+class RNO_layer(nn.Module):
+    def __init__(self, in_dim, out_dim, modes1, modes2, width, return_sequences=False):
+        super().__init__()
+        self.modes1, self.modes2, self.width = modes1, modes2, width
+        self.in_dim, self.out_dim, self.return_sequences = in_dim, out_dim, return_sequences
+        self.cell = RNO_cell(in_dim, out_dim, modes1, modes2, width)
+        self.bias_h = nn.Parameter(torch.normal(torch.tensor(0.), torch.tensor(1.)))
+
+    def forward(self, x, h=None):
+        b, steps, _, n1, n2 = x.shape
+        if h is None:
+            h = torch.zeros((b, self.width, n1, n2), device=x.device) + self.bias_h
+        seq = []
+        for t in range(steps):
+            h = self.cell(x[:, t], h)
+            if self.return_sequences:
+                seq.append(h)
+        return torch.stack(seq, dim=1) if self.return_sequences else h
+
+
+class RNO2d(nn.Module):
+    def __init__(self, modes1, modes2, width, recurrent_index, layer_num=3, pad_amount=None, pad_dim='1'):
+        super().__init__()
+        self.modes1 = modes2           # the reference overwrites modes1 with modes2 (rno.py:301-302)
+        self.width, self.pad_amount, self.pad_dim = width, pad_amount, pad_dim
+        self.recurrent_index = recurrent_index
+        self.in_dim, self.out_dim, self.layer_num = 1, 1, layer_num
+        self.input_projection_layer = nn.Linear(self.in_dim, width)
+        nn.init.normal_(self.input_projection_layer.weight, mean=0, std=1)
+        self.layers = nn.ModuleList(
+            [RNO_layer(width, width, modes1, modes2, width, return_sequences=True) for _ in range(layer_num - 1)]
+            + [RNO_layer(width, width, modes1, modes2, width, return_sequences=False)])
+        self.regressor = SpectralRegressor(in_dim=width, n_hidden=width, freq_dim=width, out_dim=self.out_dim,
+                                           modes=modes2, activation='relu', dropout=0.3)
+
+    def _pad(self, x):
+        if not self.pad_amount:
+            return x
+        if self.pad_dim in ('1', 'both'):
+            x = TF.pad(x.transpose(-1, -2), [0, self.pad_amount[0]]).transpose(-1, -2)
+        if self.pad_dim in ('2', 'both'):
+            x = TF.pad(x, [0, self.pad_amount[1]])
+        return x
+
+    def _unpad(self, h):
+        if not self.pad_amount:
+            return h
+        if self.pad_dim in ('1', 'both'):
+            h = h[:, :, :-self.pad_amount[0]]
+        if self.pad_dim in ('2', 'both'):
+            h = h[..., :-self.pad_amount[1]]
+        return h
+
+    def forward_one_step(self, x, v_plane=None, init_hidden_states=None):
+        if init_hidden_states is None:
+            init_hidden_states = [None] * self.layer_num
+        x = self._pad(self.input_projection_layer(x).permute(0, 1, 4, 2, 3))     # (B, T, C, X, Y)
+        finals = []
+        for i, layer in enumerate(self.layers):
+            out = layer(x, init_hidden_states[i])
+            if i < self.layer_num - 1:
+                x = x + out                      # residual over the whole sequence (rno.py:343-345)
+                finals.append(x[:, -1])
+            else:
+                x = out
+                finals.append(x)
+        h = self._unpad(finals[-1]).permute(0, 2, 3, 1)
+        return self.regressor(h), finals
+
+    def predict(self, x, num_steps):
+        outs, states = [], [None] * self.layer_num
+        for _ in range(num_steps):
+            pred, states = self.forward_one_step(x, init_hidden_states=states)
+            outs.append(pred)
+            x = pred.reshape(pred.shape[0], 1, pred.shape[1], pred.shape[2], pred.shape[3])
+        return torch.stack(outs, dim=1)
+
+    def forward(self, x, v_plane=None, timestep=2):
+        return self.predict(x, num_steps=x.shape[1])[:, self.recurrent_index]
+
+    def count_params(self):
+        return int(sum(p.numel() for p in self.parameters() if p.requires_grad))

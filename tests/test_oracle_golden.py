@@ -155,3 +155,54 @@ def test_observer_adam_trajectory():
         loss.backward()
         opt.step()
         assert abs(float(loss) - float(g["losses"][step])) < 2e-5 * abs(float(g["losses"][step]))
+
+
+# ---------------------------------------------------------------------------
+# RNO2d and PINO observers
+# ---------------------------------------------------------------------------
+def _check_model_grads(g, p, loss):
+    loss.backward()
+    for name, ref in g["grads"].items():
+        got = p[name].grad
+        got = (torch.view_as_real(got) if got.is_complex() else got).numpy()
+        if ref.shape != got.shape:
+            got = got.reshape(-1)[:ref.size]
+        assert rel_l2(got, ref) < 5e-5, name
+
+
+@pytest.mark.parametrize("case,args", [("rno2d_small", (4, 4, 8, 1, 2)), ("rno2d_shipped", (12, 12, 34, 0, 1))])
+def test_rno2d(case, args):
+    from oracle import observers_oracle as OO
+    g = load_golden(case)
+    p = rebuild_params(g["scales"], g["shapes"])
+    for v in p.values():
+        v.requires_grad_(True)
+    y = OO.rno2d_forward(p, _t(g["x"]), *args)
+    assert rel_l2(y.detach(), g["y"]) < 1e-5
+    _check_model_grads(g, p, O.lp_loss_rel_sum(y, _t(g["target"])))
+
+
+def _pino_params(g):
+    cn = {k for k in g["shapes"] if "weights" in k}
+    p = rebuild_params(g["scales"], g["shapes"], complex_names=cn)
+    for v in p.values():
+        v.requires_grad_(True)
+    return p
+
+
+def test_pinobserver_fullfield():
+    from oracle import observers_oracle as OO
+    g = load_golden("pino_fullfield_small")
+    p = _pino_params(g)
+    y = OO.pinobserver_fullfield_forward(p, _t(g["x"]), _t(g["re"]), [8] * 5, [(4, 4, 4)] * 4, [0.0, 0.0625])
+    assert rel_l2(y.detach(), g["y"]) < 1e-5
+    _check_model_grads(g, p, O.lp_loss_rel_sum(y, _t(g["target"])))
+
+
+def test_pinobserver2d():
+    from oracle import observers_oracle as OO
+    g = load_golden("pino2d_small")
+    p = _pino_params(g)
+    y = OO.pinobserver2d_forward(p, _t(g["x"]), _t(g["re"]), [8] * 5, [(3, 3, 3)] * 4, [0.0, 0.0625])
+    assert rel_l2(y.detach(), g["y"]) < 1e-5
+    _check_model_grads(g, p, O.lp_loss_rel_sum(y, _t(g["target"])))
