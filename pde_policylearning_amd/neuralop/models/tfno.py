@@ -77,8 +77,26 @@ class FNO(nn.Module):
                     w2=self.projection.fc2.weight, b2=self.projection.fc2.bias,
                     modes=blk.convs.half_n_modes, norm=self.fft_norm)
 
+    def fused_supported(self, x):
+        """Shapes the whole-model fused kernels cover (fno_model_plan_create): hidden width 32/64,
+        <= 4 input / output channels, projection_channels 256, last dim % 32 == 0 and <= 256."""
+        w = x.shape[-1]
+        npx = 256 if w > 128 else 128
+        plane = 1
+        for s in x.shape[2:]:
+            plane *= s
+        return (self.hidden_channels in (32, 64) and self.in_channels <= 4 and self.out_channels <= 4
+                and self.projection_channels == 256 and w % 32 == 0 and w <= 256
+                and npx % w == 0 and plane % npx == 0 and not x.requires_grad)
+
     def forward(self, x):
-        return F.fno_model(x, **self.engine_args())
+        if self.fused_supported(x):
+            return F.fno_model(x, **self.engine_args())
+        # other widths / grids: spectral convolutions on the engine, pointwise glue in torch
+        x = self.lifting(x)
+        for l in range(self.n_layers):
+            x = self.fno_blocks(x, l)
+        return self.projection(x)
 
 
 class FNO2d(FNO):
