@@ -585,7 +585,8 @@ template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   const size_t pitch = p->NPX + 4;
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
-                      (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0)) * 4;
+                      (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
+                      (a.x1g ? (size_t)16 * a.NJ * a.W : 0)) * 4;
   if (p->NPX == 128)
     return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
   return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);

@@ -69,6 +69,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   float* tinv_s = xls + (a.xin ? 8 * PITCH : 0);   // 2*K2in x W : row inverse table (if zg)
   const int R = NPX / a.W;
   float* zs = tinv_s + (a.zg ? 2 * a.K2in * a.W : 0);   // R x K2in x C x 2 : this tile's spectral gradient rows
+  float* tfwd_s = zs + (a.zg ? R * a.K2in * C * 2 : 0);  // 16*NJ x W : row forward table (if x1g)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 
   if (a.zg)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
+  if (a.x1g)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[i] = a.tfwd[i];
   const int zcount4 = a.zg ? R * a.K2in * C / 2 : 0;
 
   // A fragments of W^T: A[i][k = o] = W[o][i]
@@ -95,18 +98,27 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 #pragma unroll
   for (int j = 0; j < LJ; ++j) dl[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // register-staged prefetch: the NEXT tile's g, u and Zg rows are in flight during this tile
+  TilePrefetch<NPX, NT, C, C> pfg, pfu;
+  float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto issue = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, tid);
+    pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
+    if (tid < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    const float* gb = a.g + (size_t)b * C * a.PW + px0;
-    const float* ub = a.uin + (size_t)b * C * a.PW + px0;
-    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
-    stage_rows_t<NPX, NT, C>(gs, gb, a.PW, false, tid);
-    stage_rows_t<NPX, NT, C>(us, ub, a.PW, false, tid);
+    pfg.commit(gs, false, tid);
+    pfu.commit(us, false, tid);
     if (tid < zcount4) st4(zs + 4 * tid, zv);
     if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
     __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
 
     {  // dbias[c] partial: this thread's TPX pixels of row c
       const float* gr = gs + (tid % C) * PITCH + (tid / C) * DBPX;
@@ -174,7 +186,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
         for (int r = 0; r < 16; ++r) gq[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
       }
       __syncthreads();
-      if (a.x1g) row_dft_epilogue<C, NPX, NW>(gs, a.tfwd, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      if (a.x1g) row_dft_epilogue<C, NPX, NW>(gs, tfwd_s, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
       if (a.xin) {
         // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]
 #pragma unroll

@@ -188,15 +188,24 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     for (int co = 0; co < NCO; ++co) sdw2[ch][co] = 0.f;
   }
 
+  TilePrefetch<NPX, NT, C, C> pfx;      // next tile's u_L rows, in flight during this tile
+  if ((int)blockIdx.x < a.ntiles)
+    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
+
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    stage_rows_t<NPX, NT, C>(xs, a.x + (size_t)b * C * a.PW + px0, a.PW, a.act_in != 0, tid);
+    pfx.commit(xs, a.act_in != 0, tid);
     for (int idx = tid; idx < NCO * NPX; idx += NT) {
       const int co = idx / NPX, p = idx % NPX;
       douts[idx] = (co < a.CO) ? a.dy[((size_t)b * a.CO + co) * a.PW + px0 + p] : 0.f;
     }
     __syncthreads();
+    {
+      const int nt2 = tile + gridDim.x;
+      if (nt2 < a.ntiles)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+    }
     float dyl[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) dyl[co] = douts[co * NPX + n0 + l31];
