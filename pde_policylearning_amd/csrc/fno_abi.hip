@@ -451,7 +451,7 @@ static const int kHID = 256;
 #define FNO_GRID_PW 2
 #endif
 #ifndef FNO_GRID_PF
-#define FNO_GRID_PF 4
+#define FNO_GRID_PF 1
 #endif
 
 extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) {
@@ -600,11 +600,9 @@ static int bbwd_ksplit(const FnoModelPlan* p) {
 }
 template <int C, int NCO>
 static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
-  if (p->NPX == 128)
-    return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512),
-                  (size_t)C * 132 * 4 + (size_t)(kHID + NCO * kHID + NCO * 128) * 4, st, a);
-  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024),
-                (size_t)C * 260 * 4 + (size_t)(kHID + NCO * kHID + NCO * 256) * 4, st, a);
+  // no row structure in the projection: always 128-pixel tiles
+  const size_t lds = ((size_t)C * 132 + kHID + NCO * kHID + NCO * 128 + (size_t)kHID * (C + 1)) * 4;
+  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
 }
 template <int C>
 static int launch_pfwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
@@ -612,12 +610,14 @@ static int launch_pfwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
 }
 template <int C, int NCO>
 static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
-  // LDS: tile + chunk buffer + dy rows + b1 + W2; the final thread-sum reduction reuses the
-  // front of it (NW x HID x (1+NCO) floats) and must fit
+  // LDS: tile + dP1 chunk buffer(s) + dy rows + b1 + W2 + resident W1 (rows padded to C+1)
   const int pitch = p->NPX + 4;
-  const size_t small = (size_t)(NCO * p->NPX + kHID + NCO * kHID) * 4;
-  size_t lds = (size_t)(C + 128) * pitch * 4 + small;           // double-buffered dP1 chunk
-  if (lds > 160 * 1024) lds = (size_t)(C + 64) * pitch * 4 + small;
+  // mirrors the constexpr W1LDS / DBUF choices of k_proj_bwd
+  const size_t small = ((size_t)NCO * p->NPX + kHID + NCO * kHID) * 4;
+  const size_t w1b = (size_t)kHID * (C + 1) * 4;
+  const bool w1lds = (size_t)(C + 64) * pitch * 4 + small + w1b <= 160 * 1024;
+  const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + (w1lds ? w1b : 0) <= 160 * 1024;
+  const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + (w1lds ? w1b : 0);
   if (p->NPX == 128)
     return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
@@ -681,13 +681,12 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   }
 
   // projection (tfno.py:34-38)
-  LAUNCHCHK(launch("k_pack_w1", k_pack_w1, dim3((kHID * C + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.w1p, kHID, C));
   ProjFwdArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.x = u + (size_t)L * s.n_act; pa.w1p = w.w1p; pa.b1 = prm->proj_b1; pa.w2 = prm->proj_w2; pa.b2 = prm->proj_b2;
+  pa.x = u + (size_t)L * s.n_act; pa.w1 = prm->proj_w1; pa.b1 = prm->proj_b1; pa.w2 = prm->proj_w2; pa.b2 = prm->proj_b2;
   pa.y = y; pa.PW = g.PW; pa.CO = d.Cout; pa.act_in = (d.gelu_mask >> (L - 1)) & 1u;
-  pa.tiles_per_plane = s.tiles_per_plane; pa.ntiles = s.ntiles;
-  const int pgrid = std::min(s.ntiles, FNO_GRID_PF * p->ncu);
+  pa.tiles_per_plane = g.PW / 128; pa.ntiles = B * pa.tiles_per_plane;
+  const int pgrid = std::min(pa.ntiles, FNO_GRID_PF * p->ncu);
   if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, pgrid, pa));
   else LAUNCHCHK(launch_pfwd_c<64>(p, st, pgrid, pa));
   return FNO_OK;
@@ -709,10 +708,9 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   const float* hats = u + (size_t)(L + 1) * s.n_act;
 
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
-  LAUNCHCHK(launch("k_pack_w1", k_pack_w1, dim3((kHID * C + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.w1p, kHID, C));
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
-  pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.w1p = w.w1p; pb.b1 = prm->proj_b1;
+  pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
   pb.w2 = prm->proj_w2; pb.gout = w.ga; pb.x1g = w.x1; pb.tfwd = p->t.tfwd_b;
   pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;
   pb.PW = g.PW; pb.W = g.W; pb.P = g.P; pb.K2out = g.Klast; pb.NJ = g.NJ; pb.CO = d.Cout;

@@ -6,28 +6,15 @@
 #include "fno_dev.h"
 
 #ifndef FNO_OCC_PF
-#define FNO_OCC_PF 4
+#define FNO_OCC_PF 2
 #endif
 #ifndef FNO_OCC_PB
 #define FNO_OCC_PB 2   // measured: 2 (no spills, 1 workgroup/CU) beats 4 (spills) on MI355X
 #endif
 
-// W1 (HID, C) row-major -> MFMA A-fragment order so that a wave reads its
-// fragments as one fully coalesced 256-B load per k-step:
-//   w1p[((ch*2 + m)*(C/2) + s)*64 + lane] = W1[ch*64 + m*32 + (lane&31)][2*s + (lane>>5)]
-__global__ void k_pack_w1(const float* __restrict__ w1, float* __restrict__ w1p, int HID, int C) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= HID * C) return;
-  const int lane = e & 63;
-  const int s = (e >> 6) % (C / 2);
-  const int m = ((e >> 6) / (C / 2)) & 1;
-  const int ch = (e >> 6) / (C / 2) / 2;
-  w1p[e] = w1[(ch * 64 + m * 32 + (lane & 31)) * C + 2 * s + (lane >> 5)];
-}
-
 struct ProjFwdArgs {
   const float* x;    // (B, C, PW) pre-activation u_L
-  const float* w1p;  // packed W1
+  const float* w1;   // (HID, C) row-major
   const float* b1;   // (HID)
   const float* w2;   // (CO, HID)
   const float* b2;   // (CO)
@@ -37,7 +24,10 @@ struct ProjFwdArgs {
 
 constexpr int PROJ_MAXCO = 4;   // largest supported projection output width
 
-// wave (hm, nt): hidden rows [64*ch + 32*hm, +32) of every chunk ch, pixels [32*nt, +32)
+// wave (hm, nt): hidden rows [64*ch + 32*hm, +32) of every chunk ch, pixels [32*nt, +32).
+// W1 stays in LDS for the lifetime of the (persistent) workgroup, rows padded to C+1 floats so
+// that both the row-per-lane fragment reads here and the channel-per-lane reads of the backward
+// kernel are bank-conflict-free; the next tile's activations are prefetched into registers.
 template <int C, int HID, int NPX, int NCO>
 __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a) {
   constexpr int NTN = NPX / 32;
@@ -45,12 +35,14 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a)
   constexpr int NT = NW * 64;
   constexpr int KS = C / 2;
   constexpr int PITCH = NPX + 4;
+  constexpr int WP = C + 1;
   constexpr int NCH = HID / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                      // C x PITCH
   float* b1s = xs + C * PITCH;           // HID
-  float* w2s = b1s + HID;                // MAXCO x HID
-  float* ysh = w2s + NCO * HID;   // MAXCO x NPX: partial sums of the hm = 1 waves
+  float* w2s = b1s + HID;                // NCO x HID
+  float* ysh = w2s + NCO * HID;          // NCO x NPX: partial sums of the hm = 1 waves
+  float* w1s = ysh + NCO * NPX;          // HID x WP
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int hm = wave / NTN, nt = wave % NTN;
@@ -58,18 +50,22 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a)
 
   for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
   for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
+  for (int i = tid; i < HID * C; i += NT) w1s[(i / C) * WP + i % C] = a.w1[i];
+
+  TilePrefetch<NPX, NT, C, C> pfx;
+  if ((int)blockIdx.x < a.ntiles)
+    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    stage_rows_t<NPX, NT, C>(xs, a.x + (size_t)b * C * a.PW + px0, a.PW, a.act_in != 0, tid);
+    pfx.commit(xs, a.act_in != 0, tid);
     __syncthreads();
-    // an opaque zero offset keeps the (L2-resident) fragment loads inside the tile loop without
-    // hiding the pointer's global address space (a laundered pointer would become FLAT loads,
-    // which also count on lgkmcnt and serialise behind the LDS reads)
-    int opq = 0;
-    asm volatile("" : "+s"(opq));
-    const float* w1p_t = a.w1p + opq;
+    {
+      const int nt2 = tile + gridDim.x;
+      if (nt2 < a.ntiles)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+    }
     float ysum[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
@@ -78,9 +74,10 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wp = w1p_t + ((size_t)(ch * 2 + hm) * KS) * 64 + lane;
-#pragma unroll 8
-      for (int s = 0; s < KS; ++s) acc = mfma32(wp[s * 64], xs[(2 * s + half) * PITCH + n0 + l31], acc);
+      const float* wp = w1s + (ch * 64 + hm * 32 + l31) * WP + half;
+      const float* xp = xs + half * PITCH + n0 + l31;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma32(wp[2 * s], xp[2 * s * PITCH], acc);
       const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
       const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
 #pragma unroll
@@ -111,7 +108,6 @@ struct ProjBwdArgs {
   const float* x;     // (B, C, PW) u_L
   const float* dy;    // (B, CO, PW)
   const float* w1;    // (HID, C) row-major
-  const float* w1p;   // packed W1
   const float* b1;    // (HID)
   const float* w2;    // (CO, HID)
   float* gout;        // (B, C, PW): dL/du_L
@@ -148,8 +144,13 @@ struct ProjBwdCfg {
 //       while the other group already recomputes the next chunk
 template <int C, int HID, int NPX, int NCO>
 __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a) {
-  // the dP1 chunk is double-buffered when two 64 x PITCH buffers fit beside the tile
-  constexpr bool DBUF = ((C + 128) * (NPX + 4) + NCO * NPX + HID + NCO * HID) * 4 <= 160 * 1024;
+  // W1 is resident in LDS (rows padded to C+1 floats: conflict-free both for the row-per-lane
+  // fragments of the recompute and the channel-per-lane fragments of the dx product); the dP1
+  // chunk is double-buffered when two 64 x PITCH buffers still fit beside it
+  constexpr int WP = C + 1;
+  constexpr int kSmall = NCO * NPX + HID + NCO * HID;
+  constexpr bool W1LDS = ((C + 64) * (NPX + 4) + kSmall + HID * WP) * 4 <= 160 * 1024;   // else: W1 from L2
+  constexpr bool DBUF = ((C + 128) * (NPX + 4) + kSmall + (W1LDS ? HID * WP : 0)) * 4 <= 160 * 1024;
   using Cfg = ProjBwdCfg<C, HID, NPX>;
   constexpr int NTN = Cfg::NTN, NW = Cfg::NW, MT = Cfg::MT, NCH = Cfg::NCH, TILES = Cfg::TILES, G = Cfg::G,
                 CPW = Cfg::CPW;
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
   float* douts = dps + (DBUF ? 2 : 1) * 64 * PITCH;     // NCO x NPX
   float* b1s = douts + NCO * NPX;          // HID
   float* w2s = b1s + HID;                  // NCO x HID
+  float* w1s = w2s + NCO * HID;            // HID x WP
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15;
@@ -173,6 +175,8 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
 
   for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
   for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
+  if (W1LDS)
+    for (int i = tid; i < HID * C; i += NT) w1s[(i / C) * WP + i % C] = a.w1[i];
 
   f32x16 dw1acc[CPW];
 #pragma unroll
@@ -209,10 +213,6 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     float dyl[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) dyl[co] = douts[co * NPX + n0 + l31];
-    int opq = 0;
-    asm volatile("" : "+s"(opq));                  // keep weight loads inside the tile loop (see k_proj_fwd)
-    const float* w1p_t = a.w1p + opq;
-    const float* w1_t = a.w1 + opq;
 
     f32x16 acc2[MT];
 #pragma unroll
@@ -227,9 +227,17 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wp = w1p_t + ((size_t)(ch * 2 + hm) * KS) * 64 + lane;
+      if constexpr (W1LDS) {
+        const float* wp = w1s + (ch * 64 + hm * 32 + l31) * WP + half;
+        const float* xp = xs + half * PITCH + n0 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = mfma32(wp[2 * s], xp[2 * s * PITCH], acc);
+      } else {
+        const float* wp = a.w1 + (size_t)(ch * 64 + hm * 32 + l31) * C + half;
+        const float* xp = xs + half * PITCH + n0 + l31;
 #pragma unroll 8
-      for (int s = 0; s < KS; ++s) acc = mfma32(wp[s * 64], xs[(2 * s + half) * PITCH + n0 + l31], acc);
+        for (int s = 0; s < KS; ++s) acc = mfma32(wp[2 * s], xp[2 * s * PITCH], acc);
+      }
       // ---- E ---------------------------------------------------------------
       {
         float* dpp = dpb + (hm * 32 + 4 * half) * PITCH + n0 + l31;
@@ -267,12 +275,15 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
       }
       // ---- A3 --------------------------------------------------------------
       {
-        const float* wr = w1_t + (size_t)(ch * 64 + hm * 32 + 4 * half) * C + l31;
+        constexpr int WS = W1LDS ? WP : C;
+        const float* wr;
+        if constexpr (W1LDS) wr = w1s + (ch * 64 + hm * 32 + 4 * half) * WP + l31;
+        else wr = a.w1 + (size_t)(ch * 64 + hm * 32 + 4 * half) * C + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = (r & 3) + 8 * (r >> 2);
 #pragma unroll
-          for (int mc = 0; mc < MT; ++mc) acc2[mc] = mfma32(wr[ro * C + mc * 32], acc[r], acc2[mc]);
+          for (int mc = 0; mc < MT; ++mc) acc2[mc] = mfma32(wr[ro * WS + mc * 32], acc[r], acc2[mc]);
         }
       }
       __syncthreads();
