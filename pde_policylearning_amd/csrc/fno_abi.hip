@@ -313,6 +313,19 @@ static int reduce_slabs(hipStream_t st, const float* part, float* out, int nslab
                 ld_out, ncols, ld_in);
 }
 
+struct JobList {
+  ReduceJobs jobs;
+  JobList() { jobs.count = 0; }
+  void add(const float* part, float* out, int nslab, int rows, int ncols, int ld_in, int ld_out) {
+    ReduceJob& j = jobs.j[jobs.count++];
+    j.part = part; j.out = out; j.nslab = nslab; j.n = rows * ncols; j.ld_out = ld_out; j.ncols = ncols; j.ld_in = ld_in;
+  }
+  int run(hipStream_t st) {
+    if (jobs.count == 0) return FNO_OK;
+    return launch("k_reduce_jobs", k_reduce_jobs, dim3(64, jobs.count), dim3(64, 16), 0, st, jobs);
+  }
+};
+
 // ==========================================================================
 // standalone spectral convolution
 // ==========================================================================
@@ -534,9 +547,9 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
   if (backward) {
     w.ga = c.take<float>(s.n_act);
     w.gb = c.take<float>(s.n_act);
-    w.dwp = c.take<float>(s.n_wp);
-    w.dw_part = c.take<float>((size_t)s.grid * 8 * C * C);
-    w.db_part = c.take<float>((size_t)s.grid * C);
+    w.dwp = c.take<float>((size_t)p->d.n_layers * s.n_wp);
+    w.dw_part = c.take<float>((size_t)p->d.n_layers * s.grid * ((p->NPX / 32) / (C / 32)) * C * C);
+    w.db_part = c.take<float>((size_t)p->d.n_layers * s.grid * C);
     w.dwl_part = c.take<float>((size_t)s.grid * C * 16);
     w.dw1_part = c.take<float>((size_t)s.grid * kHID * C);
     w.db1_part = c.take<float>((size_t)s.grid * 8 * kHID);
@@ -552,7 +565,7 @@ extern "C" size_t fno_model_workspace_bytes(const FnoModelPlan* p, int B) {
 }
 extern "C" size_t fno_model_saved_bytes(const FnoModelPlan* p, int B) {
   const ModelSizes s = model_sizes(p, B);
-  return ((size_t)(p->d.n_layers + 1) * s.n_act + (size_t)p->d.n_layers * s.n_hat) * sizeof(float);
+  return ((size_t)(p->d.n_layers + 1) * s.n_act + (size_t)p->d.n_layers * (s.n_hat + 2 * s.n_wp)) * sizeof(float);
 }
 
 // ---- templated launch dispatch ---------------------------------------------
@@ -628,13 +641,12 @@ static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
 }
 
 // spectral middle of one block: x1 -> (hat) -> ohat -> z
-static int spectral_mid_fwd(const FnoModelPlan* p, hipStream_t st, int B, const ModelWs& w, const float* const* corners,
+static int spectral_mid_fwd(const FnoModelPlan* p, hipStream_t st, int B, const ModelWs& w, const float* wp,
                             float* hat) {
   const Geom& g = p->g;
   const int C = p->d.C;
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));
-  LAUNCHCHK(pack_w(st, g, C, C, corners, w.wp, w.wpt));
-  LAUNCHCHK(mode_gemm(st, hat, w.wp, w.ohat, B, g.Ktot, C, C, 0));
+  LAUNCHCHK(mode_gemm(st, hat, wp, w.ohat, B, g.Ktot, C, C, 0));
   return lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z);
 }
 
@@ -652,6 +664,18 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   float* u = (float*)saved;                                 // u[l] = u + l * n_act
   float* hats = u + (size_t)(L + 1) * s.n_act;              // hats[l] = hats + l * n_hat
+  float* wps = hats + (size_t)L * s.n_hat;                  // packed weights of every layer (kept for backward)
+  float* wpts = wps + (size_t)L * s.n_wp;
+  {
+    CornerPtrsL cp;
+    memset(&cp, 0, sizeof(cp));
+    for (int l = 0; l < L; ++l)
+      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (const float2*)prm->spec_w[l][c];
+    const ModeMap mm = make_modemap(g, C, C);
+    const size_t n = (size_t)g.Ktot * C * C;
+    LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
+                     (float2*)wps, (float2*)wpts, mm, n));
+  }
 
   // lifting (tfno.py:19-20) + row DFT of its output
   PwFwdArgs a;
@@ -664,7 +688,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
 
   for (int l = 0; l < L; ++l) {
-    LAUNCHCHK(spectral_mid_fwd(p, st, B, w, prm->spec_w[l], hats + (size_t)l * s.n_hat));
+    LAUNCHCHK(spectral_mid_fwd(p, st, B, w, wps + (size_t)l * s.n_wp, hats + (size_t)l * s.n_hat));
     memset(&a, 0, sizeof(a));
     a.x = u + (size_t)l * s.n_act;
     a.w = prm->skip_w[l];
@@ -706,6 +730,8 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   const float* u = (const float*)saved;
   const float* hats = u + (size_t)(L + 1) * s.n_act;
+  const float* wpts = hats + (size_t)L * s.n_hat + (size_t)L * s.n_wp;   // [k][o][i] packed weights from forward
+  JobList jobs;
 
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
   ProjBwdArgs pb;
@@ -718,22 +744,23 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   pb.tiles_per_plane = s.tiles_per_plane; pb.ntiles = s.ntiles;
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
-  LAUNCHCHK(reduce_slabs(st, w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C));
-  LAUNCHCHK(reduce_slabs(st, w.db1_part, gr->proj_b1, s.grid * (p->NPX / 32), 1, kHID, kHID, kHID));
-  LAUNCHCHK(reduce_slabs(st, w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID));
+  jobs.add(w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C);
+  jobs.add(w.db1_part, gr->proj_b1, s.grid * (p->NPX / 32), 1, kHID, kHID, kHID);
+  jobs.add(w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID);
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
-  LAUNCHCHK(reduce_slabs(st, w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout));
+  jobs.add(w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout);
 
   float* gcur = w.ga;   // dL/du_{l+1}
   float* gnext = w.gb;
   const int ks = bbwd_ksplit(p);
   for (int l = L - 1; l >= 0; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
+    float* dwp_l = w.dwp + (size_t)l * s.n_wp;
+    float* dw_part_l = w.dw_part + (size_t)l * s.grid * ks * C * C;
+    float* db_part_l = w.db_part + (size_t)l * s.grid * C;
     LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
-    LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, w.ohat, w.dwp, B, g.Ktot, C, C));
-    LAUNCHCHK(unpack_dw(st, g, C, C, w.dwp, gr->spec_w[l]));
-    LAUNCHCHK(pack_w(st, g, C, C, prm->spec_w[l], w.wp, w.wpt));
-    LAUNCHCHK(mode_gemm(st, w.ohat, w.wpt, w.hat, B, g.Ktot, C, C, 1));
+    LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, w.ohat, dwp_l, B, g.Ktot, C, C));
+    LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
     LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
 
     BlkBwdArgs a;
@@ -743,20 +770,32 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
     a.gout = (l > 0) ? gnext : nullptr;
     a.x1g = (l > 0) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_b;
-    a.dw_part = w.dw_part; a.db_part = w.db_part;
+    a.dw_part = dw_part_l; a.db_part = db_part_l;
     a.xin = (l == 0) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
-    LAUNCHCHK(reduce_slabs(st, w.dw_part, gr->skip_w[l], s.grid * ks, C, C, C, C));
-    if (gr->spec_bias)
-      LAUNCHCHK(reduce_slabs(st, w.db_part, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C));
+    jobs.add(dw_part_l, gr->skip_w[l], s.grid * ks, C, C, C, C);
+    if (gr->spec_bias) jobs.add(db_part_l, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C);
     if (l == 0) {
-      LAUNCHCHK(reduce_slabs(st, w.dwl_part, gr->lift_w, s.grid, C, d.Cin, 16, d.Cin));
-      LAUNCHCHK(reduce_slabs(st, w.dwl_part + d.Cin, gr->lift_b, s.grid, C, 1, 16, 1));
+      jobs.add(w.dwl_part, gr->lift_w, s.grid, C, d.Cin, 16, d.Cin);
+      jobs.add(w.dwl_part + d.Cin, gr->lift_b, s.grid, C, 1, 16, 1);
     }
     float* t = gcur; gcur = gnext; gnext = t;
+  }
+  LAUNCHCHK(jobs.run(st));
+  {
+    CornerPtrsMutL cp;
+    memset(&cp, 0, sizeof(cp));
+    for (int l = 0; l < L; ++l)
+      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (float2*)gr->spec_w[l][c];
+    const ModeMap mm = make_modemap(g, C, C);
+    size_t per = (size_t)g.modes[0] * g.wl_stride;
+    if (g.nlead == 2) per *= g.modes[1];
+    const size_t n = (size_t)(1 << g.nlead) * C * C * per;
+    LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st,
+                     (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C));
   }
   return FNO_OK;
 }

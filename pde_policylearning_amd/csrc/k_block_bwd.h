@@ -257,3 +257,31 @@ __global__ void __launch_bounds__(1024) k_reduce_slabs(const float* __restrict__
     out[(size_t)(e / ncols) * ld_out + e % ncols] = t;
   }
 }
+
+// All slab reductions of one backward pass in ONE launch: blockIdx.y selects the job.
+struct ReduceJob { const float* part; float* out; int nslab, n, ld_out, ncols, ld_in; };
+struct ReduceJobs { ReduceJob j[24]; int count; };
+__global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
+  __shared__ float sh[16][65];
+  const ReduceJob jb = jobs.j[blockIdx.y];
+  const int sy = threadIdx.y;
+  for (int e0 = blockIdx.x * 64; e0 < jb.n; e0 += gridDim.x * 64) {
+    const int e = e0 + threadIdx.x;
+    float s = 0.f;
+    if (e < jb.n) {
+      const int row = e / jb.ncols, col = e % jb.ncols;
+      const size_t slab = (size_t)(jb.n / jb.ncols) * jb.ld_in;
+      const float* p = jb.part + (size_t)row * jb.ld_in + col;
+      for (int k = sy; k < jb.nslab; k += 16) s += p[k * slab];
+    }
+    sh[sy][threadIdx.x] = s;
+    __syncthreads();
+    if (sy == 0 && e < jb.n) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+      jb.out[(size_t)(e / jb.ncols) * jb.ld_out + e % jb.ncols] = t;
+    }
+    __syncthreads();
+  }
+}

@@ -114,6 +114,8 @@ struct ModeMap {
 
 struct CornerPtrs { const float2* p[4]; };
 struct CornerPtrsMut { float2* p[4]; };
+struct CornerPtrsL { const float2* p[16][4]; };      // [layer][corner]
+struct CornerPtrsMutL { float2* p[16][4]; };
 
 __device__ __forceinline__ void mode_decompose(const ModeMap& mm, int k, int& corner, size_t& loc) {
   // k = (k1 * K[1] + k2) * K[2] + k3 (3-D) or k1 * K[1] + klast (2-D)
@@ -180,6 +182,55 @@ __global__ void k_unpack_dw(const float2* __restrict__ dwp, CornerPtrsMut gw, Mo
     v = dwp[((size_t)k * mm.Cin + i) * mm.Cout + o];
   }
   gw.p[corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
+}
+
+// all layers in one launch (blockIdx.y = layer); per-layer outputs are `stride` float2 apart
+__global__ void k_pack_w_layers(CornerPtrsL cw, float2* __restrict__ wp, float2* __restrict__ wpt, ModeMap mm,
+                                size_t stride) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)mm.Ktot * mm.Cin * mm.Cout;
+  if (e >= n) return;
+  const int l = blockIdx.y;
+  const int o = e % mm.Cout;
+  const int i = (e / mm.Cout) % mm.Cin;
+  const int k = e / ((size_t)mm.Cout * mm.Cin);
+  int corner; size_t loc;
+  mode_decompose(mm, k, corner, loc);
+  size_t per = (size_t)mm.m[0] * mm.wl_stride;
+  if (mm.nlead == 2) per *= mm.m[1];
+  const float2 v = cw.p[l][corner][((size_t)i * mm.Cout + o) * per + loc];
+  wp[l * stride + e] = v;
+  wpt[l * stride + ((size_t)k * mm.Cout + o) * mm.Cin + i] = v;
+}
+
+__global__ void k_unpack_dw_layers(const float2* __restrict__ dwp, CornerPtrsMutL gw, ModeMap mm, size_t stride) {
+  size_t per_c = (size_t)mm.m[0] * mm.wl_stride;
+  if (mm.nlead == 2) per_c *= mm.m[1];
+  const int ncorner = 1 << mm.nlead;
+  const size_t n = (size_t)ncorner * mm.Cin * mm.Cout * per_c;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int l = blockIdx.y;
+  const size_t loc = e % per_c;
+  const int o = (e / per_c) % mm.Cout;
+  const int i = (e / (per_c * mm.Cout)) % mm.Cin;
+  const int corner = e / (per_c * mm.Cout * mm.Cin);
+  const int kl = loc % mm.wl_stride;
+  float2 v = make_float2(0.f, 0.f);
+  if (kl < mm.K[mm.nlead]) {
+    int k;
+    if (mm.nlead == 2) {
+      const int l2 = (loc / mm.wl_stride) % mm.m[1];
+      const int l1 = loc / ((size_t)mm.wl_stride * mm.m[1]);
+      const int k1 = l1 + (corner >> 1) * mm.m[0], k2 = l2 + (corner & 1) * mm.m[1];
+      k = (k1 * mm.K[1] + k2) * mm.K[2] + kl;
+    } else {
+      const int l1 = loc / mm.wl_stride;
+      k = (l1 + corner * mm.m[0]) * mm.K[1] + kl;
+    }
+    v = dwp[l * stride + ((size_t)k * mm.Cin + i) * mm.Cout + o];
+  }
+  gw.p[l][corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
 }
 
 // ---------------------------------------------------------------------------
