@@ -276,6 +276,10 @@ static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, i
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
                      int conj_w) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  const size_t lds = ((size_t)Cin * Cout + (size_t)64 * Cin) * 8;
+  if (512 % Cout == 0 && lds <= 150 * 1024)
+    return launch("k_mode_gemm", k_mode_gemm_lds, dim3(Ktot, (B + 63) / 64), dim3(512), lds, st, (const float2*)x,
+                  (const float2*)w, (float2*)out, B, Ktot, Cin, Cout, conj_w);
   const int nb = 256 / Cout;
   dim3 grid(Ktot, (B + nb - 1) / nb);
   return launch("k_mode_gemm", k_mode_gemm, grid, dim3(256), 0, st, (const float2*)x, (const float2*)w, (float2*)out, B,
@@ -283,6 +287,9 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
 }
 static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (512 % Cout == 0 && Cin <= 8 * (512 / Cout))
+    return launch("k_mode_gemm_dw", k_mode_gemm_dw_lds, dim3(Ktot), dim3(512), (size_t)64 * (Cin + Cout) * 8, st,
+                  (const float2*)x, (const float2*)g, (float2*)dw, B, Ktot, Cin, Cout);
   const int ni = 256 / Cout;
   dim3 grid(Ktot, (Cin + ni - 1) / ni);
   return launch("k_mode_gemm_dw", k_mode_gemm_dw, grid, dim3(256), 0, st, (const float2*)x, (const float2*)g,
@@ -599,7 +606,7 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   const size_t pitch = p->NPX + 4;
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
                       (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
-                      (a.x1g ? (size_t)16 * a.NJ * a.W : 0)) * 4;
+                      (a.x1g ? (size_t)16 * a.NJ * (a.W + 2) : 0)) * 4;
   if (p->NPX == 128)
     return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
   return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);

@@ -114,9 +114,10 @@ FNO_DEV void stage_rows_t(float* dst, const float* src, size_t row_stride, bool 
 // Truncated row DFT of the tile held in LDS (rows = channels), fp32 MFMA 16x16x4:
 //   X1[b, prow, k2, c] = sum_w tile[c][r*W + w] * (tfwd[2k2][w] + i tfwd[2k2+1][w])
 // D[row = j][col = c]: a lane ends up with (re, im) pairs -> float2 stores, 128-B runs.
+// `tfwd` rows are `tpitch` floats apart (W in HBM; W + 2 for the bank-conflict-free LDS copy).
 template <int NCH, int NPX, int NW>
-FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd, float* __restrict__ x1, int b,
-                              int px0, int P, int W, int K2out, int NJ, int wave, int lane) {
+FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd, int tpitch, float* __restrict__ x1,
+                              int b, int px0, int P, int W, int K2out, int NJ, int wave, int lane) {
   constexpr int PITCH = NPX + 4;
   const int l15 = lane & 15, quad = lane >> 4;
   const int R = NPX / W;
@@ -126,7 +127,7 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
     const int rr = (job / (NCH / 16)) % R;
     const int jt = job / ((NCH / 16) * R);
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    const float* tf = tfwd + (size_t)(jt * 16 + l15) * W + quad;
+    const float* tf = tfwd + (size_t)(jt * 16 + l15) * tpitch + quad;
     const float* xr = tile + (nt * 16 + l15) * PITCH + rr * W + quad;
 #pragma unroll 4
     for (int s = 0; s < W / 4; s += 2) {       // two independent accumulation chains

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   if (a.zg)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1g)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[i] = a.tfwd[i];
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 2) + i % a.W] = a.tfwd[i];
   const int zcount4 = a.zg ? R * a.K2in * C / 2 : 0;
 
   // A fragments of W^T: A[i][k = o] = W[o][i]
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
         for (int r = 0; r < 16; ++r) gq[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
       }
       __syncthreads();
-      if (a.x1g) row_dft_epilogue<C, NPX, NW>(gs, tfwd_s, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      if (a.x1g) row_dft_epilogue<C, NPX, NW>(gs, tfwd_s, a.W + 2, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
       if (a.xin) {
         // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]
 #pragma unroll

@@ -47,7 +47,7 @@ static inline size_t pw_fwd_lds_bytes(int cin, int cout, int npx, int W, int K2i
   const int rows = ((cin + 1) & ~1) > cout ? ((cin + 1) & ~1) : cout;
   size_t fl = (size_t)rows * (npx + 4);
   if (has_z) fl += (size_t)2 * K2in * W + (size_t)(npx / W) * K2in * cout * 2;
-  if (has_x1) fl += (size_t)16 * NJ * W;
+  if (has_x1) fl += (size_t)16 * NJ * (W + 2);
   return fl * 4;
 }
 
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
   if (a.z)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[i] = a.tfwd[i];
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 2) + i % a.W] = a.tfwd[i];
 
   // weight fragments: A[i = o][k = c], constant over all tiles of this workgroup
   float afrag[KS];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
     }
     if (a.x1) {
       __syncthreads();
-      row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
   }

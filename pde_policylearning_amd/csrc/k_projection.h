@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     }
     if (a.x1g) {
       __syncthreads();
-      row_dft_epilogue<C, NPX, NW>(xs, a.tfwd, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<C, NPX, NW>(xs, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();
   }
