@@ -154,6 +154,16 @@ def main():
             else:
                 roofline = dict(kernel=dom["name"], bound="hbm", achieved=dom["GBps"], peak=PEAK_HBM_GBS,
                                 unit="GB/s", frac=round(f_h, 4), traffic=None)
+            # HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_traffic.py)
+            try:
+                pt = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                key = next(k for k in pt if k.startswith(dom["name"].replace("_block", "").replace("_lift", "") + "<")
+                           or k == dom["name"])
+                roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
+                roofline["algorithmic_bytes"] = round(km[dom["name"]]["bytes"])
+            except Exception:
+                pass
             roofline["avg_launch_ms"] = dom["avg_ms"]
             roofline["measured"] = f"HIP events on the launch stream, {args.profile_steps} profiled steps after the timed region"
 
