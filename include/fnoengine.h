@@ -32,6 +32,11 @@ enum { FNO_NORM_BACKWARD = 0, FNO_NORM_FORWARD = 1, FNO_NORM_ORTHO = 2 };
 
 int fno_version(void);
 const char* fno_last_error(void);
+/* GEMM arithmetic of the fused model kernels: 1 (default) = every fp32 operand split into three
+ * bf16 terms, six bf16 MFMA products, fp32 accumulation (error <= fp32 MFMA);
+ * 0 = fp32 MFMA.  Environment FNO_GEMM_F32=1 selects 0 at load time. */
+void fno_set_gemm_mode(int split_bf16x3);
+int fno_get_gemm_mode(void);
 
 /* ------------------------------------------------------------------------
  * Standalone spectral convolution  y = irfftn(pad(W_c . rfftn(x)[corner_c])) (+ bias)

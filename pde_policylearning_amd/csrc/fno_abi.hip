@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -37,6 +38,12 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" int fno_version(void) { return FNO_VERSION; }
+
+// GEMM arithmetic of the fused model path: 1 = 3-term bf16 split on the matrix cores (fp32-grade,
+// default), 0 = fp32 MFMA.  FNO_GEMM_F32=1 in the environment selects 0 at load time.
+static int g_gemm_x3 = []() { const char* e = getenv("FNO_GEMM_F32"); return (e && e[0] == '1') ? 0 : 1; }();
+extern "C" void fno_set_gemm_mode(int x3) { g_gemm_x3 = x3 ? 1 : 0; }
+extern "C" int fno_get_gemm_mode(void) { return g_gemm_x3; }
 extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
 
 // --------------------------------------------------------------------------
@@ -621,6 +628,11 @@ static int bbwd_ksplit(const FnoModelPlan* p) {
 template <int C, int NCO>
 static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
   // no row structure in the projection: always 128-pixel tiles
+  if (g_gemm_x3) {
+    const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 3 * 64 * 16 +
+                       (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
+    return launch("k_proj_fwd", k_proj_fwd_x3<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  }
   const size_t lds = ((size_t)C * 132 + kHID + NCO * kHID + NCO * 128 + (size_t)kHID * (C + 1)) * 4;
   return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
 }

@@ -63,6 +63,89 @@ FNO_DEV float half_reduce_sum(float v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+// ---------------------------------------------------------------------------
+// fp32-grade GEMMs on the bf16 matrix cores: every fp32 operand is split into three bf16 terms
+// x = h + m + l (8 + 8 + 8 significant bits) and the product keeps the six terms of weight
+// >= 2^-16 (lh, hl, mm, mh, hm, hh; the dropped ml / lm / ll terms are <= 2^-24 relative), all
+// accumulated in the MFMA's fp32 accumulator.  Measured on MI355X (tools/mfma_bf16x3_test.hip):
+// rel-L2 error vs fp64 3.4e-8 / 1.1e-7 / 2.5e-7 at K = 16 / 64 / 256, BELOW the fp32 MFMA's
+// 7.4e-8 / 1.4e-7 / 2.9e-7.  Six 32x32x16 bf16 MFMAs (192 cycles per 16 k) replace eight
+// 32x32x2 fp32 MFMAs (512 cycles), and - unlike the fp32 MFMA, which executes on the VALU's
+// fp32 lanes (tools/mfma_valu_mix.hip) - they run on the matrix pipe concurrently with VALU work.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+FNO_DEV unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+FNO_DEV float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+FNO_DEV void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  h = f2bf(x);
+  float r = x - bf2f(h);
+  m = f2bf(r);
+  r -= bf2f(m);
+  l = f2bf(r);
+}
+// split 8 floats into three packed 8 x bf16 fragments
+FNO_DEV void split3x8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned short a, b, c;
+    split3(x[j], a, b, c);
+    h[j] = (short)a; m[j] = (short)b; l[j] = (short)c;
+  }
+}
+// acc += A * B for one 16-deep k block; a[0..2] / b[0..2] = (h, m, l) fragments; small terms first
+FNO_DEV f32x16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+FNO_DEV bf16x8 ld8h(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
+FNO_DEV void st8h(unsigned short* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+// Pixel-major split-precision activation tile in LDS: xb[t][px][c] (t = h, m, l), rows of
+// C + 8 halfs (16-B aligned, b128 reads with lanes <-> pixels are bank-conflict-free).
+// Register-staged prefetch: item (px, cg) = 8 consecutive channels of one pixel, loaded as 8
+// dword loads (lanes <-> consecutive pixels: coalesced), split on commit.
+template <int NPX, int NT, int C>
+struct SplitTilePrefetch {
+  static constexpr int PBH = C + 8;                  // halfs per pixel row
+  static constexpr int ITEMS = NPX * (C / 8);
+  static constexpr int ITER = (ITEMS + NT - 1) / NT;
+  static constexpr int TERM = NPX * PBH;             // halfs per term array
+  float v[ITER][8];
+  FNO_DEV void issue(const float* src, size_t row_stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int px = idx % NPX, cg = idx / NPX;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[i][j] = (ITEMS % NT == 0 || idx < ITEMS) ? src[(size_t)(cg * 8 + j) * row_stride + px] : 0.f;
+    }
+  }
+  FNO_DEV void commit(unsigned short* xb, bool act, int tid) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int px = idx % NPX, cg = idx / NPX;
+      if (act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = gelu_f(v[i][j]);
+      }
+      bf16x8 h, m, l;
+      split3x8(v[i], h, m, l);
+      if (ITEMS % NT == 0 || idx < ITEMS) {
+        unsigned short* dst = xb + px * PBH + cg * 8;
+        st8h(dst, h);
+        st8h(dst + TERM, m);
+        st8h(dst + 2 * TERM, l);
+      }
+    }
+  }
+};
+
 FNO_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 FNO_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

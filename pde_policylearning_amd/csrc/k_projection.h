@@ -364,3 +364,107 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Split-precision (bf16x3 on the matrix cores, see fno_dev.h) variant of k_proj_fwd.
+// W1 is split once per workgroup into MFMA A-fragment order and stays in LDS:
+//   w1b[((mt*KB + kb)*3 + t)*64 + lane][8] = term t of W1[mt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j]
+// The activation tile is pixel-major bf16x3 (SplitTilePrefetch); each wave keeps its 32 pixels'
+// B fragments (KB x 3 x 4 VGPRs) in registers for all hidden chunks.
+template <int C, int HID, int NPX, int NCO>
+__global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
+  constexpr int NTN = NPX / 32;
+  constexpr int NW = 2 * NTN;
+  constexpr int NT = NW * 64;
+  constexpr int KB = C / 16;
+  constexpr int NCH = HID / 64;
+  using PF = SplitTilePrefetch<NPX, NT, C>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* xb = reinterpret_cast<unsigned short*>(smem);          // 3 x NPX x (C+8) halfs
+  unsigned short* w1b = xb + 3 * PF::TERM;                                // (HID/32) x KB x 3 x 64 x 8 halfs
+  float* b1s = reinterpret_cast<float*>(w1b + (HID / 32) * KB * 3 * 64 * 8);   // HID
+  float* w2s = b1s + HID;                                                 // NCO x HID
+  float* ysh = w2s + NCO * HID;                                           // NCO x NPX
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int hm = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+
+  for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
+  for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
+  for (int it = tid; it < (HID / 32) * KB * 64; it += NT) {      // item = (mt, kb, lane)
+    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
+    bf16x8 h, m, l;
+    split3x8(v, h, m, l);
+    unsigned short* dst = w1b + ((size_t)((mt * KB + kb) * 3) * 64 + ln) * 8;
+    st8h(dst, h);
+    st8h(dst + 64 * 8, m);
+    st8h(dst + 2 * 64 * 8, l);
+  }
+
+  PF pfx;
+  if ((int)blockIdx.x < a.ntiles)
+    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pfx.commit(xb, a.act_in != 0, tid);
+    __syncthreads();
+    {
+      const int nt2 = tile + gridDim.x;
+      if (nt2 < a.ntiles)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+    }
+    // this wave's activation fragments: B[k = c][n = px], 8 consecutive channels per lane
+    bf16x8 bfrag[KB][3];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        bfrag[kb][t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
+
+    float ysum[NCO];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const unsigned short* wa = w1b + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        bf16x8 af[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
+        acc = mfma_x3(af, bfrag[kb], acc);
+      }
+      const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
+      const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        const float gl = gelu_f(acc[r] + b1p[ro]);
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      ysum[co] += __shfl_xor(ysum[co], 32, 64);
+      if (hm == 1 && half == 0) ysh[co * NPX + n0 + l31] = ysum[co];
+    }
+    __syncthreads();
+    if (hm == 0 && half == 0) {
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+        if (co < a.CO)
+          a.y[((size_t)b * a.CO + co) * a.PW + px0 + n0 + l31] = ysum[co] + ysh[co * NPX + n0 + l31] + a.b2[co];
+    }
+    __syncthreads();
+  }
+}
