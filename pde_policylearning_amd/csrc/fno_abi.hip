@@ -540,6 +540,7 @@ static ModelSizes model_sizes(const FnoModelPlan* p, int B) {
 
 struct ModelWs {
   float *x1, *tmp, *hat, *ohat, *z, *wp, *wpt, *w1p;
+  unsigned short *wa1, *wa3;
   // backward only
   float *ga, *gb, *dwp, *dw_part, *db_part, *dwl_part, *dw1_part, *db1_part, *dw2_part, *db2_part;
   size_t total;
@@ -558,6 +559,8 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
   w.wp = c.take<float>(s.n_wp);
   w.wpt = c.take<float>(s.n_wp);
   w.w1p = c.take<float>((size_t)kHID * C);
+  w.wa1 = c.take<unsigned short>((size_t)(kHID / 32) * (C / 16) * 3 * 64 * 8);
+  w.wa3 = c.take<unsigned short>((size_t)(kHID / 32) * 2 * (C / 32) * 3 * 64 * 8);
   if (backward) {
     w.ga = c.take<float>(s.n_act);
     w.gb = c.take<float>(s.n_act);
@@ -604,7 +607,15 @@ static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const Pw
   }
   return fail(FNO_EUNSUPPORTED, "lifting %d -> %d", p->d.Cin, C);
 }
+template <int C>
+static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
+  if (p->NPX == 128)
+    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
+  return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256>, dim3(grid), dim3((C / 32) * 8 * 64), lds, st, a);
+}
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  if (g_gemm_x3) return p->d.C == 32 ? launch_block_x3<32>(p, st, grid, a) : launch_block_x3<64>(p, st, grid, a);
   if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a, "k_pw_fwd_block");
   return launch_pw<64, 64>(p, st, grid, a, "k_pw_fwd_block");
 }
@@ -654,8 +665,24 @@ static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
     return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
 }
+template <int C, int NCO>
+static int launch_pbwd_x3_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  const int pitch = p->NPX + 4;
+  const size_t small = ((size_t)NCO * p->NPX + kHID + NCO * kHID) * 4;
+  const size_t xbb = (size_t)3 * p->NPX * (C + 8) * 2;
+  const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + xbb <= 160 * 1024;
+  const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + xbb;
+  if (p->NPX == 128)
+    return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
+}
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  if (a.wa1) {
+    const size_t xbb = (size_t)3 * p->NPX * (C + 8) * 2 + (size_t)(C + 64) * (p->NPX + 4) * 4 + 8192;
+    if (xbb <= 160 * 1024)
+      return a.CO == 1 ? launch_pbwd_x3_cn<C, 1>(p, st, grid, a) : launch_pbwd_x3_cn<C, PROJ_MAXCO>(p, st, grid, a);
+  }
   return a.CO == 1 ? launch_pbwd_cn<C, 1>(p, st, grid, a) : launch_pbwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
 }
 
@@ -720,7 +747,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.act_out = (d.gelu_mask >> l) & 1u;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, FNO_GRID_PW * p->ncu), a));
+    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? 1 : FNO_GRID_PW) * p->ncu), a));
   }
 
   // projection (tfno.py:34-38)
@@ -755,6 +782,12 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
+  if (g_gemm_x3) {
+    const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;
+    LAUNCHCHK(launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.wa1,
+                     w.wa3, kHID, C));
+    pb.wa1 = w.wa1; pb.wa3 = w.wa3;
+  }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
   pb.w2 = prm->proj_w2; pb.gout = w.ga; pb.x1g = w.x1; pb.tfwd = p->t.tfwd_b;
   pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;

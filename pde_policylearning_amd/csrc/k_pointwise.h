@@ -27,6 +27,9 @@
 #ifndef FNO_OCC_PW
 #define FNO_OCC_PW 4
 #endif
+#ifndef FNO_OCC_PWX
+#define FNO_OCC_PWX 2   // measured: 1 workgroup/CU without spills (0.175 ms) beats 2 with spills (0.27 ms)
+#endif
 
 struct PwFwdArgs {
   const float* x;     // (B, CIN, PW) pre-activation input, or null (no conv part)
@@ -152,5 +155,129 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
       row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Split-precision variant of the block kernel (CIN == COUT == C): the 1x1 skip convolution runs
+// as six bf16 MFMAs per 16 channels on the matrix cores (fno_dev.h, fp32-grade accuracy), the
+// spectral K-extension and the row-DFT epilogue stay fp32.  The activation tile is staged
+// pixel-major as three bf16 arrays; the fp32 output tile for the DFT epilogue reuses that LDS.
+static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ, bool has_z, bool has_x1) {
+  size_t bytes = (size_t)3 * npx * (c + 8) * 2;
+  const size_t out_tile = (size_t)c * (npx + 4) * 4;
+  if (out_tile > bytes) bytes = out_tile;
+  size_t fl = 0;
+  if (has_z) fl += (size_t)2 * K2in * W + (size_t)(npx / W) * K2in * c * 2;
+  if (has_x1) fl += (size_t)16 * NJ * (W + 2);
+  return bytes + fl * 4;
+}
+
+template <int C, int NPX>
+__global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
+  constexpr int NTN = NPX / 32;
+  constexpr int MT = C / 32;
+  constexpr int NW = MT * NTN;
+  constexpr int NT = NW * 64;
+  constexpr int KB = C / 16;
+  constexpr int PITCH = NPX + 4;
+  using PF = SplitTilePrefetch<NPX, NT, C>;
+  constexpr size_t XB_BYTES = (size_t)3 * PF::TERM * 2;
+  constexpr size_t OUT_BYTES = (size_t)C * PITCH * 4;
+  constexpr size_t REGION = XB_BYTES > OUT_BYTES ? XB_BYTES : OUT_BYTES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* xb = reinterpret_cast<unsigned short*>(smem);     // 3 x NPX x (C+8) halfs ...
+  float* xs = smem;                                                  // ... reused as the C x PITCH fp32 output tile
+  float* tinv_s = smem + REGION / 4;
+  const int R = NPX / a.W;
+  float* zs = tinv_s + (a.z ? 2 * a.K2in * a.W : 0);
+  float* tfwd_s = zs + (a.z ? R * a.K2in * C * 2 : 0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+
+  if (a.z)
+    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
+  if (a.x1)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 2) + i % a.W] = a.tfwd[i];
+
+  // weight fragments A[i = o][k = c] split into (h, m, l), constant over all tiles
+  bf16x8 afrag[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w[(mt * 32 + l31) * C + kb * 16 + 8 * half + j];
+    split3x8(v, afrag[kb][0], afrag[kb][1], afrag[kb][2]);
+  }
+
+  const int zcount4 = a.z ? R * a.K2in * C / 2 : 0;
+  PF pf;
+  float4 zpf = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto issue = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, tid);
+    if (tid < zcount4) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+
+    pf.commit(xb, a.act_in != 0, tid);
+    if (tid < zcount4) st4(zs + 4 * tid, zpf);
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bf[t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
+      acc = mfma_x3(afrag[kb], bf, acc);
+    }
+    if (a.z) {
+      const int rr = n0 / a.W;
+      const float* zr = zs + ((rr * a.K2in) * C + mt * 32 + l31) * 2 + half;
+      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+#pragma unroll 2
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
+    }
+    __syncthreads();  // all waves are done reading the staged input (the output tile reuses it)
+
+    {
+      float* up = a.u ? a.u + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
+      float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
+      const float* bp = a.bias ? a.bias + mt * 32 + 4 * half : nullptr;
+      if (bp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += bp[(r & 3) + 8 * (r >> 2)];
+      }
+      if (up) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[r];
+      }
+      if (a.x1) {
+        if (a.act_out) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = gelu_f(acc[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
+        }
+      }
+    }
+    if (a.x1) {
+      __syncthreads();
+      row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+    }
+    __syncthreads();
   }
 }

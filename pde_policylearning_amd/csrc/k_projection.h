@@ -113,6 +113,8 @@ struct ProjBwdArgs {
   float* gout;        // (B, C, PW): dL/du_L
   float* x1g;         // (B, P, K2out, C, 2) or null
   const float* tfwd;  // (16*NJ, W)
+  const unsigned short* wa1;   // split-precision A1 fragments (k_pack_w1_x3), or null
+  const unsigned short* wa3;   // split-precision A3 fragments
   float* dw1_part;    // (gridDim, HID, C)
   float* db1_part;    // (gridDim * NPX/32, HID)
   float* dw2_part;    // (gridDim * NPX/32, CO, HID)
@@ -365,6 +367,262 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
   }
 }
 
+// Split-precision variant of k_proj_bwd: the P1 recompute (A1) and the dx product (A3) run as
+// bf16x3 MFMAs on the matrix cores with W1 fragments pre-split by k_pack_w1_x3 (L2-resident);
+// the dW1 product (B, K = pixels) stays fp32.  Otherwise identical:
+// wave (hm, nt) as in k_proj_fwd.  Per 64-row hidden chunk (ONE barrier per chunk, the dP1
+// chunk is double-buffered in LDS so wave groups run up to a chunk apart):
+//   A1  recompute P1 (MFMA 32x32x2)
+//   E   gl = gelu(P1), dP1 = gelu'(P1) * (W2^T dy); dW2 / db1 contributions are reduced over
+//       the 32 pixels of the wave with DPP adds (no LDS round trip); dP1 -> LDS
+//   A3  dx += W1^T dP1, dP1 fed to the MFMA straight from the accumulator registers (its row
+//       index is the k index of this product)
+//   --- barrier ---
+//   B   dW1[chunk] += dP1 . a^T  (MFMA, K = pixels) by the wave group that owns this chunk,
+//       while the other group already recomputes the next chunk
+template <int C, int HID, int NPX, int NCO>
+__global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs a) {
+  using Cfg = ProjBwdCfg<C, HID, NPX>;
+  constexpr int NTN = Cfg::NTN, NW = Cfg::NW, MT = Cfg::MT, NCH = Cfg::NCH, TILES = Cfg::TILES, G = Cfg::G,
+                CPW = Cfg::CPW;
+  constexpr int NT = NW * 64;
+  constexpr int PITCH = NPX + 4;
+  constexpr int KB = C / 16;
+  using SP = SplitTilePrefetch<NPX, NT, C>;                  // only its layout constants are used
+  constexpr int kSmall = NCO * NPX + HID + NCO * HID;
+  constexpr int kXB = 3 * SP::TERM / 2;                      // floats taken by the bf16x3 activation arrays
+  // the dP1 chunk is double-buffered when two 64 x PITCH buffers fit beside the tile and the bf16 arrays
+  constexpr bool DBUF = ((C + 128) * (NPX + 4) + kSmall + kXB) * 4 <= 160 * 1024;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                        // C x PITCH        : a = act(u_L); later the gout tile
+  float* dps = xs + C * PITCH;             // 2 x 64 x PITCH   : dP1 chunks (double-buffered);
+                                           //                    after the chunk loop: dx partials of hm = 1
+  float* douts = dps + (DBUF ? 2 : 1) * 64 * PITCH;     // NCO x NPX
+  float* b1s = douts + NCO * NPX;          // HID
+  float* w2s = b1s + HID;                  // NCO x HID
+  unsigned short* xb = reinterpret_cast<unsigned short*>(w2s + NCO * HID);   // 3 x NPX x (C+8) halfs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15;
+  const int hm = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+  const int dgrp = wave / TILES, dtl = wave % TILES;
+  const int dmt = dtl / MT, dnt = dtl % MT;  // dW1 tile: hidden 32-block, channel 32-block
+
+  for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
+  for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
+  f32x16 dw1acc[CPW];
+#pragma unroll
+  for (int k = 0; k < CPW; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw1acc[k][r] = 0.f;
+  // lane (l15, half) accumulates hidden row  ch*64 + hm*32 + acc_row32(l15, half)  of every chunk
+  float sdb1[NCH], sdw2[NCH][NCO];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    sdb1[ch] = 0.f;
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) sdw2[ch][co] = 0.f;
+  }
+
+  TilePrefetch<NPX, NT, C, C> pfx;      // next tile's u_L rows, in flight during this tile
+  if ((int)blockIdx.x < a.ntiles)
+    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pfx.commit(xs, a.act_in != 0, tid);
+    for (int idx = tid; idx < NCO * NPX; idx += NT) {
+      const int co = idx / NPX, p = idx % NPX;
+      douts[idx] = (co < a.CO) ? a.dy[((size_t)b * a.CO + co) * a.PW + px0 + p] : 0.f;
+    }
+    __syncthreads();
+    {
+      const int nt2 = tile + gridDim.x;
+      if (nt2 < a.ntiles)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+    }
+    // split pass: fp32 tile [c][px] -> pixel-major bf16x3 arrays (A1's B operand)
+    for (int it = tid; it < NPX * (C / 8); it += NT) {
+      const int px = it % NPX, cg = it / NPX;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = xs[(cg * 8 + j) * PITCH + px];
+      bf16x8 h, m, l;
+      split3x8(v, h, m, l);
+      unsigned short* dst = xb + px * SP::PBH + cg * 8;
+      st8h(dst, h);
+      st8h(dst + SP::TERM, m);
+      st8h(dst + 2 * SP::TERM, l);
+    }
+    __syncthreads();
+    const unsigned short* xbp = xb + (n0 + l31) * SP::PBH + 8 * half;   // this lane's pixel row
+    float dyl[NCO];
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) dyl[co] = douts[co * NPX + n0 + l31];
+
+    f32x16 acc2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      float* dpb = dps + (DBUF ? (ch & 1) : 0) * 64 * PITCH;
+      // ---- A1 ------------------------------------------------------------
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      {
+        const unsigned short* wa = a.wa1 + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          bf16x8 af[3], bf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            af[t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
+            bf[t] = ld8h(xbp + t * SP::TERM + kb * 16);
+          }
+          acc = mfma_x3(af, bf, acc);
+        }
+      }
+      // ---- E ---------------------------------------------------------------
+      {
+        float* dpp = dpb + (hm * 32 + 4 * half) * PITCH + n0 + l31;
+        const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
+        const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
+        float rdb = 0.f, rdw[NCO];
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) rdw[co] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);
+          float t = 0.f;
+#pragma unroll
+          for (int co = 0; co < NCO; ++co) t = fmaf(w2p[co * HID + ro], dyl[co], t);
+          float gl, dg;
+          gelu_both(acc[r] + b1p[ro], gl, dg);
+          const float dp = dg * t;
+          acc[r] = dp;
+          dpp[ro * PITCH] = dp;
+          const float sdp = half_reduce_sum(dp);
+          rdb = (l15 == r) ? sdp : rdb;
+#pragma unroll
+          for (int co = 0; co < NCO; ++co) {
+            const float sg = half_reduce_sum(gl * dyl[co]);
+            rdw[co] = (l15 == r) ? sg : rdw[co];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+          if (k == ch) {
+            sdb1[k] += rdb;
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) sdw2[k][co] += rdw[co];
+          }
+      }
+      // ---- A3 --------------------------------------------------------------
+      {
+        // accumulator registers 8s..8s+7 are the B fragment of hidden k-block s (rows in the
+        // order 16s + 8(j>>2) + 4*half + (j&3)); wa3 holds W1^T fragments in that same k order
+        const unsigned short* wa = a.wa3 + ((size_t)((ch * 2 + hm) * 2 * MT * 3) * 64 + lane) * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = acc[8 * s + j];
+          bf16x8 bd[3];
+          split3x8(v, bd[0], bd[1], bd[2]);
+#pragma unroll
+          for (int mc = 0; mc < MT; ++mc) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)((s * MT + mc) * 3 + t) * 64 * 8);
+            acc2[mc] = mfma_x3(af, bd, acc2[mc]);
+          }
+        }
+      }
+      __syncthreads();
+      // ---- B -----------------------------------------------------------------
+      if (dgrp == ch % G) {
+        const float* ga = dpb + (dmt * 32 + l31) * PITCH + 4 * half;
+        const float* ab = xs + (dnt * 32 + l31) * PITCH + 4 * half;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+          if (k == ch / G) {
+            f32x16 dacc = dw1acc[k];
+#pragma unroll 2
+            for (int q = 0; q < NPX / 8; ++q) {
+              const float4 av = ld4(ga + 8 * q);
+              const float4 bv = ld4(ab + 8 * q);
+              dacc = mfma32(av.x, bv.x, dacc);
+              dacc = mfma32(av.y, bv.y, dacc);
+              dacc = mfma32(av.z, bv.z, dacc);
+              dacc = mfma32(av.w, bv.w, dacc);
+            }
+            dw1acc[k] = dacc;
+          }
+      }
+      if (!DBUF) __syncthreads();   // single buffer: the next chunk overwrites it
+    }
+    __syncthreads();   // all dW1 GEMMs done with xs / dps
+
+    // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
+    if (hm == 1) {
+      float* dpp = dps + (4 * half) * PITCH + n0 + l31;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dpp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
+    }
+    __syncthreads();
+    if (hm == 0) {
+      const float* dpp = dps + (4 * half) * PITCH + n0 + l31;
+      float* xp = xs + (4 * half) * PITCH + n0 + l31;
+      const size_t goff = ((size_t)b * C + 4 * half) * a.PW + px0 + n0 + l31;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+          float v = acc2[m][r] + dpp[ro * PITCH];
+          if (a.act_in) v *= gelu_grad_f(a.x[goff + (size_t)ro * a.PW]);
+          a.gout[goff + (size_t)ro * a.PW] = v;
+          if (a.x1g) xp[ro * PITCH] = v;
+        }
+    }
+    if (a.x1g) {
+      __syncthreads();
+      row_dft_epilogue<C, NPX, NW>(xs, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+    }
+    __syncthreads();
+  }
+
+  // ---- partial slabs -------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    const int ch = dgrp + k * G;
+    if (dgrp >= G) break;
+    float* dst = a.dw1_part + (size_t)blockIdx.x * HID * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
+  }
+  if ((lane & 16) == 0) {      // lanes 16-31 / 48-63 hold duplicates
+    const size_t slab = (size_t)blockIdx.x * NTN + nt;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int hid = ch * 64 + hm * 32 + acc_row32(l15, half);
+      a.db1_part[slab * HID + hid] = sdb1[ch];
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+        if (co < a.CO) a.dw2_part[(slab * a.CO + co) * HID + hid] = sdw2[ch][co];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Split-precision (bf16x3 on the matrix cores, see fno_dev.h) variant of k_proj_fwd.
 // W1 is split once per workgroup into MFMA A-fragment order and stays in LDS:
@@ -466,5 +724,34 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
           a.y[((size_t)b * a.CO + co) * a.PW + px0 + n0 + l31] = ysum[co] + ysh[co * NPX + n0 + l31] + a.b2[co];
     }
     __syncthreads();
+  }
+}
+
+// W1 (HID, C) fp32 -> bf16x3 MFMA A-fragments for k_proj_bwd_x3 (once per step, 2 x 96 KB at C = 64):
+//   wa1[((mt*KB + kb)*3 + t)*64 + lane][j] = term t of W1[mt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j]
+//   wa3[(((mt*2 + s)*MT + mc)*3 + t)*64 + lane][j] = term t of W1[mt*32 + 16s + 8(j>>2) + 4(lane>>5) + (j&3)][mc*32 + (lane&31)]
+__global__ void k_pack_w1_x3(const float* __restrict__ w1, unsigned short* __restrict__ wa1,
+                             unsigned short* __restrict__ wa3, int HID, int C) {
+  const int KB = C / 16, MT = C / 32;
+  const int n1 = (HID / 32) * KB * 64, n3 = (HID / 32) * 2 * MT * 64;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  float v[8];
+  bf16x8 h, m, l;
+  if (it < n1) {
+    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
+    split3x8(v, h, m, l);
+    unsigned short* dst = wa1 + ((size_t)((mt * KB + kb) * 3) * 64 + ln) * 8;
+    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
+  } else if (it < n1 + n3) {
+    const int i3 = it - n1;
+    const int ln = i3 & 63, mc = (i3 >> 6) % MT, s = ((i3 >> 6) / MT) & 1, mt = (i3 >> 6) / MT / 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = w1[(size_t)(mt * 32 + 16 * s + 8 * (j >> 2) + 4 * (ln >> 5) + (j & 3)) * C + mc * 32 + (ln & 31)];
+    split3x8(v, h, m, l);
+    unsigned short* dst = wa3 + ((size_t)(((mt * 2 + s) * MT + mc) * 3) * 64 + ln) * 8;
+    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
   }
 }
