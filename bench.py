@@ -93,7 +93,7 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
     tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
-    bucket = FlatGradBucket(model.parameters())
+    bucket = FlatGradBucket(model.parameters(), direct_module=model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     loss_fn = LpLoss(size_average=False)
 

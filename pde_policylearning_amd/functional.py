@@ -154,7 +154,8 @@ class _FNOModelFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *rest):
-        n_layers, modes, norm, gelu_mask = cfg
+        n_layers, modes, norm, gelu_mask, direct = cfg
+        ctx.direct = direct
         _require_cuda(x, "x")
         if x.requires_grad:
             raise RuntimeError("fnoengine fused FNO: gradient w.r.t. the input field is not produced "
@@ -202,10 +203,17 @@ class _FNOModelFn(torch.autograd.Function):
         L = _lib.lib()
         prm = _lib.FnoModelParams()
         _fill_params(prm, nl, nc, lift_w, lift_b, skip_ws, spec_ws, sb, w1, b1, w2, b2)
-        g = [torch.empty_like(t) for t in (lift_w, lift_b, w1, b1, w2, b2)]
-        g_skip = [torch.empty_like(t) for t in skip_ws]
-        g_spec = [torch.empty_like(t) for t in spec_ws]
-        g_sb = torch.empty_like(sb) if sb is not None else None
+        if ctx.direct is not None:
+            # the engine WRITES gradients: hand it the parameters' own (pre-allocated, flat-bucket)
+            # .grad storage and return None so autograd launches no accumulation kernels
+            dg = ctx.direct
+            g = [dg[k] for k in ("lift_w", "lift_b", "w1", "b1", "w2", "b2")]
+            g_skip, g_spec, g_sb = dg["skip"], dg["spec"], dg["spec_bias"]
+        else:
+            g = [torch.empty_like(t) for t in (lift_w, lift_b, w1, b1, w2, b2)]
+            g_skip = [torch.empty_like(t) for t in skip_ws]
+            g_spec = [torch.empty_like(t) for t in spec_ws]
+            g_sb = torch.empty_like(sb) if sb is not None else None
         grd = _lib.FnoModelGrads()
         _fill_params(grd, nl, nc, g[0], g[1], g_skip, g_spec, g_sb, g[2], g[3], g[4], g[5])
         nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
@@ -213,11 +221,13 @@ class _FNOModelFn(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(L.fno_model_backward(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
                                             C.byref(grd), _ptr(ws), nws, _stream()), "model_backward")
+        if ctx.direct is not None:
+            return (None,) * (9 + len(skip_ws) + len(spec_ws))
         return (None, None, g[0], g[1], g_sb, g[2], g[3], g[4], g[5]) + tuple(g_skip) + tuple(g_spec)
 
 
 def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, modes, norm="forward",
-              gelu_mask=None):
+              gelu_mask=None, direct_grads=False):
     """Fused neuralop.models.FNO forward (default configuration).  `modes` = kept per
     corner per dim (n_modes // 2); `spec_ws` real-view corner weights, layer-major."""
     n_layers = len(skip_ws)
@@ -226,5 +236,12 @@ def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, mo
         for l in range(n_layers):
             if l < n_layers - l:                 # fno_block.py:149
                 gelu_mask |= 1 << l
-    cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask))
+    direct = None
+    if direct_grads:
+        params = [lift_w, lift_b, w1, b1, w2, b2] + list(skip_ws) + list(spec_ws) + ([spec_bias] if spec_bias is not None else [])
+        if all(p.grad is not None and p.grad.is_contiguous() for p in params):
+            direct = dict(lift_w=lift_w.grad, lift_b=lift_b.grad, w1=w1.grad, b1=b1.grad, w2=w2.grad, b2=b2.grad,
+                          skip=[p.grad for p in skip_ws], spec=[p.grad for p in spec_ws],
+                          spec_bias=spec_bias.grad if spec_bias is not None else None)
+    cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
     return _FNOModelFn.apply(cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *skip_ws, *spec_ws)

@@ -91,7 +91,9 @@ class FNO(nn.Module):
 
     def forward(self, x):
         if self.fused_supported(x):
-            return F.fno_model(x, **self.engine_args())
+            # direct_grads: set by trainer.FlatGradBucket(model, direct=True); the engine then writes
+            # parameter gradients straight into the flat bucket (one use of each parameter per step)
+            return F.fno_model(x, direct_grads=getattr(self, "_direct_grads", False), **self.engine_args())
         # other widths / grids: spectral convolutions on the engine, pointwise glue in torch
         x = self.lifting(x)
         for l in range(self.n_layers):

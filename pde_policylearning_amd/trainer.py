@@ -56,7 +56,11 @@ class FlatGradBucket(object):
     the data-parallel exchange is a single all-reduce(SUM) - sized for xGMI: one 9.6 MB message
     for FNO2d(12,12,64) instead of ~30 small ones."""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, direct_module=None):
+        """direct_module: an engine FNO whose backward may WRITE its gradients into the bucket
+        (no autograd accumulation kernels, no zeroing); valid when every parameter is used by
+        exactly one engine call per step, as in the reference training step."""
+        self.direct_module = direct_module
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         n = sum(p.numel() for p in self.params)
@@ -66,9 +70,14 @@ class FlatGradBucket(object):
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        if direct_module is not None:
+            for m in direct_module.modules():
+                if hasattr(m, "fused_supported"):
+                    m._direct_grads = True
 
     def zero(self):
-        self.flat.zero_()
+        if self.direct_module is None:
+            self.flat.zero_()
 
     def check_views(self):
         """autograd accumulates in place into an existing .grad; re-attach if something replaced it."""
