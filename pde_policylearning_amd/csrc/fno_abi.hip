@@ -250,18 +250,37 @@ static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
 }
 
 
-// many -> few (twT transposed (n_in, n_out)) or few -> many (tw (n_out, n_in))
-static int axis_pass(hipStream_t st, bool truncating, const float* in, float* out, const float2* tw, int outer,
+// many -> few (twT transposed (n_in, n_out)) or few -> many (tw (n_out, n_in)); the small (kept) extent
+// is a template parameter of the fast kernels (2*m for the usual m = 2..20), anything else is generic.
+template <int NS>
+static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2* out, const float2* tw, int outer,
+                       int n_in, int n_out, int inner) {
+  if (truncating)
+    return launch("k_axis_fwd", k_axis_fwd<NS>, dim3((inner + 63) / 64, outer), dim3(64, 8), (size_t)8 * NS * 64 * 8,
+                  st, in, out, tw, n_in, inner);
+  return launch("k_axis_inv", k_axis_inv<NS>, dim3((inner + 63) / 64, outer), dim3(64, 16), 0, st, in, out, tw, n_out,
+                inner);
+}
+static int axis_pass(hipStream_t st, bool truncating, const float* in_, float* out_, const float2* tw, int outer,
                      int n_in, int n_out, int inner) {
   if (outer > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d)", outer);
-  if (truncating) {
-    dim3 grid((inner + 63) / 64, outer, (n_out + 7) / 8);
-    return launch("k_axis_fwd", k_axis_fwd, grid, dim3(64, 8), 0, st, (const float2*)in, (float2*)out, tw, n_in,
-                  n_out, inner);
+  const float2* in = (const float2*)in_;
+  float2* out = (float2*)out_;
+  const int small = truncating ? n_out : n_in;
+  switch (small) {
+    case 4: return axis_pass_t<4>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 6: return axis_pass_t<6>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 8: return axis_pass_t<8>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 10: return axis_pass_t<10>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 12: return axis_pass_t<12>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 16: return axis_pass_t<16>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 20: return axis_pass_t<20>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 24: return axis_pass_t<24>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    default: break;
   }
-  dim3 grid((inner + 63) / 64, outer);
-  return launch("k_axis_inv", k_axis_inv, grid, dim3(64, 16), 0, st, (const float2*)in, (float2*)out, tw, n_in, n_out,
-                inner);
+  if (n_out > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d)", n_out);
+  return launch("k_axis_generic", k_axis_generic, dim3((inner + 255) / 256, n_out, outer), dim3(256), 0, st, in, out,
+                tw, n_in, n_out, inner, truncating ? 1 : 0);
 }
 
 // forward-direction passes over the leading dims: x1 [B][lead..][Klast][C] -> hat [B][K..][Klast][C]

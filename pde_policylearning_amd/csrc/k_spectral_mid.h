@@ -13,23 +13,23 @@
 #include "fno_dev.h"
 
 // ---------------------------------------------------------------------------
-// Truncating pass (many -> few):  out[o][r][q] = sum_n twT[n][r] * in[o][n][q],  n_out small.
-// Each thread keeps up to 8 complex outputs of one column q in registers; the n range is
-// split over 8 waves (loads of one wave are all in flight together) and combined through
-// LDS.  twT is wave-uniform -> scalar loads.
-//   block (64, 8), grid (ceil(inner/64), outer, ceil(n_out/8))
+// Truncating pass (many -> few):  out[o][r][q] = sum_n twT[n][r] * in[o][n][q],  n_out = NR small.
+// Each thread keeps all NR complex outputs of one column q in registers; the n range is split over
+// 8 waves (each wave's loads are all in flight together) and combined through LDS.  twT rows are
+// wave-uniform and NR is a compile-time constant -> wide scalar loads, no per-element guards.
+//   block (64, 8), grid (ceil(inner/64), outer)
+template <int NR>
 __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
-                                                  const float2* __restrict__ twT, int n_in, int n_out, int inner) {
-  __shared__ float2 sh[8][8][64];
+                                                  const float2* __restrict__ twT, int n_in, int inner) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* sh = reinterpret_cast<float2*>(smem);     // [8][NR][64]
   const int ql = threadIdx.x;
-  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);   // one wave per seg: scalar table loads
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
-  const int r0 = blockIdx.z * 8;
-  const int nr = min(8, n_out - r0);
-  float2 acc[8];
+  float2 acc[NR];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = make_float2(0.f, 0.f);
+  for (int r = 0; r < NR; ++r) acc[r] = make_float2(0.f, 0.f);
   if (q < inner) {
     const float2* src = in + (size_t)o * n_in * inner + q;
     for (int nb = seg; nb < n_in; nb += 64) {
@@ -43,64 +43,75 @@ __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in,
       for (int j = 0; j < 8; ++j) {
         const int n = nb + 8 * j;
         if (n < n_in) {
-          const float2* t = twT + (size_t)n * n_out + r0;
+          const float2* t = twT + (size_t)n * NR;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            if (r < nr) {
-              const float2 w = t[r];
-              acc[r].x = fmaf(w.x, v[j].x, acc[r].x); acc[r].x = fmaf(-w.y, v[j].y, acc[r].x);
-              acc[r].y = fmaf(w.x, v[j].y, acc[r].y); acc[r].y = fmaf(w.y, v[j].x, acc[r].y);
-            }
+          for (int r = 0; r < NR; ++r) {
+            const float2 w = t[r];
+            acc[r].x = fmaf(w.x, v[j].x, acc[r].x); acc[r].x = fmaf(-w.y, v[j].y, acc[r].x);
+            acc[r].y = fmaf(w.x, v[j].y, acc[r].y); acc[r].y = fmaf(w.y, v[j].x, acc[r].y);
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 8; ++r) sh[seg][r][ql] = acc[r];
+  for (int r = 0; r < NR; ++r) sh[(seg * NR + r) * 64 + ql] = acc[r];
   __syncthreads();
-  if (q < inner && seg < nr) {
-    float sx = 0.f, sy = 0.f;
+  if (q < inner) {
+    for (int r = seg; r < NR; r += 8) {
+      float sx = 0.f, sy = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sx += sh[k][seg][ql].x; sy += sh[k][seg][ql].y; }
-    out[((size_t)o * n_out + r0 + seg) * inner + q] = make_float2(sx, sy);
+      for (int k = 0; k < 8; ++k) { sx += sh[(k * NR + r) * 64 + ql].x; sy += sh[(k * NR + r) * 64 + ql].y; }
+      out[((size_t)o * NR + r) * inner + q] = make_float2(sx, sy);
+    }
   }
 }
 
-// Expanding pass (few -> many):  out[o][r][q] = sum_k tw[r][k] * in[o][k][q],  n_in small.
-// Each thread holds its column's (<= 16 per chunk) inputs in registers and sweeps its share
-// of r (16 waves per block share the sweep).
+// Expanding pass (few -> many):  out[o][r][q] = sum_k tw[r][k] * in[o][k][q],  n_in = NK small.
+// Each thread holds its column's NK inputs in registers and sweeps its share of r (16 waves per
+// block share the sweep); tw rows are wave-uniform, NK compile-time -> wide scalar loads.
 //   block (64, 16), grid (ceil(inner/64), outer)
+template <int NK>
 __global__ void __launch_bounds__(1024) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
-                                                   const float2* __restrict__ tw, int n_in, int n_out, int inner) {
+                                                   const float2* __restrict__ tw, int n_out, int inner) {
   const int ql = threadIdx.x;
-  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);   // one wave per seg: scalar table loads
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
   if (q >= inner) return;
-  for (int k0 = 0; k0 < n_in; k0 += 16) {
-    const int nk = min(16, n_in - k0);
-    float2 v[16];
+  float2 v[NK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      v[k] = (k < nk) ? in[((size_t)o * n_in + k0 + k) * inner + q] : make_float2(0.f, 0.f);
+  for (int k = 0; k < NK; ++k) v[k] = in[((size_t)o * NK + k) * inner + q];
 #pragma unroll 2
-    for (int r = seg; r < n_out; r += 16) {
-      const float2* t = tw + (size_t)r * n_in + k0;
-      float sr = 0.f, si = 0.f;
+  for (int r = seg; r < n_out; r += 16) {
+    const float2* t = tw + (size_t)r * NK;
+    float sr = 0.f, si = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k < nk) {
-          const float2 w = t[k];
-          sr = fmaf(w.x, v[k].x, sr); sr = fmaf(-w.y, v[k].y, sr);
-          si = fmaf(w.x, v[k].y, si); si = fmaf(w.y, v[k].x, si);
-        }
-      }
-      float2* dst = out + ((size_t)o * n_out + r) * inner + q;
-      if (k0 > 0) { const float2 p = *dst; sr += p.x; si += p.y; }
-      *dst = make_float2(sr, si);
+    for (int k = 0; k < NK; ++k) {
+      const float2 w = t[k];
+      sr = fmaf(w.x, v[k].x, sr); sr = fmaf(-w.y, v[k].y, sr);
+      si = fmaf(w.x, v[k].y, si); si = fmaf(w.y, v[k].x, si);
     }
+    out[((size_t)o * n_out + r) * inner + q] = make_float2(sr, si);
   }
+}
+
+// generic fallbacks for kept counts without a specialisation (any n_in / n_out)
+__global__ void __launch_bounds__(256) k_axis_generic(const float2* __restrict__ in, float2* __restrict__ out,
+                                                      const float2* __restrict__ tw, int n_in, int n_out, int inner,
+                                                      int tw_transposed) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y, o = blockIdx.z;
+  if (q >= inner) return;
+  const float2* src = in + (size_t)o * n_in * inner + q;
+  float sr = 0.f, si = 0.f;
+  for (int n = 0; n < n_in; ++n) {
+    const float2 v = src[(size_t)n * inner];
+    const float2 w = tw_transposed ? tw[(size_t)n * n_out + r] : tw[(size_t)r * n_in + n];
+    sr = fmaf(w.x, v.x, sr); sr = fmaf(-w.y, v.y, sr);
+    si = fmaf(w.x, v.y, si); si = fmaf(w.y, v.x, si);
+  }
+  out[((size_t)o * n_out + r) * inner + q] = make_float2(sr, si);
 }
 
 // ---------------------------------------------------------------------------
