@@ -302,10 +302,13 @@ static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, i
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
                      int conj_w) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
-  const size_t lds = ((size_t)Cin * Cout + (size_t)64 * Cin) * 8;
-  if (512 % Cout == 0 && lds <= 150 * 1024)
-    return launch("k_mode_gemm", k_mode_gemm_lds, dim3(Ktot, (B + 63) / 64), dim3(512), lds, st, (const float2*)x,
-                  (const float2*)w, (float2*)out, B, Ktot, Cin, Cout, conj_w);
+  if (512 % Cout == 0 && Cout >= 32) {
+    const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
+    const size_t lds = ((size_t)Cin * Cout + (size_t)bt * Cin) * 8;
+    if (lds <= 150 * 1024)
+      return launch("k_mode_gemm", k_mode_gemm_lds<2>, dim3(Ktot, (B + bt - 1) / bt), dim3(512), lds, st,
+                    (const float2*)x, (const float2*)w, (float2*)out, B, Ktot, Cin, Cout, conj_w);
+  }
   const int nb = 256 / Cout;
   dim3 grid(Ktot, (B + nb - 1) / nb);
   return launch("k_mode_gemm", k_mode_gemm, grid, dim3(256), 0, st, (const float2*)x, (const float2*)w, (float2*)out, B,
@@ -313,9 +316,11 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
 }
 static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
-  if (512 % Cout == 0 && Cin <= 8 * (512 / Cout))
-    return launch("k_mode_gemm_dw", k_mode_gemm_dw_lds, dim3(Ktot), dim3(512), (size_t)64 * (Cin + Cout) * 8, st,
-                  (const float2*)x, (const float2*)g, (float2*)dw, B, Ktot, Cin, Cout);
+  if (512 % Cout == 0 && Cout >= 32) {
+    const int it = 2 * (512 / Cout);                   // 2 input channels per thread
+    return launch("k_mode_gemm_dw", k_mode_gemm_dw_lds<2>, dim3(Ktot, (Cin + it - 1) / it), dim3(512),
+                  (size_t)64 * (it + Cout) * 8, st, (const float2*)x, (const float2*)g, (float2*)dw, B, Ktot, Cin, Cout);
+  }
   const int ni = 256 / Cout;
   dim3 grid(Ktot, (Cin + ni - 1) / ni);
   return launch("k_mode_gemm_dw", k_mode_gemm_dw, grid, dim3(256), 0, st, (const float2*)x, (const float2*)g,

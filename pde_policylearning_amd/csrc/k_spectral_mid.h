@@ -271,18 +271,20 @@ __global__ void __launch_bounds__(256) k_mode_gemm(const float2* __restrict__ x,
   out[((size_t)b * Ktot + k) * Cout + o] = make_float2(sr, si);
 }
 
-// LDS-tiled variant for the hot case (Cout a divisor of 512, one mode per workgroup): the mode's
-// weight matrix and the batch's spectra for that mode are staged once in LDS and every thread
-// accumulates 512/Cout... batch rows of one output channel, so W is read from L2 once per mode
-// instead of once per sample.   grid (Ktot, ceil(B / 64)), block 512, LDS (Cin*Cout + 64*Cin) float2
+// LDS-tiled variant for the hot case (Cout a divisor of 512): a workgroup owns one mode and a
+// batch tile of BT = J * (512 / Cout) samples; the mode's weight matrix and the tile's spectra are
+// staged once in LDS and every thread accumulates J batch rows of one output channel.
+//   grid (Ktot, ceil(B / BT)), block 512, LDS (Cin*Cout + BT*Cin) float2
+template <int J>
 __global__ void __launch_bounds__(512) k_mode_gemm_lds(const float2* __restrict__ x, const float2* __restrict__ w,
                                                        float2* __restrict__ out, int B, int Ktot, int Cin, int Cout,
                                                        int conj_w) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* ws = reinterpret_cast<float2*>(smem);      // Cin x Cout
-  float2* xs = ws + (size_t)Cin * Cout;              // 64 x Cin
-  const int k = blockIdx.x, b0 = blockIdx.y * 64;
-  const int nb = min(64, B - b0);
+  float2* xs = ws + (size_t)Cin * Cout;              // BT x Cin
+  const int ng = 512 / Cout, BT = J * ng;
+  const int k = blockIdx.x, b0 = blockIdx.y * BT;
+  const int nb = min(BT, B - b0);
   const int tid = threadIdx.x;
   const float2* wk = w + (size_t)k * Cin * Cout;
   for (int i = tid; i < Cin * Cout; i += 512) ws[i] = wk[i];
@@ -291,64 +293,69 @@ __global__ void __launch_bounds__(512) k_mode_gemm_lds(const float2* __restrict_
     xs[i] = x[((size_t)(b0 + bb) * Ktot + k) * Cin + ci];
   }
   __syncthreads();
-  const int o = tid % Cout, bg = tid / Cout, ng = 512 / Cout;
+  const int o = tid % Cout, bg = tid / Cout;
   const float sg = conj_w ? -1.f : 1.f;
-  for (int bb0 = bg; bb0 < nb; bb0 += 8 * ng) {      // 8 batch rows per thread per sweep
-    float sr[8], si[8];
+  float sr[J], si[J];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sr[j] = 0.f; si[j] = 0.f; }
-    for (int i = 0; i < Cin; ++i) {
-      float2 wv = ws[(size_t)i * Cout + o];
-      wv.y *= sg;
+  for (int j = 0; j < J; ++j) { sr[j] = 0.f; si[j] = 0.f; }
+#pragma unroll 4
+  for (int i = 0; i < Cin; ++i) {
+    float2 wv = ws[(size_t)i * Cout + o];
+    wv.y *= sg;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int bb = bb0 + j * ng;
-        const float2 a = xs[(bb < nb ? bb : 0) * Cin + i];
-        sr[j] = fmaf(a.x, wv.x, sr[j]); sr[j] = fmaf(-a.y, wv.y, sr[j]);
-        si[j] = fmaf(a.x, wv.y, si[j]); si[j] = fmaf(a.y, wv.x, si[j]);
-      }
+    for (int j = 0; j < J; ++j) {
+      const int bb = bg + j * ng;
+      const float2 a = xs[(bb < nb ? bb : 0) * Cin + i];
+      sr[j] = fmaf(a.x, wv.x, sr[j]); sr[j] = fmaf(-a.y, wv.y, sr[j]);
+      si[j] = fmaf(a.x, wv.y, si[j]); si[j] = fmaf(a.y, wv.x, si[j]);
     }
+  }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int bb = bb0 + j * ng;
-      if (bb < nb) out[((size_t)(b0 + bb) * Ktot + k) * Cout + o] = make_float2(sr[j], si[j]);
-    }
+  for (int j = 0; j < J; ++j) {
+    const int bb = bg + j * ng;
+    if (bb < nb) out[((size_t)(b0 + bb) * Ktot + k) * Cout + o] = make_float2(sr[j], si[j]);
   }
 }
 
-// dW[k][i][o] = sum_b conj(X[b][k][i]) * G[b][k][o], one mode per workgroup, batch staged in LDS
-// in chunks of 64.   grid (Ktot), block 512, LDS 64*(Cin + Cout) float2; needs Cin <= 8 * (512/Cout)
+// dW[k][i][o] = sum_b conj(X[b][k][i]) * G[b][k][o]: a workgroup owns one mode and J * (512/Cout)
+// input channels; the batch is staged in LDS in chunks of 64.
+//   grid (Ktot, ceil(Cin / (J * 512/Cout))), block 512, LDS 64*(J*ng + Cout) float2
+template <int J>
 __global__ void __launch_bounds__(512) k_mode_gemm_dw_lds(const float2* __restrict__ x, const float2* __restrict__ g,
                                                           float2* __restrict__ dw, int B, int Ktot, int Cin,
                                                           int Cout) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float2* xs = reinterpret_cast<float2*>(smem);      // 64 x Cin
-  float2* gs = xs + (size_t)64 * Cin;                // 64 x Cout
   const int k = blockIdx.x, tid = threadIdx.x;
   const int o = tid % Cout, ig = tid / Cout, ng = 512 / Cout;
-  float sr[8], si[8];
+  const int IT = J * ng, i0 = blockIdx.y * IT;
+  float2* xs = reinterpret_cast<float2*>(smem);      // 64 x IT
+  float2* gs = xs + (size_t)64 * IT;                 // 64 x Cout
+  float sr[J], si[J];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sr[j] = 0.f; si[j] = 0.f; }
+  for (int j = 0; j < J; ++j) { sr[j] = 0.f; si[j] = 0.f; }
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int nb = min(64, B - b0);
     __syncthreads();
-    for (int i = tid; i < nb * Cin; i += 512) xs[i] = x[((size_t)(b0 + i / Cin) * Ktot + k) * Cin + i % Cin];
+    for (int i = tid; i < nb * IT; i += 512) {
+      const int bb = i / IT, ii = i0 + i % IT;
+      xs[i] = (ii < Cin) ? x[((size_t)(b0 + bb) * Ktot + k) * Cin + ii] : make_float2(0.f, 0.f);
+    }
     for (int i = tid; i < nb * Cout; i += 512) gs[i] = g[((size_t)(b0 + i / Cout) * Ktot + k) * Cout + i % Cout];
     __syncthreads();
+#pragma unroll 4
     for (int bb = 0; bb < nb; ++bb) {
       const float2 gg = gs[bb * Cout + o];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = ig + j * ng;
-        const float2 a = xs[bb * Cin + (i < Cin ? i : 0)];
+      for (int j = 0; j < J; ++j) {
+        const float2 a = xs[bb * IT + ig + j * ng];
         sr[j] = fmaf(a.x, gg.x, sr[j]); sr[j] = fmaf(a.y, gg.y, sr[j]);      // conj(a) * g
         si[j] = fmaf(a.x, gg.y, si[j]); si[j] = fmaf(-a.y, gg.x, si[j]);
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = ig + j * ng;
+  for (int j = 0; j < J; ++j) {
+    const int i = i0 + ig + j * ng;
     if (i < Cin) dw[((size_t)k * Cin + i) * Cout + o] = make_float2(sr[j], si[j]);
   }
 }
