@@ -689,24 +689,15 @@ static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
     return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
 }
-template <int C, int NCO>
-static int launch_pbwd_x3_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
-  const int pitch = p->NPX + 4;
-  const size_t small = ((size_t)NCO * p->NPX + kHID + NCO * kHID) * 4;
-  const size_t xbb = (size_t)3 * p->NPX * (C + 8) * 2;
-  const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + xbb <= 160 * 1024;
-  const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + xbb;
-  if (p->NPX == 128)
-    return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
-  return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
+static size_t pbwd_x3_lds(int C, int npx, int nco) {
+  return ((size_t)3 * npx * (C + 8) + (size_t)3 * C * (npx + 8) + (size_t)3 * 64 * (npx + 8)) * 2 +
+         ((size_t)nco * npx + kHID + (size_t)nco * kHID) * 4;
 }
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
-  if (a.wa1) {
-    const size_t xbb = (size_t)3 * p->NPX * (C + 8) * 2 + (size_t)(C + 64) * (p->NPX + 4) * 4 + 8192;
-    if (xbb <= 160 * 1024)
-      return a.CO == 1 ? launch_pbwd_x3_cn<C, 1>(p, st, grid, a) : launch_pbwd_x3_cn<C, PROJ_MAXCO>(p, st, grid, a);
-  }
+  // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
+  if (a.wa1 && a.CO == 1 && p->NPX == 128 && pbwd_x3_lds(C, 128, 1) <= 160 * 1024)
+    return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
   return a.CO == 1 ? launch_pbwd_cn<C, 1>(p, st, grid, a) : launch_pbwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
 }
 

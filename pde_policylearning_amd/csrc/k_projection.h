@@ -367,19 +367,20 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
   }
 }
 
-// Split-precision variant of k_proj_bwd: the P1 recompute (A1) and the dx product (A3) run as
-// bf16x3 MFMAs on the matrix cores with W1 fragments pre-split by k_pack_w1_x3 (L2-resident);
-// the dW1 product (B, K = pixels) stays fp32.  Otherwise identical:
-// wave (hm, nt) as in k_proj_fwd.  Per 64-row hidden chunk (ONE barrier per chunk, the dP1
-// chunk is double-buffered in LDS so wave groups run up to a chunk apart):
-//   A1  recompute P1 (MFMA 32x32x2)
-//   E   gl = gelu(P1), dP1 = gelu'(P1) * (W2^T dy); dW2 / db1 contributions are reduced over
-//       the 32 pixels of the wave with DPP adds (no LDS round trip); dP1 -> LDS
-//   A3  dx += W1^T dP1, dP1 fed to the MFMA straight from the accumulator registers (its row
-//       index is the k index of this product)
+// Split-precision variant of k_proj_bwd: ALL THREE GEMMs run as bf16x3 MFMAs on the matrix cores
+// (fno_dev.h) with W1 fragments pre-split by k_pack_w1_x3 (L2-resident); the fp32 lanes only do the
+// GELU / reductions / splits.  Wave (hm, nt) as in k_proj_fwd.  LDS holds three bf16x3 images:
+//   xb [3][NPX][C+8]    a, pixel-major   -> B operand of the P1 recompute (contraction over channels)
+//   xr [3][C][NPX+8]    a, row-major     -> B operand of dW1           (contraction over pixels)
+//   dr [3][64][NPX+8]   dP1 chunk, row-major -> A operand of dW1
+// Per 64-row hidden chunk:
+//   A1  recompute P1                                            (24 bf16 MFMAs per wave)
+//   E   gl = gelu(P1), dP1 = gelu'(P1) * (W2^T dy); DPP reductions for dW2 / db1; dP1 is split
+//       once: the three terms go to `dr` AND stay in registers as the B fragments of A3
+//   A3  dx += W1^T dP1 straight from those registers            (24 bf16 MFMAs)
 //   --- barrier ---
-//   B   dW1[chunk] += dP1 . a^T  (MFMA, K = pixels) by the wave group that owns this chunk,
-//       while the other group already recomputes the next chunk
+//   B   dW1[chunk] += dP1 . a^T by the wave group that owns the chunk   (48 bf16 MFMAs)
+//   --- barrier --- (dr is single-buffered)
 template <int C, int HID, int NPX, int NCO>
 __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs a) {
   using Cfg = ProjBwdCfg<C, HID, NPX>;
@@ -388,19 +389,20 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
   constexpr int NT = NW * 64;
   constexpr int PITCH = NPX + 4;
   constexpr int KB = C / 16;
-  using SP = SplitTilePrefetch<NPX, NT, C>;                  // only its layout constants are used
-  constexpr int kSmall = NCO * NPX + HID + NCO * HID;
-  constexpr int kXB = 3 * SP::TERM / 2;                      // floats taken by the bf16x3 activation arrays
-  // the dP1 chunk is double-buffered when two 64 x PITCH buffers fit beside the tile and the bf16 arrays
-  constexpr bool DBUF = ((C + 128) * (NPX + 4) + kSmall + kXB) * 4 <= 160 * 1024;
+  using SP = SplitTilePrefetch<NPX, NT, C>;      // layout constants of the pixel-major image
+  constexpr int RP = NPX + 8;                    // halfs per row of the row-major images
+  constexpr int XR_TERM = C * RP, DR_TERM = 64 * RP;
+  static_assert((size_t)C * PITCH * 4 <= (size_t)3 * DR_TERM * 2 && (size_t)C * PITCH * 4 <= (size_t)3 * XR_TERM * 2,
+                "fp32 tiles alias the bf16 images");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                        // C x PITCH        : a = act(u_L); later the gout tile
-  float* dps = xs + C * PITCH;             // 2 x 64 x PITCH   : dP1 chunks (double-buffered);
-                                           //                    after the chunk loop: dx partials of hm = 1
-  float* douts = dps + (DBUF ? 2 : 1) * 64 * PITCH;     // NCO x NPX
-  float* b1s = douts + NCO * NPX;          // HID
-  float* w2s = b1s + HID;                  // NCO x HID
-  unsigned short* xb = reinterpret_cast<unsigned short*>(w2s + NCO * HID);   // 3 x NPX x (C+8) halfs
+  unsigned short* xb = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* xr = xb + 3 * SP::TERM;
+  unsigned short* dr = xr + 3 * XR_TERM;
+  float* douts = reinterpret_cast<float*>(dr + 3 * DR_TERM);   // NCO x NPX
+  float* b1s = douts + NCO * NPX;                               // HID
+  float* w2s = b1s + HID;                                       // NCO x HID
+  float* tmpf = reinterpret_cast<float*>(dr);    // C x PITCH fp32: staging tile for the split pass, later the gout tile
+  float* part = reinterpret_cast<float*>(xr);    // C x PITCH fp32: dx partials of the hm = 1 waves (after the chunk loop)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15;
@@ -425,14 +427,31 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     for (int co = 0; co < NCO; ++co) sdw2[ch][co] = 0.f;
   }
 
-  TilePrefetch<NPX, NT, C, C> pfx;      // next tile's u_L rows, in flight during this tile
+  using PFX = TilePrefetch<NPX, NT, C, C>;
+  PFX pfx;      // next tile's u_L rows, in flight during this tile
   if ((int)blockIdx.x < a.ntiles)
     pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pfx.commit(xs, a.act_in != 0, tid);
+    // commit: a = act(u) -> fp32 staging tile + row-major bf16x3 image
+#pragma unroll
+    for (int i = 0; i < PFX::ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
+      float4 t = pfx.v[i];
+      if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
+      st4(tmpf + c * PITCH + 4 * q, t);
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+      unsigned short hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split3(tv[j], hh[j], mm[j], ll[j]);
+      unsigned short* dst = xr + c * RP + 4 * q;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+      *reinterpret_cast<uint2*>(dst + XR_TERM) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+      *reinterpret_cast<uint2*>(dst + 2 * XR_TERM) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+    }
     for (int idx = tid; idx < NCO * NPX; idx += NT) {
       const int co = idx / NPX, p = idx % NPX;
       douts[idx] = (co < a.CO) ? a.dy[((size_t)b * a.CO + co) * a.PW + px0 + p] : 0.f;
@@ -443,12 +462,12 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
       if (nt2 < a.ntiles)
         pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
     }
-    // split pass: fp32 tile [c][px] -> pixel-major bf16x3 arrays (A1's B operand)
+    // split pass: fp32 tile [c][px] -> pixel-major bf16x3 image (A1's B operand)
     for (int it = tid; it < NPX * (C / 8); it += NT) {
       const int px = it % NPX, cg = it / NPX;
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = xs[(cg * 8 + j) * PITCH + px];
+      for (int j = 0; j < 8; ++j) v[j] = tmpf[(cg * 8 + j) * PITCH + px];
       bf16x8 h, m, l;
       split3x8(v, h, m, l);
       unsigned short* dst = xb + px * SP::PBH + cg * 8;
@@ -456,7 +475,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
       st8h(dst + SP::TERM, m);
       st8h(dst + 2 * SP::TERM, l);
     }
-    __syncthreads();
+    __syncthreads();            // tmpf (= dr) is free from here on
     const unsigned short* xbp = xb + (n0 + l31) * SP::PBH + 8 * half;   // this lane's pixel row
     float dyl[NCO];
 #pragma unroll
@@ -470,7 +489,6 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-      float* dpb = dps + (DBUF ? (ch & 1) : 0) * 64 * PITCH;
       // ---- A1 ------------------------------------------------------------
       f32x16 acc;
 #pragma unroll
@@ -489,8 +507,9 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
         }
       }
       // ---- E ---------------------------------------------------------------
+      bf16x8 bd[2][3];      // dP1 split: accumulator registers 8s..8s+7 = B fragment of hidden k-block s
       {
-        float* dpp = dpb + (hm * 32 + 4 * half) * PITCH + n0 + l31;
+        unsigned short* drp = dr + (hm * 32 + 4 * half) * RP + n0 + l31;
         const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
         const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
         float rdb = 0.f, rdw[NCO];
@@ -505,8 +524,14 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
           float gl, dg;
           gelu_both(acc[r] + b1p[ro], gl, dg);
           const float dp = dg * t;
-          acc[r] = dp;
-          dpp[ro * PITCH] = dp;
+          unsigned short ph, pm, pl;
+          split3(dp, ph, pm, pl);
+          bd[r >> 3][0][r & 7] = (short)ph;
+          bd[r >> 3][1][r & 7] = (short)pm;
+          bd[r >> 3][2][r & 7] = (short)pl;
+          drp[ro * RP] = ph;
+          drp[ro * RP + DR_TERM] = pm;
+          drp[ro * RP + 2 * DR_TERM] = pl;
           const float sdp = half_reduce_sum(dp);
           rdb = (l15 == r) ? sdp : rdb;
 #pragma unroll
@@ -523,71 +548,64 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
             for (int co = 0; co < NCO; ++co) sdw2[k][co] += rdw[co];
           }
       }
-      // ---- A3 --------------------------------------------------------------
+      // ---- A3: W1^T fragments come in the accumulator's k order (k_pack_w1_x3) ------------
       {
-        // accumulator registers 8s..8s+7 are the B fragment of hidden k-block s (rows in the
-        // order 16s + 8(j>>2) + 4*half + (j&3)); wa3 holds W1^T fragments in that same k order
         const unsigned short* wa = a.wa3 + ((size_t)((ch * 2 + hm) * 2 * MT * 3) * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = acc[8 * s + j];
-          bf16x8 bd[3];
-          split3x8(v, bd[0], bd[1], bd[2]);
 #pragma unroll
           for (int mc = 0; mc < MT; ++mc) {
             bf16x8 af[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)((s * MT + mc) * 3 + t) * 64 * 8);
-            acc2[mc] = mfma_x3(af, bd, acc2[mc]);
+            acc2[mc] = mfma_x3(af, bd[s], acc2[mc]);
           }
         }
       }
       __syncthreads();
-      // ---- B -----------------------------------------------------------------
+      // ---- B: dW1[hid][c] += sum_px dP1[hid][px] a[c][px], both operands row-major bf16x3 -----
       if (dgrp == ch % G) {
-        const float* ga = dpb + (dmt * 32 + l31) * PITCH + 4 * half;
-        const float* ab = xs + (dnt * 32 + l31) * PITCH + 4 * half;
+        const unsigned short* ga = dr + (dmt * 32 + l31) * RP + 8 * half;
+        const unsigned short* ab = xr + (dnt * 32 + l31) * RP + 8 * half;
 #pragma unroll
         for (int k = 0; k < CPW; ++k)
           if (k == ch / G) {
             f32x16 dacc = dw1acc[k];
 #pragma unroll 2
-            for (int q = 0; q < NPX / 8; ++q) {
-              const float4 av = ld4(ga + 8 * q);
-              const float4 bv = ld4(ab + 8 * q);
-              dacc = mfma32(av.x, bv.x, dacc);
-              dacc = mfma32(av.y, bv.y, dacc);
-              dacc = mfma32(av.z, bv.z, dacc);
-              dacc = mfma32(av.w, bv.w, dacc);
+            for (int kq = 0; kq < NPX / 16; ++kq) {
+              bf16x8 af[3], bf[3];
+#pragma unroll
+              for (int t = 0; t < 3; ++t) {
+                af[t] = ld8h(ga + t * DR_TERM + kq * 16);
+                bf[t] = ld8h(ab + t * XR_TERM + kq * 16);
+              }
+              dacc = mfma_x3(af, bf, dacc);
             }
             dw1acc[k] = dacc;
           }
       }
-      if (!DBUF) __syncthreads();   // single buffer: the next chunk overwrites it
+      __syncthreads();   // dr is rewritten by the next chunk
     }
-    __syncthreads();   // all dW1 GEMMs done with xs / dps
 
     // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
     if (hm == 1) {
-      float* dpp = dps + (4 * half) * PITCH + n0 + l31;
+      float* pp = part + (4 * half) * PITCH + n0 + l31;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dpp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
+        for (int r = 0; r < 16; ++r) pp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
     }
     __syncthreads();
     if (hm == 0) {
-      const float* dpp = dps + (4 * half) * PITCH + n0 + l31;
-      float* xp = xs + (4 * half) * PITCH + n0 + l31;
+      const float* pp = part + (4 * half) * PITCH + n0 + l31;
+      float* xp = tmpf + (4 * half) * PITCH + n0 + l31;
       const size_t goff = ((size_t)b * C + 4 * half) * a.PW + px0 + n0 + l31;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc2[m][r] + dpp[ro * PITCH];
+          float v = acc2[m][r] + pp[ro * PITCH];
           if (a.act_in) v *= gelu_grad_f(a.x[goff + (size_t)ro * a.PW]);
           a.gout[goff + (size_t)ro * a.PW] = v;
           if (a.x1g) xp[ro * PITCH] = v;
@@ -595,7 +613,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     }
     if (a.x1g) {
       __syncthreads();
-      row_dft_epilogue<C, NPX, NW>(xs, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<C, NPX, NW>(tmpf, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();
   }
