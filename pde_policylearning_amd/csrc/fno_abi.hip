@@ -55,6 +55,12 @@ static std::vector<ProfRec> g_recs;
 struct ProfAgg { std::string name; float ms; int n; };
 static std::vector<ProfAgg> g_agg;
 
+#ifdef FNO_TRACE
+extern "C" int fno_debug_trace_dump(unsigned long long* host, size_t n) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" void fno_profile_enable(int on) { g_prof = on != 0; }
 extern "C" void fno_profile_reset(void) {
   for (auto& r : g_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -501,6 +507,12 @@ static const int kHID = 256;
 #ifndef FNO_GRID_PW
 #define FNO_GRID_PW 2
 #endif
+#ifndef FNO_GRID_PWX
+#define FNO_GRID_PWX 4
+#endif
+#ifndef FNO_NTW_PWX
+#define FNO_NTW_PWX 2   // 4-wave workgroups, two per CU
+#endif
 #ifndef FNO_GRID_PF
 #define FNO_GRID_PF 1
 #endif
@@ -635,8 +647,9 @@ template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   if (p->NPX == 128)
-    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
-  return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256>, dim3(grid), dim3((C / 32) * 8 * 64), lds, st, a);
+    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+                  lds, st, a);
+  return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
 }
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   if (g_gemm_x3) return p->d.C == 32 ? launch_block_x3<32>(p, st, grid, a) : launch_block_x3<64>(p, st, grid, a);
@@ -762,7 +775,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.act_out = (d.gelu_mask >> l) & 1u;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? 1 : FNO_GRID_PW) * p->ncu), a));
+    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
 
   // projection (tfno.py:34-38)

@@ -173,11 +173,18 @@ static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ
   return bytes + fl * 4;
 }
 
-template <int C, int NPX>
-__global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
+#ifndef FNO_TRACE_SEL
+#define FNO_TRACE_SEL (a.act_in && a.act_out)
+#endif
+// NTW = 32-pixel column tiles per wave.  NTW = 2 halves the workgroup (4 waves at C = 64, NPX = 128)
+// so that TWO workgroups share a CU at the same 256-VGPR budget per wave: their phases (split /
+// MFMA / epilogue / row DFT) drift apart and the matrix pipe of one overlaps the VALU work of the other.
+template <int C, int NPX, int NTW>
+__global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;
+  constexpr int NTG = NTN / NTW;          // wave groups along the pixel dimension
   constexpr int MT = C / 32;
-  constexpr int NW = MT * NTN;
+  constexpr int NW = MT * NTG;
   constexpr int NT = NW * 64;
   constexpr int KB = C / 16;
   constexpr int PITCH = NPX + 4;
@@ -195,8 +202,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_PWX) k_pw_
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int mt = wave / NTN, nt = wave % NTN;
-  const int n0 = nt * 32;
+  const int mt = wave / NTG, ng = wave % NTG;
 
   if (a.z)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
@@ -224,60 +230,81 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_PWX) k_pw_
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
+  int tslot = 0;
+  FNO_TRACE_IF(FNO_TRACE_SEL);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-
+    FNO_STAMP(tslot + 0);
     pf.commit(xb, a.act_in != 0, tid);
     if (tid < zcount4) st4(zs + 4 * tid, zpf);
+    for (int i = tid + NT; i < zcount4; i += NT)   // rare tail (small workgroups): straight from L2
+      st4(zs + 4 * i, ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
+    FNO_STAMP(tslot + 1);
     __syncthreads();
+    FNO_STAMP(tslot + 2);
     if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
 
-    f32x16 acc;
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int q = 0; q < NTW; ++q) {
+      const int n0 = (ng * NTW + q) * 32;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      bf16x8 bf[3];
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) bf[t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
-      acc = mfma_x3(afrag[kb], bf, acc);
-    }
-    if (a.z) {
-      const int rr = n0 / a.W;
-      const float* zr = zs + ((rr * a.K2in) * C + mt * 32 + l31) * 2 + half;
-      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+      for (int kb = 0; kb < KB; ++kb) {
+        bf16x8 bf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bf[t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
+        acc[q] = mfma_x3(afrag[kb], bf, acc[q]);
+      }
+      if (a.z) {
+        const int rr = n0 / a.W;
+        const float* zr = zs + ((rr * a.K2in) * C + mt * 32 + l31) * 2 + half;
+        const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
 #pragma unroll 2
-      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
+        for (int s = 0; s < a.K2in; ++s) acc[q] = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc[q]);
+      }
     }
+    FNO_STAMP(tslot + 3);
     __syncthreads();  // all waves are done reading the staged input (the output tile reuses it)
+    FNO_STAMP(tslot + 4);
 
     {
-      float* up = a.u ? a.u + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
-      float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
       const float* bp = a.bias ? a.bias + mt * 32 + 4 * half : nullptr;
-      if (bp) {
+      float bv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += bp[(r & 3) + 8 * (r >> 2)];
-      }
-      if (up) {
+      for (int r = 0; r < 16; ++r) bv[r] = bp ? bp[(r & 3) + 8 * (r >> 2)] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[r];
-      }
-      if (a.x1) {
-        if (a.act_out) {
+      for (int q = 0; q < NTW; ++q) {
+        const int n0 = (ng * NTW + q) * 32;
+        float* up = a.u ? a.u + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
+        float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = gelu_f(acc[r]);
-        } else {
+        for (int r = 0; r < 16; ++r) acc[q][r] += bv[r];
+        if (up) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
+          for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[q][r];
+        }
+        if (a.x1) {
+          if (a.act_out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = gelu_f(acc[q][r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[q][r];
+          }
         }
       }
     }
+    FNO_STAMP(tslot + 5);
     if (a.x1) {
       __syncthreads();
+      FNO_STAMP(tslot + 6);
       row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
+    FNO_STAMP(tslot + 7);
     __syncthreads();
+    tslot += 8;
   }
 }
