@@ -130,6 +130,28 @@ int fno_model_backward(const FnoModelPlan* plan, int batch, const FnoModelParams
                        const float* dy, const void* saved, const FnoModelGrads* g, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* ------------------------------------------------------------------------
+ * Training-step tail (run_pde_observers.py:185-193), SURVEY.md section 8(f) rank 2.
+ * Loss: pd = pred*(std+eps)+mean, td = target*(std+eps)+mean  (NormalizerGivenMeanStd.cuda_decode,
+ * libs/utilities3.py:115-129; mean/std NULL = identity; stat_len = 1 or n, broadcast over the batch),
+ * loss = sum_b ||pd_b - td_b||_2 / ||td_b||_2, divided by batch when size_average
+ * (LpLoss.rel, libs/utilities3.py:323-334).  forward leaves per-sample coefficients in `ws`
+ * (fno_lploss_workspace_bytes) for backward, which writes dloss/dpred scaled by the device scalar
+ * *grad_loss (NULL = 1).  No host synchronisation (the reference's loss.item() is the caller's choice).
+ * ---------------------------------------------------------------------- */
+size_t fno_lploss_workspace_bytes(int batch);
+int fno_lploss_rel_forward(int batch, size_t n_per_sample, const float* pred, const float* target, const float* mean,
+                           const float* std, int stat_len, float eps, int size_average, float* loss /*device scalar*/,
+                           void* ws, size_t ws_bytes, void* stream);
+int fno_lploss_rel_backward(int batch, size_t n_per_sample, const float* pred, const float* target, const float* std,
+                            int stat_len, float eps, const float* grad_loss, float* dpred, const void* ws,
+                            size_t ws_bytes, void* stream);
+/* torch.optim.Adam (run_pde_observers.py:134: lr, weight_decay as L2 added to the gradient; no amsgrad)
+ * on ONE flat fp32 bucket of n elements: param / grad / exp_avg / exp_avg_sq, 16-byte aligned.
+ * `step` is the 1-based step count (bias corrections are computed on the host in double). */
+int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

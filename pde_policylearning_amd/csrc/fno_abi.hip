@@ -17,6 +17,7 @@
 #include "k_pointwise.h"
 #include "k_projection.h"
 #include "k_spectral_mid.h"
+#include "k_train.h"
 
 // --------------------------------------------------------------------------
 // errors
@@ -877,5 +878,60 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
     LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st,
                      (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C));
   }
+  return FNO_OK;
+}
+
+// ===========================================================================
+// Training-step tail: fused decode + LpLoss.rel (+ gradient) and Adam on a flat bucket
+// ===========================================================================
+static const int kLossSplit = 16;
+extern "C" size_t fno_lploss_workspace_bytes(int batch) {
+  return ((size_t)batch * kLossSplit * 2 + (size_t)batch) * sizeof(float);
+}
+extern "C" int fno_lploss_rel_forward(int batch, size_t n, const float* pred, const float* target, const float* mean,
+                                      const float* stdv, int stat_len, float eps, int size_average, float* loss,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  if (batch < 1 || n < 1 || !pred || !target || !loss || !ws) return fail(FNO_EINVAL, "fno_lploss_rel_forward: bad argument");
+  if ((mean || stdv) && stat_len != 1 && (size_t)stat_len != n)
+    return fail(FNO_EINVAL, "decode statistics must have 1 or %zu elements, got %d", n, stat_len);
+  if (ws_bytes < fno_lploss_workspace_bytes(batch))
+    return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", fno_lploss_workspace_bytes(batch), ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* coef = partial + (size_t)batch * kLossSplit * 2;
+  LAUNCHCHK(launch("k_lploss_partial", k_lploss_partial, dim3(kLossSplit, batch), dim3(256), 0, st, pred, target, mean, stdv,
+                   stat_len, eps, n, partial));
+  LAUNCHCHK(launch("k_lploss_finish", k_lploss_finish, dim3(1), dim3(256), 0, st, (const float*)partial, batch, kLossSplit,
+                   size_average ? 1.0f / (float)batch : 1.0f, loss, coef));
+  return FNO_OK;
+}
+extern "C" int fno_lploss_rel_backward(int batch, size_t n, const float* pred, const float* target, const float* stdv,
+                                       int stat_len, float eps, const float* grad_loss, float* dpred, const void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (batch < 1 || n < 1 || !pred || !target || !dpred || !ws) return fail(FNO_EINVAL, "fno_lploss_rel_backward: bad argument");
+  if (stdv && stat_len != 1 && (size_t)stat_len != n)
+    return fail(FNO_EINVAL, "decode statistics must have 1 or %zu elements, got %d", n, stat_len);
+  if (ws_bytes < fno_lploss_workspace_bytes(batch)) return fail(FNO_ENOMEM, "workspace too small");
+  const float* coef = (const float*)ws + (size_t)batch * kLossSplit * 2;
+  const int gx = (int)std::min<size_t>((n + 1023) / 1024, 64);
+  LAUNCHCHK(launch("k_lploss_grad", k_lploss_grad, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, pred, target, stdv,
+                   stat_len, eps, n, coef, grad_loss, dpred));
+  return FNO_OK;
+}
+extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!n) return FNO_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(FNO_EINVAL, "fno_adam_step: bad argument");
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+    return fail(FNO_EINVAL, "fno_adam_step: buffers must be 16-byte aligned");
+  AdamArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  a.step_size = (float)((double)lr / bc1);
+  a.bc2_sqrt = (float)std::sqrt(bc2);
+  int ncu = 256;
+  const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)ncu * 8);
+  LAUNCHCHK(launch("k_adam", k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
   return FNO_OK;
 }

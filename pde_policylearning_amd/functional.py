@@ -245,3 +245,66 @@ def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, mo
                           spec_bias=spec_bias.grad if spec_bias is not None else None)
     cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
     return _FNOModelFn.apply(cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *skip_ws, *spec_ws)
+
+
+# ----------------------------------------------------------------------------
+# training-step tail: decode + relative-L2 loss, Adam on a flat bucket
+# ----------------------------------------------------------------------------
+class _LpLossRelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mean, std, eps, size_average):
+        _require_cuda(pred, "pred")
+        _require_cuda(target, "target")
+        L = _lib.lib()
+        B = pred.shape[0]
+        pred_c, tgt_c = pred.contiguous(), target.contiguous()
+        n = pred_c.numel() // B
+        if tgt_c.numel() != pred_c.numel():
+            raise RuntimeError(f"fnoengine lp_loss_rel: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+        stat_len = 1
+        for s in (mean, std):
+            if s is not None:
+                _require_cuda(s, "mean/std")
+                stat_len = s.numel()
+        if mean is not None and std is not None and mean.numel() != std.numel():
+            raise RuntimeError("fnoengine lp_loss_rel: mean and std must have the same number of elements")
+        mean_c = mean.contiguous() if mean is not None else None
+        std_c = std.contiguous() if std is not None else None
+        nws = L.fno_lploss_workspace_bytes(B)
+        ws = _bytes(nws, pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.check(L.fno_lploss_rel_forward(B, n, _ptr(pred_c), _ptr(tgt_c), _ptr(mean_c), _ptr(std_c), stat_len,
+                                            float(eps), int(bool(size_average)), _ptr(loss), _ptr(ws), nws, _stream()),
+                   "lploss_rel_forward")
+        ctx.save_for_backward(pred_c, tgt_c, std_c if std_c is not None else pred_c.new_empty(0), ws)
+        ctx.meta = (B, n, stat_len, float(eps), std_c is not None, nws, pred.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred_c, tgt_c, std_c, ws = ctx.saved_tensors
+        B, n, stat_len, eps, has_std, nws, shape = ctx.meta
+        L = _lib.lib()
+        dpred = torch.empty_like(pred_c)
+        g = gloss.contiguous().to(torch.float32)
+        _lib.check(L.fno_lploss_rel_backward(B, n, _ptr(pred_c), _ptr(tgt_c), _ptr(std_c if has_std else None), stat_len,
+                                             eps, _ptr(g), _ptr(dpred), _ptr(ws), nws, _stream()), "lploss_rel_backward")
+        return dpred.view(shape), None, None, None, None, None
+
+
+def lp_loss_rel(pred, target, mean=None, std=None, eps=1e-5, size_average=False):
+    """LpLoss(d=2, p=2).rel of the DECODED fields in two streaming passes (libs/utilities3.py:115-129,
+    323-334; run_pde_observers.py:188-192).  mean / std: None (no decode), scalars or per-element planes
+    broadcast over the batch."""
+    return _LpLossRelFn.apply(pred, target, mean, std, eps, size_average)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One torch.optim.Adam update of a flat fp32 bucket, in place, one kernel."""
+    for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _require_cuda(t, name)
+        if not t.is_contiguous() or t.numel() != param.numel():
+            raise RuntimeError(f"fnoengine adam_step: `{name}` must be contiguous with {param.numel()} elements")
+    _lib.check(_lib.lib().fno_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                        float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                        int(step), _stream()), "adam_step")

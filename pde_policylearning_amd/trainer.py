@@ -38,6 +38,24 @@ class LpLoss(object):
         return self.rel(x, y)
 
 
+class FusedLpLoss(LpLoss):
+    """LpLoss whose relative form (the one the training loops call) runs in the engine: decode of
+    prediction and target, both norms and the gradient in two streaming passes over the fields
+    (include/fnoengine.h fno_lploss_rel_*).  `decoder` = MeanStdDecoder or None.  GPU only."""
+
+    def __init__(self, d=2, p=2, size_average=True, reduction=True, decoder=None):
+        super().__init__(d, p, size_average, reduction)
+        assert p == 2 and reduction, "the engine implements the reduced L2 form used by the training loops"
+        self.decoder = decoder
+
+    def rel(self, x, y):
+        from . import functional as F
+        dec = self.decoder
+        mean = dec.mean.to(x.device) if dec is not None else None
+        std = dec.std.to(x.device) if dec is not None else None
+        return F.lp_loss_rel(x, y, mean, std, dec.eps if dec is not None else 0.0, self.size_average)
+
+
 class MeanStdDecoder(object):
     """x * (std + eps) + mean  (NormalizerGivenMeanStd.cuda_decode, libs/utilities3.py:115-129),
     with the statistics placed on the model's device once."""
@@ -98,6 +116,46 @@ class FlatGradBucket(object):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
+class FusedAdam(object):
+    """torch.optim.Adam semantics (run_pde_observers.py:134: lr, weight_decay, default betas / eps) as ONE
+    kernel over a flat parameter bucket.  Parameters are re-pointed at views of one contiguous buffer
+    laid out exactly like the FlatGradBucket, so the step reads the all-reduced gradient bucket directly."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.bucket = bucket
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.flat_param = torch.empty_like(bucket.flat)
+        off = 0
+        with torch.no_grad():
+            for p in bucket.params:
+                v = self.flat_param[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                off += p.numel()
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero()
+
+    def step(self):
+        from . import functional as F
+        self.bucket.check_views()
+        self.step_count += 1
+        F.adam_step(self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                    self.betas, self.eps, self.weight_decay)
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
+                    eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
 def broadcast_parameters(module, src=0, group=None):
     """Identical replicas on every rank (rank `src` wins)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -118,12 +176,18 @@ def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=Non
     (run_pde_observers.py:185-193).  Returns the local loss tensor (no host sync)."""
     bucket.zero()
     pred = model_fn(*inputs)
-    if decoder is not None:
-        pred = decoder.decode(pred.reshape(target.shape))
-        tgt = decoder.decode(target)
+    if isinstance(loss_fn, FusedLpLoss):
+        # decode, both norms and the gradient happen inside the engine's loss kernels
+        if decoder is not None:
+            loss_fn.decoder = decoder
+        loss = loss_fn(pred.reshape(target.shape), target)
     else:
-        tgt = target
-    loss = loss_fn(pred, tgt)
+        if decoder is not None:
+            pred = decoder.decode(pred.reshape(target.shape))
+            tgt = decoder.decode(target)
+        else:
+            tgt = target
+        loss = loss_fn(pred, tgt)
     loss.backward()
     bucket.all_reduce()
     if optimizer is not None:

@@ -319,3 +319,90 @@ def test_direct_gradient_write_matches_autograd_accumulation(dev):
         train_step(m1, b1, None, (x,), t, LpLoss(size_average=False))
         train_step(m2, b2, None, (x,), t, LpLoss(size_average=False))
         assert torch.equal(b1.flat, b2.flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# training-step tail: fused decode + LpLoss, fused Adam
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stats", ["none", "scalar", "plane"])
+@pytest.mark.parametrize("size_average", [False, True])
+def test_fused_lploss_matches_reference_formula(dev, stats, size_average):
+    """fno_lploss_rel_* vs the torch restatement of cuda_decode + LpLoss.rel
+    (libs/utilities3.py:115-129, 323-334), value and gradient; tolerance 1e-5 relative."""
+    from pde_policylearning_amd.trainer import FusedLpLoss, LpLoss, MeanStdDecoder
+    torch.manual_seed(5)
+    B, S = 6, 40                                    # ragged: 1600 elements per sample, not a multiple of the block
+    pred = torch.randn(B, S, S, device=dev, requires_grad=True)
+    tgt = torch.randn(B, S, S, device=dev)
+    dec = None
+    if stats == "scalar":
+        dec = MeanStdDecoder(0.37, 1.9, device=dev)
+    elif stats == "plane":
+        dec = MeanStdDecoder(torch.randn(S, S).numpy(), (torch.rand(S, S) + 0.5).numpy(), device=dev)
+    ref_in = pred.detach().clone().requires_grad_(True)
+    a, b = (dec.decode(ref_in), dec.decode(tgt)) if dec is not None else (ref_in, tgt)
+    ref = LpLoss(size_average=size_average)(a.view(B, -1), b.view(B, -1))
+    ref.backward()
+    out = FusedLpLoss(size_average=size_average, decoder=dec)(pred, tgt)
+    (out * 1.0).backward()
+    assert abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_l2(_cpu(pred.grad), _cpu(ref_in.grad)) < 1e-5
+
+
+def test_fused_lploss_upstream_scale_and_zero_difference(dev):
+    """The upstream gradient scalar is applied on the device; a sample equal to its target gets a zero
+    gradient (torch.norm's subgradient) instead of NaN."""
+    from pde_policylearning_amd import functional as F
+    tgt = torch.randn(3, 8, 8, device=dev)
+    pred = (tgt + torch.randn(3, 8, 8, device=dev)).requires_grad_(True)
+    with torch.no_grad():
+        pred[1] = tgt[1]
+    (F.lp_loss_rel(pred, tgt) * 2.5).backward()
+    g1 = pred.grad.clone()
+    pred.grad = None
+    F.lp_loss_rel(pred, tgt).backward()
+    assert torch.isfinite(g1).all() and float(g1[1].abs().max()) == 0.0
+    assert rel_l2(_cpu(g1), _cpu(pred.grad * 2.5)) < 1e-6
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """fno_adam_step on the flat bucket vs torch.optim.Adam(lr, weight_decay) for 6 steps, ragged sizes."""
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam
+    torch.manual_seed(11)
+    shapes = [(7, 5), (33,), (4, 4, 3, 3, 2), (1,), (129,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-3, weight_decay=1e-4)
+    bucket = FlatGradBucket(my_p)
+    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
+    for step in range(6):
+        grads = [torch.randn(s, device=dev) * (0.1 + step) for s in shapes]
+        for p, q, g in zip(ref_p, my_p, grads):
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        ref_opt.step()
+        opt.step()
+        for p, q in zip(ref_p, my_p):
+            assert rel_l2(_cpu(q.data), _cpu(p.data)) < 1e-6, step
+    assert all(q.data.data_ptr() >= opt.flat_param.data_ptr() for q in my_p)
+
+
+def test_fno2d_observer_train_trajectory_fused_tail(dev):
+    """Same fixture as above with the WHOLE step in the engine: fused model, fused decode+loss, fused Adam
+    writing into the direct-gradient bucket."""
+    from pde_policylearning_amd.libs.models.fno_models import FNO2dObserver
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, MeanStdDecoder, train_step
+    g = load_golden("observer_adam3")
+    B, S = g["p_plane"].shape[0], g["p_plane"].shape[1]
+    model = FNO2dObserver(8, 8, 16)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(rebuild_params(g["scales"], shapes))
+    model = model.to(dev)
+    bucket = FlatGradBucket(model.parameters())
+    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
+    dec = MeanStdDecoder(g["mean"], g["std"], device=dev)
+    pp, tgt = _t(g["p_plane"], dev), _t(g["target"], dev).reshape(B, S, S)
+    loss_fn = FusedLpLoss(size_average=False, decoder=dec)
+    for step in range(3):
+        loss = train_step(lambda a: model(a, None), bucket, opt, (pp,), tgt, loss_fn)
+        assert abs(float(loss) - float(g["losses"][step])) < 5e-5 * abs(float(g["losses"][step])), step
