@@ -93,6 +93,40 @@ FNO_DEV float half_reduce_sum(float v) {
   return v + __shfl_xor(v, 16, 64);
 }
 
+// Transposed reduction: every lane holds 16 values v[0..15] (one per accumulator register); on return
+// each lane holds ONE total, sum over the 32 lanes of its wave half of v[rid], rid = reduce16_id(lane).
+// Each butterfly step halves the number of live values (the lane keeps the half selected by one of its
+// lane-id bits and adds the partner's partial of that half), so the whole reduction costs 3 VALU ops per
+// input value instead of the 6 of sixteen independent all-lane reductions.
+//   step (xor mask, select bit): (8, b3) (7, b2) (2, b1) (1, b0), then one cross-row add (xor 16).
+template <int CTRL>
+FNO_DEV float dpp_xchg_(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+FNO_DEV int reduce16_id(int lane) { return ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 1) & 1) << 2) | ((lane & 1) << 3); }
+FNO_DEV float half_reduce16(const float (&v)[16], int lane) {
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+  float w[8], u[4], t[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float keep = b3 ? v[2 * k + 1] : v[2 * k], send = b3 ? v[2 * k] : v[2 * k + 1];
+    w[k] = keep + dpp_xchg_<0x128>(send);          // row_ror:8  (lane ^ 8)
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = b2 ? w[2 * k + 1] : w[2 * k], send = b2 ? w[2 * k] : w[2 * k + 1];
+    u[k] = keep + dpp_xchg_<0x141>(send);          // row_half_mirror (lane ^ 7)
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b1 ? u[2 * k + 1] : u[2 * k], send = b1 ? u[2 * k] : u[2 * k + 1];
+    t[k] = keep + dpp_xchg_<0x4E>(send);           // quad_perm [2,3,0,1] (lane ^ 2)
+  }
+  const float keep = b0 ? t[1] : t[0], send = b0 ? t[0] : t[1];
+  const float r = keep + dpp_xchg_<0xB1>(send);    // quad_perm [1,0,3,2] (lane ^ 1)
+  return r + __shfl_xor(r, 16, 64);
+}
+
 // ---------------------------------------------------------------------------
 // fp32-grade GEMMs on the bf16 matrix cores: every fp32 operand is split into three bf16 terms
 // x = h + m + l (8 + 8 + 8 significant bits) and the product keeps the six terms of weight

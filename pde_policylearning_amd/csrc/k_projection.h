@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
   for (int k = 0; k < CPW; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dw1acc[k][r] = 0.f;
-  // lane (l15, half) accumulates hidden row  ch*64 + hm*32 + acc_row32(l15, half)  of every chunk
+  // lane accumulates hidden row  ch*64 + hm*32 + acc_row32(reduce16_id(lane), half)  of every chunk
   float sdb1[NCH], sdw2[NCH][NCO];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -512,9 +512,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
         unsigned short* drp = dr + (hm * 32 + 4 * half) * RP + n0 + l31;
         const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
         const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
-        float rdb = 0.f, rdw[NCO];
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) rdw[co] = 0.f;
+        float dpv[16], glv[NCO][16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = (r & 3) + 8 * (r >> 2);
@@ -532,14 +530,15 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
           drp[ro * RP] = ph;
           drp[ro * RP + DR_TERM] = pm;
           drp[ro * RP + 2 * DR_TERM] = pl;
-          const float sdp = half_reduce_sum(dp);
-          rdb = (l15 == r) ? sdp : rdb;
+          dpv[r] = dp;
 #pragma unroll
-          for (int co = 0; co < NCO; ++co) {
-            const float sg = half_reduce_sum(gl * dyl[co]);
-            rdw[co] = (l15 == r) ? sg : rdw[co];
-          }
+          for (int co = 0; co < NCO; ++co) glv[co][r] = gl * dyl[co];
         }
+        // pixel sums of this wave's 32 columns: lane -> accumulator register reduce16_id(lane)
+        const float rdb = half_reduce16(dpv, lane);
+        float rdw[NCO];
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) rdw[co] = half_reduce16(glv[co], lane);
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
           if (k == ch) {
@@ -632,7 +631,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     const size_t slab = (size_t)blockIdx.x * NTN + nt;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const int hid = ch * 64 + hm * 32 + acc_row32(l15, half);
+      const int hid = ch * 64 + hm * 32 + acc_row32(reduce16_id(lane), half);
       a.db1_part[slab * HID + hid] = sdb1[ch];
 #pragma unroll
       for (int co = 0; co < NCO; ++co)
