@@ -508,6 +508,9 @@ static const int kHID = 256;
 #ifndef FNO_GRID_PW
 #define FNO_GRID_PW 2
 #endif
+#ifndef FNO_BBWD_X3
+#define FNO_BBWD_X3 1
+#endif
 #ifndef FNO_GRID_PWX
 #define FNO_GRID_PWX 4
 #endif
@@ -657,12 +660,21 @@ static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const P
   if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a, "k_pw_fwd_block");
   return launch_pw<64, 64>(p, st, grid, a, "k_pw_fwd_block");
 }
+static size_t bbwd_x3_lds(int C, int npx, const BlkBwdArgs& a) {
+  return (size_t)6 * C * (npx + 8) * 2 +
+         ((size_t)C * (npx + 4) + (a.xin ? 8 * (npx + 4) : 0) +
+          (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(npx / a.W) * a.K2in * C * 2 : 0) +
+          (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
+}
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   const size_t pitch = p->NPX + 4;
+  if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
+    return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+                  bbwd_x3_lds(C, 128, a), st, a);
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
                       (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
-                      (a.x1g ? (size_t)16 * a.NJ * (a.W + 2) : 0)) * 4;
+                      (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
   if (p->NPX == 128)
     return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
   return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);

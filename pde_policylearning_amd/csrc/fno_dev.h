@@ -261,7 +261,7 @@ FNO_DEV void stage_rows_t(float* dst, const float* src, size_t row_stride, bool 
 // Truncated row DFT of the tile held in LDS (rows = channels), fp32 MFMA 16x16x4:
 //   X1[b, prow, k2, c] = sum_w tile[c][r*W + w] * (tfwd[2k2][w] + i tfwd[2k2+1][w])
 // D[row = j][col = c]: a lane ends up with (re, im) pairs -> float2 stores, 128-B runs.
-// `tfwd` rows are `tpitch` floats apart (W in HBM; W + 2 for the bank-conflict-free LDS copy).
+// `tfwd` rows are `tpitch` floats apart (W in HBM; W + 4 for the 16-B aligned, bank-conflict-free LDS copy).
 template <int NCH, int NPX, int NW>
 FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd, int tpitch, float* __restrict__ x1,
                               int b, int px0, int P, int W, int K2out, int NJ, int wave, int lane) {
@@ -274,12 +274,18 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
     const int rr = (job / (NCH / 16)) % R;
     const int jt = job / ((NCH / 16) * R);
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-    const float* tf = tfwd + (size_t)(jt * 16 + l15) * tpitch + quad;
-    const float* xr = tile + (nt * 16 + l15) * PITCH + rr * W + quad;
+    // k index of MFMA #t in group q: quad <-> pixel 16q + 4*quad + t, so each lane feeds four
+    // MFMAs from ONE b128 read per operand (two independent accumulation chains)
+    const float* tf = tfwd + (size_t)(jt * 16 + l15) * tpitch + 4 * quad;
+    const float* xr = tile + (nt * 16 + l15) * PITCH + rr * W + 4 * quad;
 #pragma unroll 4
-    for (int s = 0; s < W / 4; s += 2) {       // two independent accumulation chains
-      d0 = mfma16(tf[4 * s], xr[4 * s], d0);
-      d1 = mfma16(tf[4 * s + 4], xr[4 * s + 4], d1);
+    for (int q = 0; q < W / 16; ++q) {
+      const float4 av = ld4(tf + 16 * q);
+      const float4 bv = ld4(xr + 16 * q);
+      d0 = mfma16(av.x, bv.x, d0);
+      d1 = mfma16(av.y, bv.y, d1);
+      d0 = mfma16(av.z, bv.z, d0);
+      d1 = mfma16(av.w, bv.w, d1);
     }
     const int prow = px0 / W + rr;
     const int c = nt * 16 + l15;

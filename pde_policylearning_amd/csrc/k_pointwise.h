@@ -50,7 +50,7 @@ static inline size_t pw_fwd_lds_bytes(int cin, int cout, int npx, int W, int K2i
   const int rows = ((cin + 1) & ~1) > cout ? ((cin + 1) & ~1) : cout;
   size_t fl = (size_t)rows * (npx + 4);
   if (has_z) fl += (size_t)2 * K2in * W + (size_t)(npx / W) * K2in * cout * 2;
-  if (has_x1) fl += (size_t)16 * NJ * (W + 2);
+  if (has_x1) fl += (size_t)16 * NJ * (W + 4);
   return fl * 4;
 }
 
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
   if (a.z)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 2) + i % a.W] = a.tfwd[i];
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
 
   // weight fragments: A[i = o][k = c], constant over all tiles of this workgroup
   float afrag[KS];
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
     }
     if (a.x1) {
       __syncthreads();
-      row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
   }
@@ -169,12 +169,12 @@ static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ
   if (out_tile > bytes) bytes = out_tile;
   size_t fl = 0;
   if (has_z) fl += (size_t)2 * K2in * W + (size_t)(npx / W) * K2in * c * 2;
-  if (has_x1) fl += (size_t)16 * NJ * (W + 2);
+  if (has_x1) fl += (size_t)16 * NJ * (W + 4);
   return bytes + fl * 4;
 }
 
 #ifndef FNO_TRACE_SEL
-#define FNO_TRACE_SEL (a.act_in && a.act_out)
+#define FNO_TRACE_SEL false
 #endif
 // NTW = 32-pixel column tiles per wave.  NTW = 2 halves the workgroup (4 waves at C = 64, NPX = 128)
 // so that TWO workgroups share a CU at the same 256-VGPR budget per wave: their phases (split /
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
   if (a.z)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 2) + i % a.W] = a.tfwd[i];
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
 
   // weight fragments A[i = o][k = c] split into (h, m, l), constant over all tiles
   bf16x8 afrag[KB][3];
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     if (a.x1) {
       __syncthreads();
       FNO_STAMP(tslot + 6);
-      row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 2, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     FNO_STAMP(tslot + 7);
     __syncthreads();
