@@ -111,7 +111,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
   int tslot = 0;
-  FNO_TRACE_IF(a.act_in && a.x1g && a.zg);
+  FNO_TRACE_IF(false);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   };
 
   int tslot = 0;
-  FNO_TRACE_IF(a.act_in && a.x1g && a.zg);
+  FNO_TRACE_IF(false);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;

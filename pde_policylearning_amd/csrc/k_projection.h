@@ -427,14 +427,25 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     for (int co = 0; co < NCO; ++co) sdw2[ch][co] = 0.f;
   }
 
+  bf16x8 afn[KB][3];     // A fragments (W1 rows of this wave) of the chunk about to be recomputed
+  auto load_w1 = [&](int ch) {
+    const unsigned short* wa = a.wa1 + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) afn[kb][t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
+  };
   using PFX = TilePrefetch<NPX, NT, C, C>;
   PFX pfx;      // next tile's u_L rows, in flight during this tile
   if ((int)blockIdx.x < a.ntiles)
     pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
 
+  int tslot = 0;
+  FNO_TRACE_IF(true);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
+    FNO_STAMP(tslot + 0);
     // commit: a = act(u) -> fp32 staging tile + row-major bf16x3 image
 #pragma unroll
     for (int i = 0; i < PFX::ITER; ++i) {
@@ -456,7 +467,9 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
       const int co = idx / NPX, p = idx % NPX;
       douts[idx] = (co < a.CO) ? a.dy[((size_t)b * a.CO + co) * a.PW + px0 + p] : 0.f;
     }
+    FNO_STAMP(tslot + 1);
     __syncthreads();
+    FNO_STAMP(tslot + 2);
     {
       const int nt2 = tile + gridDim.x;
       if (nt2 < a.ntiles)
@@ -475,7 +488,9 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
       st8h(dst + SP::TERM, m);
       st8h(dst + 2 * SP::TERM, l);
     }
+    FNO_STAMP(tslot + 3);
     __syncthreads();            // tmpf (= dr) is free from here on
+    FNO_STAMP(tslot + 4);
     const unsigned short* xbp = xb + (n0 + l31) * SP::PBH + 8 * half;   // this lane's pixel row
     float dyl[NCO];
 #pragma unroll
@@ -486,26 +501,25 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+    if (tile == (int)blockIdx.x) load_w1(0);     // later tiles: chunk 0 was prefetched by the previous tile's last chunk
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
+      if (ch == 1) FNO_STAMP(tslot + 5);
       // ---- A1 ------------------------------------------------------------
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       {
-        const unsigned short* wa = a.wa1 + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          bf16x8 af[3], bf[3];
+          bf16x8 bf[3];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            af[t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
-            bf[t] = ld8h(xbp + t * SP::TERM + kb * 16);
-          }
-          acc = mfma_x3(af, bf, acc);
+          for (int t = 0; t < 3; ++t) bf[t] = ld8h(xbp + t * SP::TERM + kb * 16);
+          acc = mfma_x3(afn[kb], bf, acc);
         }
       }
+      if (ch == 1) FNO_STAMP(tslot + 6);
       // ---- E ---------------------------------------------------------------
       bf16x8 bd[2][3];      // dP1 split: accumulator registers 8s..8s+7 = B fragment of hidden k-block s
       {
@@ -547,6 +561,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
             for (int co = 0; co < NCO; ++co) sdw2[k][co] += rdw[co];
           }
       }
+      if (ch == 1) FNO_STAMP(tslot + 7);
       // ---- A3: W1^T fragments come in the accumulator's k order (k_pack_w1_x3) ------------
       {
         const unsigned short* wa = a.wa3 + ((size_t)((ch * 2 + hm) * 2 * MT * 3) * 64 + lane) * 8;
@@ -561,7 +576,11 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
           }
         }
       }
+      // W1 fragments of the NEXT chunk: L2 latency hides behind the barrier and the dW1 phase
+      load_w1(ch + 1 < NCH ? ch + 1 : 0);
+      if (ch == 1) FNO_STAMP(tslot + 8);
       __syncthreads();
+      if (ch == 1) FNO_STAMP(tslot + 9);
       // ---- B: dW1[hid][c] += sum_px dP1[hid][px] a[c][px], both operands row-major bf16x3 -----
       if (dgrp == ch % G) {
         const unsigned short* ga = dr + (dmt * 32 + l31) * RP + 8 * half;
@@ -583,9 +602,12 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
             dw1acc[k] = dacc;
           }
       }
+      if (ch == 1) FNO_STAMP(tslot + 10);
       __syncthreads();   // dr is rewritten by the next chunk
+      if (ch == 1) FNO_STAMP(tslot + 11);
     }
 
+    FNO_STAMP(tslot + 12);
     // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
     if (hm == 1) {
       float* pp = part + (4 * half) * PITCH + n0 + l31;
@@ -610,11 +632,15 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
           if (a.x1g) xp[ro * PITCH] = v;
         }
     }
+    FNO_STAMP(tslot + 13);
     if (a.x1g) {
       __syncthreads();
+      FNO_STAMP(tslot + 14);
       row_dft_epilogue<C, NPX, NW>(tmpf, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
+    FNO_STAMP(tslot + 15);
     __syncthreads();
+    tslot += 16;
   }
 
   // ---- partial slabs -------------------------------------------------------
