@@ -33,6 +33,9 @@ CONFIGS = {
 }
 
 
+PMC_TRAFFIC_JSON = "r01_v9_pmc_traffic.json"
+
+
 def kernel_model(cfg):
     """Algorithmic FLOPs and HBM bytes PER LAUNCH of each hot kernel."""
     B, C = cfg["batch"], cfg["width"]
@@ -156,12 +159,15 @@ def main():
                                 unit="GB/s", frac=round(f_h, 4), traffic=None)
             # HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_traffic.py)
             try:
-                pt = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                key = next(k for k in pt if k.startswith(dom["name"].replace("_block", "").replace("_lift", "") + "<")
-                           or k == dom["name"])
-                roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
-                roofline["algorithmic_bytes"] = round(km[dom["name"]]["bytes"])
+                pj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON)))
+                if pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
+                    pt = pj["kernels"]
+                    base = dom["name"].replace("_block", "").replace("_lift", "")
+                    key = next(k for k in pt if k.split("<")[0] in (base, base + "_x3"))
+                    roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
+                    roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                                  "separate passes, corrected; same command and workload)")
+                    roofline["algorithmic_bytes"] = round(km[dom["name"]]["bytes"])
             except Exception:
                 pass
             roofline["avg_launch_ms"] = dom["avg_ms"]

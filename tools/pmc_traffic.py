@@ -31,7 +31,7 @@ def main():
     kernels = {k: dict(fetch_bytes=2 * fe[k] * 1024, write_bytes=wr.get(k, 0.0) * 1024,
                        raw_FETCH_SIZE=fe[k], raw_WRITE_SIZE=wr.get(k, 0.0))
                for k in fe if k.startswith("k_")}
-    json.dump(dict(note="per-launch averages; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact; separate --pmc passes",
+    json.dump(dict(workload="fno2d_128x128_w64_m12_b64", note="per-launch averages; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact; separate --pmc passes",
                    kernels=kernels), open(out, "w"), indent=1)
 
 
