@@ -435,6 +435,50 @@ extern "C" size_t fno_spec_xhat_bytes(const FnoSpecPlan* p, int B) {
   return (size_t)B * p->g.Ktot * p->d.Cin * 2 * sizeof(float);
 }
 
+// Last-dim passes of the standalone path: MFMA tile kernels when the shape allows it
+// (32 / 64 channels, rows of 32 / 64 / 128 floats, whole 128-pixel tiles), generic kernels otherwise.
+static bool row_fast_ok(const Geom& g, int C) {
+  return (C == 32 || C == 64) && g.W % 32 == 0 && 128 % g.W == 0 && g.PW % 128 == 0 && g.NJ <= 4;
+}
+static int dev_ncu() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  return ncu;
+}
+static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, int B, int C, const float* x, float* x1) {
+  if (row_fast_ok(g, C)) {
+    RowDftArgs a;
+    a.x = x; a.x1 = x1; a.tfwd = tfwd; a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.tiles_per_plane = g.PW / 128; a.ntiles = B * a.tiles_per_plane;
+    const size_t lds = ((size_t)C * 132 + (size_t)16 * g.NJ * (g.W + 4)) * 4;
+    const int grid = std::min(a.ntiles, 3 * dev_ncu());
+    if (C == 32) return launch("k_rowdft_tile", k_rowdft_tile<32, 128>, dim3(grid), dim3(256), lds, st, a);
+    return launch("k_rowdft_tile", k_rowdft_tile<64, 128>, dim3(grid), dim3(256), lds, st, a);
+  }
+  return launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)C * (g.W + 1) * 4, st, x,
+                (float2*)x1, tfwd, C, g.P, g.W, g.Klast);
+}
+static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, int C, const float* z, const float* bias,
+                       float* y) {
+  const size_t lds = pw_fwd_lds_bytes(2, C, 128, g.W, g.Klast, g.NJ, true, false);
+  if (row_fast_ok(g, C) && lds <= 64 * 1024) {
+    PwFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.z = z; a.tinv = tinv; a.bias = bias; a.u = y;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = 0; a.NJ = g.NJ;
+    a.tiles_per_plane = g.PW / 128; a.ntiles = B * a.tiles_per_plane;
+    const int grid = std::min(a.ntiles, 2 * dev_ncu());
+    if (C == 32) return launch("k_rowidft_tile", k_pw_fwd<2, 32, 128>, dim3(grid), dim3(256), lds, st, a);
+    return launch("k_rowidft_tile", k_pw_fwd<2, 64, 128>, dim3(grid), dim3(512), lds, st, a);
+  }
+  return launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * C * 8, st,
+                (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
+}
+
 extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, const float* const* wc, const float* bias,
                                 float* y, float* xhat_save, void* ws, size_t ws_bytes, void* stream) {
   if (!p || !x || !wc || !y || B < 1) return fail(FNO_EINVAL, "fno_spec_forward: bad argument");
@@ -445,14 +489,12 @@ extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, con
   SpecWs w = carve_spec(p, B, ws, ws_bytes, &ok);
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   float* hat = xhat_save ? xhat_save : w.hat_in;
-  LAUNCHCHK(launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)Cin * (g.W + 1) * 4, st, x,
-                   (float2*)w.x1, (const float*)p->t.tfwd_f, Cin, g.P, g.W, g.Klast));
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, B, Cin, x, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, Cin, w.x1, w.tmp, hat));
   LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
   LAUNCHCHK(mode_gemm(st, hat, w.wp, w.hat_out, B, g.Ktot, Cin, Cout, 0));
   LAUNCHCHK(lead_inverse(st, g, p->t, B, Cout, w.hat_out, w.tmp, w.z));
-  LAUNCHCHK(launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * Cout * 8, st,
-                   (const float2*)w.z, y, (const float*)p->t.tinv_f, bias, Cout, g.P, g.W, g.Klast));
+  LAUNCHCHK(row_inverse(st, g, p->t.tinv_f, B, Cout, w.z, bias, y));
   return FNO_OK;
 }
 
@@ -472,8 +514,7 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
     LAUNCHCHK(reduce_slabs(st, w.dbpart, dbias, 64, 1, Cout, Cout, Cout));
   }
   if (!dx && !dwc) return FNO_OK;
-  LAUNCHCHK(launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)Cout * (g.W + 1) * 4, st, dy,
-                   (float2*)w.x1, (const float*)p->t.tfwd_b, Cout, g.P, g.W, g.Klast));
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, B, Cout, dy, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, true, B, Cout, w.x1, w.tmp, w.hat_out));   // G
   if (dwc) {
     LAUNCHCHK(mode_gemm_dw(st, xhat, w.hat_out, w.dwp, B, g.Ktot, Cin, Cout));
@@ -483,8 +524,7 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
     LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
     LAUNCHCHK(mode_gemm(st, w.hat_out, w.wpt, w.hat_in, B, g.Ktot, Cout, Cin, 1));   // GX
     LAUNCHCHK(lead_inverse(st, g, p->t, B, Cin, w.hat_in, w.tmp, w.z));
-    LAUNCHCHK(launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * Cin * 8, st,
-                     (const float2*)w.z, dx, (const float*)p->t.tinv_b, (const float*)nullptr, Cin, g.P, g.W, g.Klast));
+    LAUNCHCHK(row_inverse(st, g, p->t.tinv_b, B, Cin, w.z, nullptr, dx));
   }
   return FNO_OK;
 }

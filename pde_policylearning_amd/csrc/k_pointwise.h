@@ -108,6 +108,8 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
 
     if (has_conv) pf.commit(xs, a.act_in != 0, tid);
     if (tid < zcount4) st4(zs + 4 * tid, zpf);
+    for (int i = tid + NT; i < zcount4; i += NT)     // more Z rows than threads (short rows): straight from L2
+      st4(zs + 4 * i, ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * COUT * 2 + 4 * i));
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);   // overlaps everything below
 
@@ -155,6 +157,41 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_p
       row_dft_epilogue<COUT, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     }
     __syncthreads();  // xs is restaged by the next tile
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Last-dim forward pass of the STANDALONE spectral convolution (fno_spec_*: dialects B / C and the
+// unfused FNO): X1[b,row,k2,c] = sum_w x[b,c,row,w] * Tfwd[k2][w].  Same tile / prefetch / MFMA
+// row-DFT machinery as the fused kernels, no GEMM.  4 waves, ~50 KB LDS -> 3 workgroups per CU.
+struct RowDftArgs {
+  const float* x;      // (B, C, PW)
+  float* x1;           // (B, P, K2out, C, 2)
+  const float* tfwd;   // (16*NJ, W)
+  int PW, W, P, K2out, NJ;
+  int tiles_per_plane, ntiles;
+};
+template <int C, int NPX>
+__global__ void __launch_bounds__(256) k_rowdft_tile(RowDftArgs a) {
+  constexpr int NW = 4, NT = NW * 64, PITCH = NPX + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                      // C x PITCH
+  float* tfwd_s = xs + C * PITCH;        // 16*NJ x (W + 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  TilePrefetch<NPX, NT, C, C> pf;
+  auto issue = [&](int tile) {
+    pf.issue(a.x + (size_t)(tile / a.tiles_per_plane) * C * a.PW + (tile % a.tiles_per_plane) * NPX, a.PW, tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pf.commit(xs, false, tid);
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+    __syncthreads();
   }
 }
 

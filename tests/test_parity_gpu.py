@@ -406,3 +406,56 @@ def test_fno2d_observer_train_trajectory_fused_tail(dev):
     for step in range(3):
         loss = train_step(lambda a: model(a, None), bucket, opt, (pp,), tgt, loss_fn)
         assert abs(float(loss) - float(g["losses"][step])) < 5e-5 * abs(float(g["losses"][step])), step
+
+
+# ---------------------------------------------------------------------------------------------
+# standalone spectral convolution at the shapes that take the MFMA last-dim tile kernels
+# (k_rowdft_tile / k_rowidft_tile: 32 or 64 channels, rows of 32 / 64 / 128 floats) vs the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dialect,shape,modes", [
+    ("B", (2, 64, 128, 128), (12, 12)),        # RNO2d cell convolution as named in BASELINE config 3
+    ("B", (3, 32, 64, 64), (8, 6)),
+    ("C", (2, 32, 64, 32), (5, 7)),            # rows of 32 floats: 4 rows per tile
+    ("C", (1, 64, 16, 32, 64), (4, 6, 9)),     # 3-D, last dim 64
+    ("A", (2, 64, 64, 128), (6, 6)),           # unfused FNO block convolution with bias
+])
+def test_specconv_tile_rows_vs_oracle(dev, dialect, shape, modes):
+    from pde_policylearning_amd import functional as F
+    C, nd = shape[1], len(shape) - 2
+    ncorner = 2 ** (nd - 1)
+    x = torch.from_numpy(fill_named("x", shape, 1.0))
+    dy = torch.from_numpy(fill_named("dy", shape, 1.0))
+    wr = [torch.from_numpy(fill_named(f"w{i}", (C, C) + tuple(modes) + (2,), 0.02)) for i in range(ncorner)]
+    bias = torch.from_numpy(fill_named("bias", (C,) + (1,) * nd, 0.1)) if dialect == "A" else None
+    # oracle (CPU)
+    xo = x.clone().requires_grad_(True)
+    wo = [w.clone().requires_grad_(True) for w in wr]
+    bo = bias.clone().requires_grad_(True) if bias is not None else None
+    wc = [torch.view_as_complex(w) for w in wo]
+    if dialect == "B":
+        yo = O.spectral_conv_B(xo, wo[0], wo[1], *modes)
+        norm = "ortho"
+    elif dialect == "C":
+        yo = O.spectral_conv_C3d(xo, *wc, *modes) if nd == 3 else O.spectral_conv_C2d(xo, *wc, *modes)
+        norm = "backward"
+    else:
+        yo = O.spectral_conv_A(xo, wc, bo, list(modes), "forward")
+        norm = "forward"
+    yo.backward(dy)
+    # engine
+    xe = x.to(dev).requires_grad_(True)
+    we = [w.to(dev).requires_grad_(True) for w in wr]
+    be = bias.to(dev).requires_grad_(True) if bias is not None else None
+    live = list(modes)
+    if dialect == "C" and nd == 3:
+        live[2] = min(shape[-1] // 2 + 1, modes[2])
+    # engine corner order is (lo,lo), (lo,hi), (hi,lo), (hi,hi); basics.py:127-134 numbers them w1 (lo,lo), w2 (hi,lo), w3 (lo,hi)
+    order = [0, 2, 1, 3] if (dialect == "C" and nd == 3) else list(range(ncorner))
+    ye = F.spectral_conv(xe, [we[i] for i in order], be, live, norm, weight_last_extent=modes[-1])
+    assert rel_l2(_cpu(ye), yo.detach().numpy()) < TOL_COMP
+    ye.backward(dy.to(dev))
+    assert rel_l2(_cpu(xe.grad), xo.grad.numpy()) < TOL_COMP
+    for a, b in zip(we, wo):
+        assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_COMP
+    if bias is not None:
+        assert rel_l2(_cpu(be.grad), bo.grad.numpy()) < TOL_COMP
