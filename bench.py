@@ -30,6 +30,13 @@ CONFIGS = {
     "fno2d_128x128_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(128, 128)),
     "fno2d_64x64_w32_m8_b4": dict(kind="2d", modes=(8, 8), width=32, batch=4, size=(64, 64)),
     "fno3d_64_w32_m8_b16": dict(kind="3d", modes=(8, 8, 8), width=32, batch=16, size=(64, 64, 64)),
+    # observer models of BASELINE configs 3 / 5.  Secondary workloads: their spectral
+    # convolutions run in the engine (fno_spec_*), the channels-last pointwise glue is still torch ops; no
+    # roofline / cpu_baseline legs.
+    "rno2d_128x128_w64_m12_b32": dict(kind="rno2d", batch=32, size=(128, 128)),            # cfg 3 as named (256 / 8 GPUs)
+    "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32)),        # configs/matlab_rno.yaml values
+    "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32)),     # the YAML's active model
+    "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
 }
 
 
@@ -89,19 +96,45 @@ def main():
 
     cfg = CONFIGS[args.config]
     torch.manual_seed(0)                       # run_pde_observers.py:25
-    ctor = FNO2d if cfg["kind"] == "2d" else FNO3d
-    model = ctor(*cfg["modes"], cfg["width"], in_channels=3, out_channels=1).to(dev)
-    broadcast_parameters(model)
     B = cfg["batch"]
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
-    tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
-    bucket = FlatGradBucket(model.parameters(), direct_module=model)
+    fused_model = cfg["kind"] in ("2d", "3d")
+    if fused_model:
+        ctor = FNO2d if cfg["kind"] == "2d" else FNO3d
+        model = ctor(*cfg["modes"], cfg["width"], in_channels=3, out_channels=1).to(dev)
+        x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
+        tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
+        inputs = (x,)
+    elif cfg["kind"].startswith("rno2d"):
+        from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+        width = 64 if cfg["kind"] == "rno2d" else 34
+        model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82
+        x = torch.randn((B, 1) + cfg["size"] + (1,), generator=gen).to(dev)    # (B, T, X, Y, 1), model_timestep 1
+        tgt = torch.randn((B,) + cfg["size"] + (1,), generator=gen).to(dev)
+        inputs = (x,)
+    else:
+        from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
+        if cfg["kind"] == "pino_ff":     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
+            model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
+                                         layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+            x = torch.randn((B,) + cfg["size"] + (1, 1), generator=gen).to(dev)
+        else:                             # train_pino.py:154-160: x (B, X, Y, T, 4), T padded by round(T * 0.0625)
+            model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+                                  out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+            x = torch.randn((B,) + cfg["size"] + (4,), generator=gen).to(dev)
+        re = (torch.rand((B, 1), generator=gen) * 100 + 100).to(dev)
+        inputs = (x, re)
+        with torch.no_grad():
+            tgt = torch.randn(model(*inputs).shape, generator=gen).to(dev)
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
     opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
+    if not fused_model:
+        args.no_cpu_baseline = True
 
     def step():
-        return train_step(model, bucket, opt, (x,), tgt, loss_fn)
+        return train_step(model, bucket, opt, inputs, tgt, loss_fn)
 
     def sync():
         torch.cuda.synchronize()
@@ -137,7 +170,7 @@ def main():
         L.fno_profile_enable(0)
         prof = _lib.profile_summary()
         L.fno_profile_reset()
-        km = kernel_model(cfg)
+        km = kernel_model(cfg) if fused_model else {}
         tot = sum(ms for _, ms, _ in prof)
         for name, ms, n in sorted(prof, key=lambda r: -r[1]):
             avg = ms / n
@@ -217,7 +250,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "FNO2d fwd+bwd fields/sec" if cfg["kind"] == "2d" else "FNO3d fwd+bwd fields/sec",
+            "metric": {"2d": "FNO2d", "3d": "FNO3d", "rno2d": "RNO2d", "rno2d_shipped": "RNO2d", "pino_ff": "PINObserverFullField",
+                       "pino2d": "PINObserver2d"}[cfg["kind"]] + " fwd+bwd fields/sec",
             "value": round(fields_per_s, 2),
             "unit": "fields/s",
             "n_gpus": world,

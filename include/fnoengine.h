@@ -129,6 +129,16 @@ int fno_model_forward(const FnoModelPlan* plan, int batch, const FnoModelParams*
 int fno_model_backward(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
                        const float* dy, const void* saved, const FnoModelGrads* g, void* ws, size_t ws_bytes,
                        void* stream);
+/* Block stacks.  FnoModelDesc.Cin == 0 drops the lifting (x is the (B, C, ...) input of block 0) and
+ * Cout == 0 drops the projection (y = u_L, (B, C, ...); the last block must then carry no GELU).  This is
+ * the fused form of the reference's other "Fourier layers":
+ *   neuralop/models/rno.py:215-228  FourierLayer2d = SpectralConv2d(ortho) + Conv1d(k=1)   (n_layers = 1)
+ *   libs/models/pino_models/pinobserver.py:221-226  sp_convs[i](x) + ws[i](x), GELU except last
+ * with skip_w[l] = the Conv1d weight and spec_bias = the Conv1d biases (L, C).  For such stacks the
+ * input gradient dx (B, C, ...) is produced as well (NULL to skip). */
+int fno_model_backward_dx(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
+                          const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Training-step tail (run_pde_observers.py:185-193), SURVEY.md section 8(f) rank 2.

@@ -565,9 +565,13 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
   if (!d || !out) return fail(FNO_EINVAL, "null argument");
   if (d->n_layers < 1 || d->n_layers > FNO_MAX_LAYERS) return fail(FNO_EINVAL, "n_layers=%d", d->n_layers);
   if (d->C != 32 && d->C != 64) return fail(FNO_EUNSUPPORTED, "fused path supports hidden width 32 or 64 (got %d)", d->C);
-  if (d->Cin < 1 || d->Cin > 4) return fail(FNO_EUNSUPPORTED, "fused path supports 1..4 input channels (got %d)", d->Cin);
-  if (d->Cout < 1 || d->Cout > PROJ_MAXCO) return fail(FNO_EUNSUPPORTED, "fused path supports 1..%d output channels", PROJ_MAXCO);
-  if (d->hidden_proj != kHID) return fail(FNO_EUNSUPPORTED, "fused path supports projection_channels=256 (got %d)", d->hidden_proj);
+  // Cin == 0: no lifting (x is the (B, C, ...) input of block 0); Cout == 0: no projection (y = u_L)
+  if (d->Cin < 0 || d->Cin > 4) return fail(FNO_EUNSUPPORTED, "fused path supports 0..4 input channels (got %d)", d->Cin);
+  if (d->Cout < 0 || d->Cout > PROJ_MAXCO) return fail(FNO_EUNSUPPORTED, "fused path supports 0..%d output channels", PROJ_MAXCO);
+  if (d->Cout > 0 && d->hidden_proj != kHID)
+    return fail(FNO_EUNSUPPORTED, "fused path supports projection_channels=256 (got %d)", d->hidden_proj);
+  if (d->Cout == 0 && ((d->gelu_mask >> (d->n_layers - 1)) & 1u))
+    return fail(FNO_EUNSUPPORTED, "a block stack without projection must end without activation");
   FnoModelPlan* p = new FnoModelPlan();
   p->d = *d;
   int rc = make_geom(p->g, d->ndim, d->dims, d->modes, 0, d->norm);
@@ -804,24 +808,29 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
                      (float2*)wps, (float2*)wpts, mm, n));
   }
 
-  // lifting (tfno.py:19-20) + row DFT of its output
+  const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
   PwFwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
-  a.u = u; a.x1 = w.x1; a.tfwd = p->t.tfwd_f;
-  a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
-  a.act_in = 0; a.act_out = 0;
-  a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-  LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
+  if (has_lift) {
+    // lifting (tfno.py:19-20) + row DFT of its output
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
+    a.u = u; a.x1 = w.x1; a.tfwd = p->t.tfwd_f;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.act_in = 0; a.act_out = 0;
+    a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
+  } else {
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, B, C, x, w.x1));     // block stack: x is u_0
+  }
 
   for (int l = 0; l < L; ++l) {
     LAUNCHCHK(spectral_mid_fwd(p, st, B, w, wps + (size_t)l * s.n_wp, hats + (size_t)l * s.n_hat));
     memset(&a, 0, sizeof(a));
-    a.x = u + (size_t)l * s.n_act;
+    a.x = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act;
     a.w = prm->skip_w[l];
     a.bias = prm->spec_bias ? prm->spec_bias + (size_t)l * C : nullptr;
     a.z = w.z; a.tinv = p->t.tinv_f;
-    a.u = u + (size_t)(l + 1) * s.n_act;
+    a.u = (l == L - 1 && !has_proj) ? y : u + (size_t)(l + 1) * s.n_act;
     a.x1 = (l + 1 < L) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
@@ -831,6 +840,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
 
+  if (!has_proj) return FNO_OK;
   // projection (tfno.py:34-38)
   ProjFwdArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -846,7 +856,13 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
 extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
                                   const float* dy, const void* saved, const FnoModelGrads* gr, void* ws,
                                   size_t ws_bytes, void* stream) {
+  return fno_model_backward_dx(p, B, prm, x, dy, saved, gr, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                                     const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
+                                     size_t ws_bytes, void* stream) {
   if (!p || !prm || !x || !dy || !saved || !gr || B < 1) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
+  if (dx && p->d.Cin > 0) return fail(FNO_EUNSUPPORTED, "input gradient is produced for block stacks (Cin == 0) only");
   hipStream_t st = (hipStream_t)stream;
   const Geom& g = p->g;
   const FnoModelDesc& d = p->d;
@@ -860,9 +876,13 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   const float* wpts = hats + (size_t)L * s.n_hat + (size_t)L * s.n_wp;   // [k][o][i] packed weights from forward
   JobList jobs;
 
+  const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
+  if (!has_proj) {
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, B, C, dy, w.x1));     // dy is dL/du_L
+  } else {
   if (g_gemm_x3) {
     const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;
     LAUNCHCHK(launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.wa1,
@@ -882,9 +902,11 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
   jobs.add(w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID);
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
   jobs.add(w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout);
+  }
 
-  float* gcur = w.ga;   // dL/du_{l+1}
-  float* gnext = w.gb;
+  const float* gcur = has_proj ? w.ga : dy;   // dL/du_{l+1}
+  float* gnext = has_proj ? w.gb : w.ga;
+  float* gspare = has_proj ? w.ga : w.gb;
   const int ks = bbwd_ksplit(p);
   for (int l = L - 1; l >= 0; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
@@ -898,24 +920,25 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
 
     BlkBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.g = gcur; a.uin = u + (size_t)l * s.n_act; a.w = prm->skip_w[l];
+    a.g = gcur; a.uin = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act; a.w = prm->skip_w[l];
     a.zg = w.z; a.tinv = p->t.tinv_b;
-    a.gout = (l > 0) ? gnext : nullptr;
+    a.gout = (l > 0) ? gnext : (has_lift ? nullptr : dx);
     a.x1g = (l > 0) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_l; a.db_part = db_part_l;
-    a.xin = (l == 0) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
+    a.xin = (l == 0 && has_lift) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
     jobs.add(dw_part_l, gr->skip_w[l], s.grid * ks, C, C, C, C);
     if (gr->spec_bias) jobs.add(db_part_l, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C);
-    if (l == 0) {
+    if (l == 0 && has_lift) {
       jobs.add(w.dwl_part, gr->lift_w, s.grid, C, d.Cin, 16, d.Cin);
       jobs.add(w.dwl_part + d.Cin, gr->lift_b, s.grid, C, 1, 16, 1);
     }
-    float* t = gcur; gcur = gnext; gnext = t;
+    gcur = gnext;
+    { float* t = gnext; gnext = gspare; gspare = t; }
   }
   LAUNCHCHK(jobs.run(st));
   {

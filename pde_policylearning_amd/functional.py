@@ -308,3 +308,94 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
     _lib.check(_lib.lib().fno_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                         float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                         int(step), _stream()), "adam_step")
+
+
+# ----------------------------------------------------------------------------
+# fused block stack: y = B_{L-1}(...B_0(x)),  B_l(u) = [gelu](specconv_l(u) + conv1x1_l(u) + bias_l)
+# ----------------------------------------------------------------------------
+class _FNOBlocksFn(torch.autograd.Function):
+    """Tensor arguments: x, bias (L, C) or None, skip_w[0..L), spec_w[0..L*ncorner)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, bias, *rest):
+        n_layers, modes, norm, gelu_mask = cfg
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        dims = tuple(x.shape[2:])
+        ndim = len(dims)
+        ncorner = 2 ** (ndim - 1)
+        skip_ws = [t.contiguous() for t in rest[:n_layers]]
+        spec_ws = [t.contiguous() for t in rest[n_layers:]]
+        assert len(spec_ws) == n_layers * ncorner
+        for t in skip_ws + spec_ws + ([bias] if bias is not None else []):
+            _require_cuda(t, "parameter")
+        sb = bias.contiguous() if bias is not None else None
+        B, c = x.shape[0], x.shape[1]
+        L = _lib.lib()
+        plan = model_plan(ndim, 0, c, 0, 0, n_layers, dims, modes, norm, gelu_mask, x.device)
+        prm = _lib.FnoModelParams()
+        for l in range(n_layers):
+            prm.skip_w[l] = skip_ws[l].data_ptr()
+            for k in range(ncorner):
+                prm.spec_w[l][k] = spec_ws[l * ncorner + k].data_ptr()
+        prm.spec_bias = sb.data_ptr() if sb is not None else 0
+        y = torch.empty_like(x)
+        saved = _bytes(L.fno_model_saved_bytes(plan, B), x.device)
+        nws = L.fno_model_workspace_bytes(plan, B)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_model_forward(plan, B, C.byref(prm), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), nws,
+                                           _stream()), "blocks_forward")
+        ctx.plan, ctx.B, ctx.n_layers, ctx.ncorner, ctx.has_sb = plan, B, n_layers, ncorner, sb is not None
+        ctx.save_for_backward(x, saved, *skip_ws, *spec_ws, *([sb] if sb is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sv = ctx.saved_tensors
+        x, saved = sv[:2]
+        nl, nc = ctx.n_layers, ctx.ncorner
+        skip_ws = list(sv[2:2 + nl])
+        spec_ws = list(sv[2 + nl:2 + nl + nl * nc])
+        sb = sv[2 + nl + nl * nc] if ctx.has_sb else None
+        dy = dy.contiguous()
+        L = _lib.lib()
+        prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
+        g_skip = [torch.empty_like(t) for t in skip_ws]
+        g_spec = [torch.empty_like(t) for t in spec_ws]
+        g_sb = torch.empty_like(sb) if sb is not None else None
+        for l in range(nl):
+            prm.skip_w[l], grd.skip_w[l] = skip_ws[l].data_ptr(), g_skip[l].data_ptr()
+            for k in range(nc):
+                prm.spec_w[l][k], grd.spec_w[l][k] = spec_ws[l * nc + k].data_ptr(), g_spec[l * nc + k].data_ptr()
+        prm.spec_bias = sb.data_ptr() if sb is not None else 0
+        grd.spec_bias = g_sb.data_ptr() if g_sb is not None else 0
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
+        ws = _bytes(nws, dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                               C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "blocks_backward")
+        return (None, dx, g_sb) + tuple(g_skip) + tuple(g_spec)
+
+
+def blocks_supported(x, n_layers=1):
+    """Shapes the fused block kernels cover (fno_model_plan_create): 32 / 64 channels, last dim a
+    multiple of 32 (<= 256), planes that tile by 128 (256) pixels."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() in (4, 5)):
+        return False
+    c, w = x.shape[1], x.shape[-1]
+    pw = 1
+    for s in x.shape[2:]:
+        pw *= s
+    npx = 256 if w > 128 else 128
+    return c in (32, 64) and w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0 and n_layers <= _lib.FNO_MAX_LAYERS
+
+
+def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0):
+    """Stack of fused Fourier layers (include/fnoengine.h, block stacks): per layer one spectral
+    convolution (corner weights `spec_ws`, layer-major, real view (C, C, m.., 2)), one 1x1 convolution
+    (`skip_ws[l]`, (C, C) or (C, C, 1..)) and one bias row of `bias` (L, C); GELU after layer l iff bit l
+    of `gelu_mask`.  Returns (B, C, ...); differentiable w.r.t. x and every parameter."""
+    cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask))
+    return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *spec_ws)

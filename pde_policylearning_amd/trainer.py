@@ -81,17 +81,31 @@ class FlatGradBucket(object):
         self.direct_module = direct_module
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
-        n = sum(p.numel() for p in self.params)
+        n = sum(self._nfloat(p) for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, v in zip(self.params, self.views(self.flat)):
+            p.grad = v
         if direct_module is not None:
             for m in direct_module.modules():
                 if hasattr(m, "fused_supported"):
                     m._direct_grads = True
+
+    @staticmethod
+    def _nfloat(p):
+        """fp32 slots of a parameter: complex64 parameters (libs/models/pino_models/basics.py:74-77) take two."""
+        return p.numel() * (2 if p.is_complex() else 1)
+
+    def views(self, flat):
+        """Per-parameter views of a flat fp32 buffer laid out like the bucket (complex parameters as
+        complex views of interleaved pairs, which is also how torch.optim.Adam treats them)."""
+        out, off = [], 0
+        for p in self.params:
+            k = self._nfloat(p)
+            seg = flat[off:off + k]
+            out.append(torch.view_as_complex(seg.view(*p.shape, 2)) if p.is_complex() else seg.view_as(p))
+            off += k
+        return out
 
     def zero(self):
         if self.direct_module is None:
@@ -99,15 +113,12 @@ class FlatGradBucket(object):
 
     def check_views(self):
         """autograd accumulates in place into an existing .grad; re-attach if something replaced it."""
-        off = 0
-        for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
+        for p, v in zip(self.params, self.views(self.flat)):
             if p.grad is None:
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-            off += p.numel()
 
     def all_reduce(self):
         """SUM over ranks, no division (sum-reduced loss)."""
@@ -125,13 +136,10 @@ class FusedAdam(object):
         self.bucket = bucket
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.flat_param = torch.empty_like(bucket.flat)
-        off = 0
         with torch.no_grad():
-            for p in bucket.params:
-                v = self.flat_param[off:off + p.numel()].view_as(p)
+            for p, v in zip(bucket.params, bucket.views(self.flat_param)):
                 v.copy_(p.data)
                 p.data = v
-                off += p.numel()
         self.exp_avg = torch.zeros_like(bucket.flat)
         self.exp_avg_sq = torch.zeros_like(bucket.flat)
         self.step_count = 0
