@@ -119,6 +119,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
     pfg.commit(gs, false, tid);
     pfu.commit(us, false, tid);
     if (tid < zcount4) st4(zs + 4 * tid, zv);
+    for (int i = tid + NT; i < zcount4; i += NT)      // more spectral rows than threads (short rows, many modes)
+      st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
     if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
     FNO_STAMP(tslot + 1);
     __syncthreads();
@@ -366,6 +368,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       put_row4(ar, c, q, uv);
     }
     if (tid < zcount4) st4(zs + 4 * tid, zv);
+    for (int i = tid + NT; i < zcount4; i += NT)      // more spectral rows than threads (short rows, many modes)
+      st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
     if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
     FNO_STAMP(tslot + 1);
     __syncthreads();

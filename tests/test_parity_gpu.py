@@ -178,7 +178,8 @@ def _fno_params(C, L, half_modes, cin=3, cout=1, seed_tag="p"):
 
 
 @pytest.mark.parametrize("C,S,modes,B,L", [(32, 32, (8, 8), 3, 4), (64, 64, (12, 10), 2, 2),
-                                           (32, 128, (16, 16), 1, 3), (64, 256, (12, 12), 1, 1)])
+                                           (32, 128, (16, 16), 1, 3), (64, 256, (12, 12), 1, 1),
+                                           (64, 32, (16, 16), 2, 2)])     # 4 rows per tile x 8 modes: more Z rows than threads
 def test_fno2d_vs_oracle(dev, C, S, modes, B, L):
     half = [m // 2 for m in modes]
     p = _fno_params(C, L, half)
