@@ -546,26 +546,62 @@ __global__ void __launch_bounds__(1024) k_reduce_slabs(const float* __restrict__
 struct ReduceJob { const float* part; float* out; int nslab, n, ld_out, ncols, ld_in; };
 struct ReduceJobs { ReduceJob j[24]; int count; };
 __global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
-  __shared__ float sh[16][65];
+  // block (16, 64): 16 column groups x 64 slab lanes.  Many small workgroups (a 64x64 weight gradient
+  // alone gives 64 of them) keep every CU loading; each thread has <= 8 independent 16-B loads in flight.
+  __shared__ float4 sh[64][17];
   const ReduceJob jb = jobs.j[blockIdx.y];
-  const int sy = threadIdx.y;
-  for (int e0 = blockIdx.x * 64; e0 < jb.n; e0 += gridDim.x * 64) {
-    const int e = e0 + threadIdx.x;
+  const int tx = threadIdx.x, sy = threadIdx.y;
+  const size_t slab = (size_t)(jb.n / jb.ncols) * jb.ld_in;
+  if (jb.ncols % 4 == 0 && jb.ld_in % 4 == 0) {
+    const int ng = jb.n / 4;
+    for (int g0 = blockIdx.x * 16; g0 < ng; g0 += gridDim.x * 16) {
+      const int g = g0 + tx;
+      const int row = (4 * g) / jb.ncols, col = (4 * g) % jb.ncols;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < ng) {
+        const float* p = jb.part + (size_t)row * jb.ld_in + col;
+#pragma unroll 4
+        for (int k = sy; k < jb.nslab; k += 64) {
+          const float4 v = ld4(p + k * slab);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+      }
+      sh[sy][tx] = s;
+      __syncthreads();
+      for (int off = 32; off > 0; off >>= 1) {       // fixed-order tree over the 64 slab lanes
+        if (sy < off) {
+          const float4 v = sh[sy + off][tx];
+          float4 t = sh[sy][tx];
+          t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+          sh[sy][tx] = t;
+        }
+        __syncthreads();
+      }
+      if (sy == 0 && g < ng) {
+        const float4 t = sh[0][tx];
+        float* o = jb.out + (size_t)row * jb.ld_out + col;     // destination rows may be unaligned (flat bucket offsets)
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // scalar columns (bias-type jobs): 16 elements x 64 slab lanes
+  for (int e0 = blockIdx.x * 16; e0 < jb.n; e0 += gridDim.x * 16) {
+    const int e = e0 + tx;
     float s = 0.f;
     if (e < jb.n) {
       const int row = e / jb.ncols, col = e % jb.ncols;
-      const size_t slab = (size_t)(jb.n / jb.ncols) * jb.ld_in;
       const float* p = jb.part + (size_t)row * jb.ld_in + col;
-      for (int k = sy; k < jb.nslab; k += 16) s += p[k * slab];
+      for (int k = sy; k < jb.nslab; k += 64) s += p[k * slab];
     }
-    sh[sy][threadIdx.x] = s;
+    sh[sy][tx].x = s;
     __syncthreads();
-    if (sy == 0 && e < jb.n) {
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
-      jb.out[(size_t)(e / jb.ncols) * jb.ld_out + e % jb.ncols] = t;
+    for (int off = 32; off > 0; off >>= 1) {
+      if (sy < off) sh[sy][tx].x += sh[sy + off][tx].x;
+      __syncthreads();
     }
+    if (sy == 0 && e < jb.n) jb.out[(size_t)(e / jb.ncols) * jb.ld_out + e % jb.ncols] = sh[0][tx].x;
     __syncthreads();
   }
 }
