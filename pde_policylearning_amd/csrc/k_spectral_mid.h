@@ -433,13 +433,24 @@ __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restric
 // dbias[c] partials: sum over (b, pixels) of dy (B, C, PW) -> part[blk][c]
 __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ dy, float* __restrict__ part, int B,
                                                       int C, int PW) {
-  // grid = (nchunk, C); block sums its chunk of (b, px) for channel c
+  // grid = (nchunk, C); block sums its chunk of (b, px) for channel c; 16-B loads when rows allow it
   const int c = blockIdx.y;
-  const size_t n = (size_t)B * PW;
   float s = 0.f;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = e / PW, p = e % PW;
-    s += dy[(b * C + c) * PW + p];
+  if (PW % 4 == 0) {
+    const size_t n4 = (size_t)B * (PW / 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+      const size_t b = e / (PW / 4), p = e % (PW / 4);
+      const float4 v = ld4(dy + (b * C + c) * PW + 4 * p);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    s = (acc.x + acc.y) + (acc.z + acc.w);
+  } else {
+    const size_t n = (size_t)B * PW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+      const size_t b = e / PW, p = e % PW;
+      s += dy[(b * C + c) * PW + p];
+    }
   }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   __shared__ float sh[4];
