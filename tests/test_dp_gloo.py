@@ -121,3 +121,33 @@ def test_flat_bucket_views_and_single_message():
     assert float(b.flat.abs().sum()) > 0
     b.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+
+
+def test_flat_bucket_complex_parameters():
+    """cfloat parameters (libs/models/pino_models/basics.py:74-77) take two fp32 slots of the bucket and their
+    .grad is a complex view of that storage, so one real all-reduce / Adam pass covers them."""
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    w = nn.Parameter(torch.randn(3, 2, dtype=torch.cfloat))
+    v = nn.Parameter(torch.randn(5))
+    b = FlatGradBucket([w, v])
+    assert b.flat.numel() == 2 * 6 + 5
+    x = torch.randn(2, dtype=torch.cfloat)
+    loss = (w @ x).abs().sum() + (v * v).sum()
+    loss.backward()
+    b.check_views()
+    assert w.grad.is_complex() and w.grad.data_ptr() == b.flat.data_ptr()
+    ref = torch.autograd.grad((w @ x).abs().sum(), w)[0]
+    assert torch.allclose(torch.view_as_real(w.grad), torch.view_as_real(ref))
+    assert torch.allclose(b.flat[:12], torch.view_as_real(ref).reshape(-1))
+    assert torch.allclose(b.flat[12:], 2 * v.detach())
+
+
+def test_fused_tail_fails_loudly_without_gpu():
+    """The engine's loss / Adam have no CPU path either."""
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss
+    with pytest.raises(RuntimeError, match="GPU"):
+        FusedLpLoss(size_average=False)(torch.zeros(2, 4, 4), torch.ones(2, 4, 4))
+    p = nn.Parameter(torch.zeros(8))
+    opt = FusedAdam(FlatGradBucket([p]))
+    with pytest.raises(RuntimeError, match="GPU"):
+        opt.step()
