@@ -360,6 +360,27 @@ def gen_pino(outdir):
          shapes={k: np.array(v.shape) for k, v in m.state_dict().items()})
 
 
+def gen_pino_loss(outdir):
+    """PINO residual loss straight from the reference file (libs/pino_utils/losses.py; the copy in
+    libs/envs/diff_control_env.py is line-for-line the same but sits in a package whose __init__ needs MATLAB)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_pino_losses", os.path.join(sys.path[0], "libs", "pino_utils", "losses.py"))
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    for tag, (B, n, nt) in {"n32": (2, 32, 6), "n64": (2, 64, 5), "n128": (1, 128, 4)}.items():
+        u = input_fill("pinoloss.u." + tag, (B, n, n, nt)).requires_grad_(True)
+        u0 = input_fill("pinoloss.u0." + tag, (B, n, n))
+        re = torch.from_numpy(np.array([180.0, 395.0][:B], dtype=np.float32))
+        v = 1.0 / re
+        f = L.get_forcing(n)
+        t_interval = 0.5
+        du = L.FDM_NS_vorticity(u, v, t_interval)
+        loss_ic, loss_f = L.PINO_loss3d(u, u0, f, v, t_interval)          # == Channelflow_PINO_loss
+        (5.0 * loss_ic + 1.0 * loss_f).backward()                        # configs/pino-observer-finetune-1s.yaml weights
+        save(os.path.join(outdir, f"pino_loss_{tag}.npz"), meta=np.array([B, n, nt]), re=re, t_interval=np.float32(t_interval),
+             forcing=f, loss_ic=loss_ic.detach(), loss_f=loss_f.detach(), du_residual=du.detach(), grad_u=u.grad)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -370,7 +391,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import fno_oracle as O
+from oracle.detfill import fill_named
 from tests.util import load_golden, rebuild_params, rel_l2
 
 TOL = 2e-6     # fp32 oracle vs fp32 reference: same torch ops, reduction order may differ
@@ -206,3 +207,25 @@ def test_pinobserver2d():
     y = OO.pinobserver2d_forward(p, _t(g["x"]), _t(g["re"]), [8] * 5, [(3, 3, 3)] * 4, [0.0, 0.0625])
     assert rel_l2(y.detach(), g["y"]) < 1e-5
     _check_model_grads(g, p, O.lp_loss_rel_sum(y, _t(g["target"])))
+
+
+@pytest.mark.parametrize("tag", ["n32", "n64", "n128"])
+def test_pino_residual_loss_golden(tag):
+    """oracle/pino_loss_oracle.py vs vectors produced by the reference's own FDM_NS_vorticity / PINO_loss3d
+    (libs/pino_utils/losses.py:68-104, 246-262 == libs/envs/diff_control_env.py:5-60)."""
+    from oracle import pino_loss_oracle as P
+    g = load_golden("pino_loss_" + tag)
+    B, n, nt = [int(v) for v in g["meta"]]
+    u = torch.from_numpy(fill_named("input:pinoloss.u." + tag, (B, n, n, nt), 1.0)).requires_grad_(True)
+    u0 = torch.from_numpy(fill_named("input:pinoloss.u0." + tag, (B, n, n), 1.0))
+    visc = 1.0 / torch.from_numpy(g["re"])
+    f = P.forcing(n)
+    assert rel_l2(f.numpy(), g["forcing"]) < 1e-6
+    t_int = float(g["t_interval"])
+    du = P.ns_vorticity_residual(u, visc, t_int)
+    assert rel_l2(du.detach().numpy(), g["du_residual"]) < 1e-6
+    lic, lf = P.pino_loss(u, u0, f, visc, t_int)
+    assert abs(float(lic) - float(g["loss_ic"])) < 1e-6 * abs(float(g["loss_ic"]))
+    assert abs(float(lf) - float(g["loss_f"])) < 1e-6 * abs(float(g["loss_f"]))
+    (5.0 * lic + lf).backward()
+    assert rel_l2(u.grad.numpy(), g["grad_u"]) < 1e-5
