@@ -162,6 +162,25 @@ int fno_lploss_rel_backward(int batch, size_t n_per_sample, const float* pred, c
 int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ------------------------------------------------------------------------
+ * PINO residual loss, SURVEY.md section 8(f) rank 1: FDM_NS_vorticity + Channelflow_PINO_loss
+ * (libs/envs/diff_control_env.py:5-60 == libs/pino_utils/losses.py:68-104, 246-262; train_pino.py:98-101).
+ *   u (B, n, n, nt) model output, u0 (B, n, n) initial vorticity, forcing (n, n), visc (B) = 1 / Re,
+ *   Du = w_t + u . grad(w) - visc lap(w) with spectral derivatives over (x, y) and a central difference in t
+ *   on the interior time levels; loss_f = mean_b ||Du_b - forcing|| / ||forcing||, loss_ic = mean_b
+ *   ||u_b(t = 0) - u0_b|| / ||u0_b||  (LpLoss(size_average=True).rel).
+ * forward leaves the derived fields and per-sample coefficients in `ws` (fno_pino_loss_workspace_bytes);
+ * backward writes du = g_ic * dloss_ic/du + g_f * dloss_f/du (device scalars, NULL = 1).
+ * n must be 32, 64 or 128 (one plane per workgroup, in-LDS radix-2 FFTs).
+ * ---------------------------------------------------------------------- */
+size_t fno_pino_loss_workspace_bytes(int batch, int n, int nt);
+int fno_pino_loss_forward(int batch, int n, int nt, const float* u, const float* u0, const float* forcing,
+                          const float* visc, float t_interval, float* loss_ic, float* loss_f, void* ws, size_t ws_bytes,
+                          void* stream);
+int fno_pino_loss_backward(int batch, int n, int nt, const float* u, const float* u0, const float* forcing,
+                           const float* visc, float t_interval, const float* g_ic, const float* g_f, float* du, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

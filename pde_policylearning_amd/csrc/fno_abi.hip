@@ -17,6 +17,7 @@
 #include "k_pointwise.h"
 #include "k_projection.h"
 #include "k_spectral_mid.h"
+#include "k_pino_loss.h"
 #include "k_train.h"
 
 // --------------------------------------------------------------------------
@@ -1008,5 +1009,84 @@ extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* e
   int ncu = 256;
   const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)ncu * 8);
   LAUNCHCHK(launch("k_adam", k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
+  return FNO_OK;
+}
+
+// ===========================================================================
+// PINO residual loss (spectral Navier-Stokes vorticity residual + initial-condition term)
+// ===========================================================================
+static const int kIcSplit = 16;
+struct PinoWs { float *fields, *dws, *part_f, *part_ic, *coef_f, *coef_ic; size_t total; bool ok; };
+static PinoWs carve_pino(int B, int n, int T, void* ws, size_t ws_bytes) {
+  Carver c(ws, ws_bytes);
+  const size_t np = (size_t)B * (T - 2) * n * n;
+  PinoWs w;
+  w.fields = c.take<float>(5 * np);
+  w.dws = c.take<float>(np);
+  w.part_f = c.take<float>((size_t)B * (T - 2));
+  w.part_ic = c.take<float>((size_t)B * kIcSplit * 2);
+  w.coef_f = c.take<float>(B);
+  w.coef_ic = c.take<float>(B);
+  w.total = c.off;
+  w.ok = c.ok;
+  return w;
+}
+static int pino_check(int B, int n, int T) {
+  if (B < 1 || T < 3) return fail(FNO_EINVAL, "pino loss: batch %d, %d time levels (need >= 3)", B, T);
+  if (n != 32 && n != 64 && n != 128)
+    return fail(FNO_EUNSUPPORTED, "pino loss: square grids of 32, 64 or 128 points per side (got %d)", n);
+  return FNO_OK;
+}
+extern "C" size_t fno_pino_loss_workspace_bytes(int batch, int n, int nt) {
+  if (batch < 1 || n < 1 || nt < 3) return 0;
+  return carve_pino(batch, n, nt, nullptr, 0).total;
+}
+template <int N>
+static int pino_launch_planes(bool backward, int planes, hipStream_t st, const PinoArgs& a) {
+  const size_t lds = ((size_t)N * (N + 1) + N / 2) * 8 + 64;
+  if (backward) return launch("k_pino_plane_bwd", k_pino_plane_bwd<N>, dim3(planes), dim3(PinoCfg<N>::NT), lds, st, a);
+  return launch("k_pino_plane_fwd", k_pino_plane_fwd<N>, dim3(planes), dim3(PinoCfg<N>::NT), lds, st, a);
+}
+static int pino_planes(bool backward, int n, int planes, hipStream_t st, const PinoArgs& a) {
+  if (n == 32) return pino_launch_planes<32>(backward, planes, st, a);
+  if (n == 64) return pino_launch_planes<64>(backward, planes, st, a);
+  return pino_launch_planes<128>(backward, planes, st, a);
+}
+extern "C" int fno_pino_loss_forward(int B, int n, int T, const float* u, const float* u0, const float* forcing,
+                                     const float* visc, float t_interval, float* loss_ic, float* loss_f, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  LAUNCHCHK(pino_check(B, n, T));
+  if (!u || !u0 || !forcing || !visc || !loss_ic || !loss_f || !ws) return fail(FNO_EINVAL, "fno_pino_loss_forward: null argument");
+  PinoWs w = carve_pino(B, n, T, ws, ws_bytes);
+  if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  PinoArgs a;
+  memset(&a, 0, sizeof(a));
+  a.u = u; a.forcing = forcing; a.visc = visc; a.fields = w.fields; a.partial = w.part_f;
+  a.B = B; a.T = T; a.inv2dt = (float)((double)(T - 1) / (2.0 * (double)t_interval));
+  LAUNCHCHK(pino_planes(false, n, B * (T - 2), st, a));
+  LAUNCHCHK(launch("k_pino_ic_partial", k_pino_ic_partial, dim3(kIcSplit, B), dim3(256), 0, st, u, u0, n * n, T, w.part_ic));
+  LAUNCHCHK(launch("k_pino_finish", k_pino_finish, dim3(1), dim3(256), 0, st, (const float*)w.part_f, (const float*)w.part_ic,
+                   forcing, B, T, n * n, kIcSplit, loss_ic, loss_f, w.coef_ic, w.coef_f));
+  return FNO_OK;
+}
+extern "C" int fno_pino_loss_backward(int B, int n, int T, const float* u, const float* u0, const float* forcing,
+                                      const float* visc, float t_interval, const float* g_ic, const float* g_f, float* du,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  LAUNCHCHK(pino_check(B, n, T));
+  if (!u || !u0 || !visc || !du || !ws) return fail(FNO_EINVAL, "fno_pino_loss_backward: null argument");
+  PinoWs w = carve_pino(B, n, T, ws, ws_bytes);
+  if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t np = (size_t)B * (T - 2) * n * n;
+  PinoArgs a;
+  memset(&a, 0, sizeof(a));
+  a.u = u; a.forcing = forcing; a.visc = visc; a.fields = w.fields; a.dws = w.dws; a.coef_f = w.coef_f; a.g_f = g_f;
+  a.B = B; a.T = T; a.inv2dt = (float)((double)(T - 1) / (2.0 * (double)t_interval));
+  LAUNCHCHK(pino_planes(true, n, B * (T - 2), st, a));
+  const size_t npix = (size_t)B * n * n;
+  LAUNCHCHK(launch("k_pino_assemble", k_pino_assemble, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, u, u0,
+                   (const float*)w.dws, (const float*)(w.fields + 4 * np), (const float*)w.coef_f, (const float*)w.coef_ic,
+                   g_f, g_ic, B, n * n, T, a.inv2dt, du));
   return FNO_OK;
 }

@@ -399,3 +399,51 @@ def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0):
     of `gelu_mask`.  Returns (B, C, ...); differentiable w.r.t. x and every parameter."""
     cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask))
     return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *spec_ws)
+
+
+# ----------------------------------------------------------------------------
+# PINO residual loss (spectral Navier-Stokes vorticity residual + initial condition)
+# ----------------------------------------------------------------------------
+class _PinoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, u0, forcing, visc, t_interval):
+        for t, name in ((u, "u"), (u0, "u0"), (forcing, "forcing"), (visc, "visc")):
+            _require_cuda(t, name)
+        B, n, n2, nt = u.shape
+        if n != n2:
+            raise RuntimeError(f"fnoengine pino_loss: square grids only (got {n} x {n2})")
+        u_c, u0_c = u.contiguous(), u0.reshape(B, n, n).contiguous()
+        f_c = forcing.reshape(n, n).contiguous()
+        v_c = visc.reshape(B).contiguous()
+        L = _lib.lib()
+        nws = L.fno_pino_loss_workspace_bytes(B, n, nt)
+        ws = _bytes(nws, u.device)
+        losses = torch.empty(2, dtype=torch.float32, device=u.device)
+        with torch.cuda.device(u.device):
+            _lib.check(L.fno_pino_loss_forward(B, n, nt, _ptr(u_c), _ptr(u0_c), _ptr(f_c), _ptr(v_c), float(t_interval),
+                                               _ptr(losses[0:1]), _ptr(losses[1:2]), _ptr(ws), nws, _stream()),
+                       "pino_loss_forward")
+        ctx.save_for_backward(u_c, u0_c, f_c, v_c, ws)
+        ctx.meta = (B, n, nt, float(t_interval), nws, u.shape)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_ic, g_f):
+        u_c, u0_c, f_c, v_c, ws = ctx.saved_tensors
+        B, n, nt, t_interval, nws, shape = ctx.meta
+        L = _lib.lib()
+        du = torch.empty_like(u_c)
+        gi = g_ic.contiguous().to(torch.float32).reshape(1)
+        gf = g_f.contiguous().to(torch.float32).reshape(1)
+        with torch.cuda.device(du.device):
+            _lib.check(L.fno_pino_loss_backward(B, n, nt, _ptr(u_c), _ptr(u0_c), _ptr(f_c), _ptr(v_c), t_interval,
+                                                _ptr(gi), _ptr(gf), _ptr(du), _ptr(ws), nws, _stream()),
+                       "pino_loss_backward")
+        return du.view(shape), None, None, None, None
+
+
+def pino_loss(u, u0, forcing, visc, t_interval=1.0):
+    """(loss_ic, loss_f) of Channelflow_PINO_loss / PINO_loss3d (libs/envs/diff_control_env.py:44-60):
+    u (B, n, n, nt) model output, u0 (B, n, n), forcing (n, n) or (1, n, n, 1), visc (B,) = 1 / Re.
+    Differentiable w.r.t. u.  n in {32, 64, 128}."""
+    return _PinoLossFn.apply(u, u0, forcing, visc, t_interval)

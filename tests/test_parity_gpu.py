@@ -524,3 +524,54 @@ def test_rno2d_named_config_uses_fused_layers_and_matches_unfused(dev):
         # two fp32 evaluations of the same gradient through a GRU cell and a spectral regressor (neither is exact;
         # the oracle comparisons above carry the parity claim): 5e-4 guards against wiring mistakes
         assert rel_l2(_cpu(a), _cpu(p.grad)) < 5e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# PINO residual loss vs vectors generated by the reference's own code
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["n32", "n64", "n128"])
+def test_pino_residual_loss_golden(dev, tag):
+    from pde_policylearning_amd import functional as F
+    g = load_golden("pino_loss_" + tag)
+    B, n, nt = [int(v) for v in g["meta"]]
+    u = torch.from_numpy(fill_named("input:pinoloss.u." + tag, (B, n, n, nt), 1.0)).to(dev).requires_grad_(True)
+    u0 = torch.from_numpy(fill_named("input:pinoloss.u0." + tag, (B, n, n), 1.0)).to(dev)
+    visc = (1.0 / torch.from_numpy(g["re"])).to(dev)
+    f = torch.from_numpy(g["forcing"]).to(dev)
+    lic, lf = F.pino_loss(u, u0, f, visc, float(g["t_interval"]))
+    assert abs(float(lic) - float(g["loss_ic"])) < 1e-5 * abs(float(g["loss_ic"]))
+    assert abs(float(lf) - float(g["loss_f"])) < 1e-5 * abs(float(g["loss_f"]))
+    (5.0 * lic + lf).backward()                      # configs/pino-observer-finetune-1s.yaml: ic_loss 5, f_loss 1
+    assert rel_l2(_cpu(u.grad), g["grad_u"]) < 1e-5
+
+
+def test_pino_residual_fields_vs_oracle(dev):
+    """Residual Du itself (stored by the forward pass) against the oracle, at a batch where samples differ in viscosity."""
+    from oracle import pino_loss_oracle as P
+    from pde_policylearning_amd import functional as F
+    B, n, nt = 3, 64, 7
+    u = torch.from_numpy(fill_named("pl.u", (B, n, n, nt), 1.0))
+    u0 = torch.from_numpy(fill_named("pl.u0", (B, n, n), 1.0))
+    visc = torch.tensor([1 / 100.0, 1 / 250.0, 1 / 40.0])
+    f = P.forcing(n)
+    uo = u.clone().requires_grad_(True)
+    lic, lf = P.pino_loss(uo, u0, f, visc, 1.0)
+    (lic + 2.0 * lf).backward()
+    ue = u.to(dev).requires_grad_(True)
+    eic, ef = F.pino_loss(ue, u0.to(dev), f.to(dev), visc.to(dev), 1.0)
+    assert abs(float(eic) - float(lic)) < 1e-5 * float(lic) and abs(float(ef) - float(lf)) < 1e-5 * float(lf)
+    (eic + 2.0 * ef).backward()
+    assert rel_l2(_cpu(ue.grad), uo.grad.numpy()) < 1e-5
+
+
+def test_pino_loss_reference_surface(dev):
+    """train_pino.py:98-101 call shape: Channelflow_PINO_loss(out, u0, forcing, v, t_duration) with out (B, S, S, T, 1)."""
+    from pde_policylearning_amd.libs.envs.diff_control_env import Channelflow_PINO_loss, get_forcing
+    g = load_golden("pino_loss_n32")
+    B, n, nt = [int(v) for v in g["meta"]]
+    assert rel_l2(get_forcing(n).numpy(), g["forcing"]) < 1e-6
+    out = torch.from_numpy(fill_named("input:pinoloss.u.n32", (B, n, n, nt), 1.0)).to(dev).unsqueeze(-1)
+    u0 = torch.from_numpy(fill_named("input:pinoloss.u0.n32", (B, n, n), 1.0)).to(dev)
+    lic, lf = Channelflow_PINO_loss(out, u0, get_forcing(n).to(dev), (1.0 / torch.from_numpy(g["re"])).to(dev), float(g["t_interval"]))
+    assert abs(float(lic) - float(g["loss_ic"])) < 1e-5 * abs(float(g["loss_ic"]))
+    assert abs(float(lf) - float(g["loss_f"])) < 1e-5 * abs(float(g["loss_f"]))
