@@ -40,7 +40,7 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r01_v9_pmc_traffic.json"
+PMC_TRAFFIC_JSON = "r01_v12_pmc_traffic.json"
 
 
 def kernel_model(cfg):
@@ -195,7 +195,7 @@ def main():
                 pj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON)))
                 if pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
                     pt = pj["kernels"]
-                    base = dom["name"].replace("_block", "").replace("_lift", "")
+                    base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
                     key = next(k for k in pt if k.split("<")[0] in (base, base + "_x3"))
                     roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "

@@ -25,7 +25,7 @@
 #include "fno_dev.h"
 
 #ifndef FNO_OCC_PW
-#define FNO_OCC_PW 4
+#define FNO_OCC_PW 4   // lifting / no-GEMM variants (CIN <= 4) ask for 6 waves per SIMD: 3 workgroups per CU fit their 42 KB of LDS
 #endif
 #ifndef FNO_OCC_PWX
 #define FNO_OCC_PWX 2   // measured: 1 workgroup/CU without spills (0.175 ms) beats 2 with spills (0.27 ms)
@@ -55,7 +55,7 @@ static inline size_t pw_fwd_lds_bytes(int cin, int cout, int npx, int W, int K2i
 }
 
 template <int CIN, int COUT, int NPX>
-__global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
+__global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, CIN <= 4 ? 6 : FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;          // pixel sub-tiles
   constexpr int MT = COUT / 32;          // channel sub-tiles
   constexpr int NW = MT * NTN;
