@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--config", default="fno2d_128x128_w64_m12_b64", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step once into a hipGraph and replay it (single GPU; pays off on the "
+                         "launch-bound small configurations)")
     args = ap.parse_args()
 
     import torch
@@ -128,13 +131,23 @@ def main():
             tgt = torch.randn(model(*inputs).shape, generator=gen).to(dev)
     broadcast_parameters(model)
     bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
-    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)       # run_pde_observers.py:134
+    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
     if not fused_model:
         args.no_cpu_baseline = True
 
     def step():
         return train_step(model, bucket, opt, inputs, tgt, loss_fn)
+
+    eager_step = step
+    if args.graph:
+        if world > 1:
+            sys.exit("bench.py --graph is a single-GPU mode")
+        from pde_policylearning_amd.trainer import GraphedTrainStep
+        graphed = GraphedTrainStep(model, bucket, opt, inputs, tgt, loss_fn)
+
+        def step():
+            return graphed()
 
     def sync():
         torch.cuda.synchronize()
@@ -165,7 +178,7 @@ def main():
         L.fno_profile_reset()
         L.fno_profile_enable(1)
         for _ in range(args.profile_steps):
-            step()
+            eager_step()           # per-kernel events need individual launches
         torch.cuda.synchronize()
         L.fno_profile_enable(0)
         prof = _lib.profile_summary()
@@ -265,7 +278,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
                        "step": "zero_grad+fwd+LpLoss(sum)+bwd" + ("+allreduce(sum)" if world > 1 else "") + "+Adam",
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,

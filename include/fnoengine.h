@@ -161,6 +161,11 @@ int fno_lploss_rel_backward(int batch, size_t n_per_sample, const float* pred, c
  * `step` is the 1-based step count (bias corrections are computed on the host in double). */
 int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void* stream);
+/* Same update with the step count on the DEVICE: *step_counter is incremented and the bias corrections are
+ * derived from it by a one-thread kernel, so a captured hipGraph of the whole training step can be
+ * replayed (no host-side scalar changes between replays).  scratch2: two device floats. */
+int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int* step_counter, float* scratch2, void* stream);
 
 /* ------------------------------------------------------------------------
  * PINO residual loss, SURVEY.md section 8(f) rank 1: FDM_NS_vorticity + Channelflow_PINO_loss

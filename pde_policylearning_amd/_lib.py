@@ -84,6 +84,7 @@ def lib():
     L.fno_lploss_rel_forward.argtypes = [ci, sz, vp, vp, vp, vp, ci, fl, ci, vp, vp, sz, vp]
     L.fno_lploss_rel_backward.argtypes = [ci, sz, vp, vp, vp, ci, fl, vp, vp, vp, sz, vp]
     L.fno_adam_step.argtypes = [sz, vp, vp, vp, vp, fl, fl, fl, fl, fl, ci, vp]
+    L.fno_adam_step_dev.argtypes = [sz, vp, vp, vp, vp, fl, fl, fl, fl, fl, vp, vp, vp]
     L.fno_pino_loss_workspace_bytes.argtypes = [ci, ci, ci]
     L.fno_pino_loss_workspace_bytes.restype = sz
     L.fno_pino_loss_forward.argtypes = [ci, ci, ci, vp, vp, vp, vp, fl, vp, vp, vp, sz, vp]
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "fno_spec_forward", "fno_spec_backward",
     "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",
     "fno_model_forward", "fno_model_backward", "fno_model_backward_dx",
-    "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step",
+    "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
     "fno_pino_loss_workspace_bytes", "fno_pino_loss_forward", "fno_pino_loss_backward",
     "fno_profile_enable", "fno_profile_count", "fno_profile_get", "fno_profile_reset",
 ]

@@ -994,22 +994,40 @@ extern "C" int fno_lploss_rel_backward(int batch, size_t n, const float* pred, c
                    stat_len, eps, n, coef, grad_loss, dpred));
   return FNO_OK;
 }
-extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+static int adam_launch(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, int* step_dev, float* dyn, hipStream_t st) {
   if (!n) return FNO_OK;
-  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(FNO_EINVAL, "fno_adam_step: bad argument");
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(FNO_EINVAL, "fno_adam_step: bad argument");
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
     return fail(FNO_EINVAL, "fno_adam_step: buffers must be 16-byte aligned");
   AdamArgs a;
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
-  a.step_size = (float)((double)lr / bc1);
-  a.bc2_sqrt = (float)std::sqrt(bc2);
-  int ncu = 256;
-  const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)ncu * 8);
-  LAUNCHCHK(launch("k_adam", k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, a));
+  a.dyn = nullptr; a.step_size = 0.f; a.bc2_sqrt = 1.f;
+  if (step_dev) {
+    LAUNCHCHK(launch("k_adam_prep", k_adam_prep, dim3(1), dim3(1), 0, st, step_dev, dyn, lr, beta1, beta2));
+    a.dyn = dyn;
+  } else {
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)std::sqrt(bc2);
+  }
+  const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)dev_ncu() * 8);
+  LAUNCHCHK(launch("k_adam", k_adam, dim3(grid), dim3(256), 0, st, a));
   return FNO_OK;
+}
+extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (step < 1) return fail(FNO_EINVAL, "fno_adam_step: step must be >= 1");
+  return adam_launch(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr,
+                     (hipStream_t)stream);
+}
+extern "C" int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int* step_counter,
+                                 float* scratch2, void* stream) {
+  if (!step_counter || !scratch2) return fail(FNO_EINVAL, "fno_adam_step_dev: null step counter / scratch");
+  return adam_launch(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 0, step_counter, scratch2,
+                     (hipStream_t)stream);
 }
 
 // ===========================================================================

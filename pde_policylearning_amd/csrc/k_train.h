@@ -79,8 +79,17 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v;
   size_t n;
   float lr, beta1, beta2, eps, wd, step_size, bc2_sqrt;
+  const float* dyn;   // graph mode: {step_size, bc2_sqrt} written by k_adam_prep on the device, else null
 };
+// graph-replayable step counter: ++*step, then the two bias-correction scalars of that step (double arithmetic)
+__global__ void k_adam_prep(int* step, float* dyn, float lr, float beta1, float beta2) {
+  const int t = ++step[0];
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  dyn[0] = (float)((double)lr / bc1);
+  dyn[1] = (float)sqrt(bc2);
+}
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
+  if (a.dyn) { a.step_size = a.dyn[0]; a.bc2_sqrt = a.dyn[1]; }
   const size_t n4 = a.n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 p = ld4(a.p + 4 * i), g = ld4(a.g + 4 * i), m = ld4(a.m + 4 * i), v = ld4(a.v + 4 * i);

@@ -299,12 +299,20 @@ def lp_loss_rel(pred, target, mean=None, std=None, eps=1e-5, size_average=False)
     return _LpLossRelFn.apply(pred, target, mean, std, eps, size_average)
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-    """One torch.optim.Adam update of a flat fp32 bucket, in place, one kernel."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              step_counter=None, scratch=None):
+    """One torch.optim.Adam update of a flat fp32 bucket, in place, one kernel.  With `step_counter`
+    (int32 device tensor) the step count lives on the device (fno_adam_step_dev: graph-replayable)."""
     for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _require_cuda(t, name)
         if not t.is_contiguous() or t.numel() != param.numel():
             raise RuntimeError(f"fnoengine adam_step: `{name}` must be contiguous with {param.numel()} elements")
+    if step_counter is not None:
+        _lib.check(_lib.lib().fno_adam_step_dev(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                                float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                float(weight_decay), _ptr(step_counter), _ptr(scratch), _stream()),
+                   "adam_step_dev")
+        return
     _lib.check(_lib.lib().fno_adam_step(param.numel(), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                         float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                         int(step), _stream()), "adam_step")

@@ -132,9 +132,14 @@ class FusedAdam(object):
     kernel over a flat parameter bucket.  Parameters are re-pointed at views of one contiguous buffer
     laid out exactly like the FlatGradBucket, so the step reads the all-reduced gradient bucket directly."""
 
-    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """capturable: keep the step count on the device (fno_adam_step_dev) so that a captured hipGraph of
+        the training step (GraphedTrainStep) can be replayed."""
         self.bucket = bucket
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.capturable = capturable
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=bucket.flat.device) if capturable else None
+        self.scratch = torch.zeros(2, dtype=torch.float32, device=bucket.flat.device) if capturable else None
         self.flat_param = torch.empty_like(bucket.flat)
         with torch.no_grad():
             for p, v in zip(bucket.params, bucket.views(self.flat_param)):
@@ -150,16 +155,20 @@ class FusedAdam(object):
     def step(self):
         from . import functional as F
         self.bucket.check_views()
-        self.step_count += 1
+        self.step_count += 1            # host mirror; under graph replay the device counter is authoritative
         F.adam_step(self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                    self.betas, self.eps, self.weight_decay)
+                    self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
 
     def state_dict(self):
+        if self.capturable:
+            self.step_count = int(self.step_dev.item())
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
                     eps=self.eps, weight_decay=self.weight_decay)
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        if self.capturable:
+            self.step_dev.fill_(self.step_count)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
@@ -201,3 +210,43 @@ def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=Non
     if optimizer is not None:
         optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep(object):
+    """The whole training step (zero_grad -> forward -> loss -> backward -> [all-reduce] -> Adam) captured ONCE
+    into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~50 launches of a small configuration
+    (BASELINE config 1) become one graph launch.  Everything the step enqueues goes through the engine's C ABI
+    on the capture stream; no host-side scalar changes between replays (FusedAdam(capturable=True) keeps its step
+    count on the device).  Warm-up steps run before capture on a side stream and their effect on the optimizer /
+    parameters is rolled back, so the first replay is step 1."""
+
+    def __init__(self, model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None, warmup=2):
+        assert isinstance(optimizer, FusedAdam) and optimizer.capturable, "GraphedTrainStep needs FusedAdam(capturable=True)"
+        self.inputs = [t.clone() for t in inputs]
+        self.target = target.clone()
+        opt = optimizer
+        snap = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev, bucket.flat)]
+        host_step = opt.step_count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model_fn, bucket, opt, self.inputs, self.target, loss_fn, decoder)
+        torch.cuda.current_stream().wait_stream(side)
+        for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev, bucket.flat), snap):
+            dst.copy_(src)
+        opt.step_count = host_step
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model_fn, bucket, opt, self.inputs, self.target, loss_fn, decoder)
+        opt.step_count = host_step            # capture enqueued nothing
+
+    def __call__(self, inputs=None, target=None):
+        if inputs is not None:
+            for dst, src in zip(self.inputs, inputs):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        if target is not None and target.data_ptr() != self.target.data_ptr():
+            self.target.copy_(target)
+        self.graph.replay()
+        return self.loss

@@ -575,3 +575,28 @@ def test_pino_loss_reference_surface(dev):
     lic, lf = Channelflow_PINO_loss(out, u0, get_forcing(n).to(dev), (1.0 / torch.from_numpy(g["re"])).to(dev), float(g["t_interval"]))
     assert abs(float(lic) - float(g["loss_ic"])) < 1e-5 * abs(float(g["loss_ic"]))
     assert abs(float(lf) - float(g["loss_f"])) < 1e-5 * abs(float(g["loss_f"]))
+
+
+def test_graphed_train_step_equals_eager(dev):
+    """hipGraph replay of the whole step (trainer.GraphedTrainStep) reproduces the eager trajectory bit for bit,
+    including the device-side Adam step counter."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, GraphedTrainStep, train_step
+    torch.manual_seed(4)
+    m1 = FNO2d(8, 8, 32).to(dev)
+    m2 = FNO2d(8, 8, 32).to(dev)
+    m2.load_state_dict(m1.state_dict())
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    t = torch.randn(4, 1, 64, 64, device=dev)
+    b1 = FlatGradBucket(m1.parameters(), direct_module=m1)
+    b2 = FlatGradBucket(m2.parameters(), direct_module=m2)
+    o1 = FusedAdam(b1, lr=1e-3, weight_decay=1e-4)
+    o2 = FusedAdam(b2, lr=1e-3, weight_decay=1e-4, capturable=True)
+    loss_fn = FusedLpLoss(size_average=False)
+    step2 = GraphedTrainStep(m2, b2, o2, (x,), t, loss_fn)
+    for i in range(4):
+        l1 = train_step(m1, b1, o1, (x,), t, loss_fn)
+        l2 = step2()
+        assert float(l1) == float(l2), i
+    assert torch.equal(o1.flat_param, o2.flat_param)
+    assert o2.state_dict()["step"] == 4
