@@ -186,6 +186,28 @@ int fno_pino_loss_backward(int batch, int n, int nt, const float* u, const float
                            const float* visc, float t_interval, const float* g_ic, const float* g_f, float* du, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Gates of the recurrent neural operator cell, neuralop/models/rno.py:254-260 (all tensors (B, C, X, Y) fp32,
+ * n elements, 16-byte aligned, n % 4 == 0; b* are the cell's SCALAR biases on the device):
+ *   reset gate : r = sigmoid(a3 + a4 + b2), rh = r * h                                   (:256-257)
+ *   output gate: z = sigmoid(a1 + a2 + b1), z2 = sigmoid(a7 + a8 + b4), s3 = a5 + a6 + b3,
+ *                h_new = (1 - z) * h + z2 * selu(s3)                                     (:254-255, :257-260)
+ * a_i = f_i(.) are the cell's Fourier layers.  backward returns the gradient of each pre-activation sum
+ * (shared by its two addends), the direct gradient to h, and fno_rno_gate_partials() per-workgroup partial
+ * sums of every bias gradient (reset: [P]; output: [3][P] for b1, b4, b3) to be summed by the caller.
+ * ---------------------------------------------------------------------- */
+int fno_rno_gate_partials(void);
+int fno_rno_reset_gate_forward(size_t n, const float* a3, const float* a4, const float* b2, const float* h, float* r,
+                               float* rh, void* stream);
+int fno_rno_reset_gate_backward(size_t n, const float* d_rh, const float* r, const float* h, float* d_s, float* d_h,
+                                float* db_partials, void* stream);
+int fno_rno_output_gate_forward(size_t n, const float* a1, const float* a2, const float* b1, const float* a7,
+                                const float* a8, const float* b4, const float* a5, const float* a6, const float* b3,
+                                const float* h, float* z, float* z2, float* s3, float* h_new, void* stream);
+int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const float* z2, const float* s3,
+                                 const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h, float* db_partials,
+                                 void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

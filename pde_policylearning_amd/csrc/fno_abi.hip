@@ -18,6 +18,7 @@
 #include "k_projection.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
+#include "k_rno_gates.h"
 #include "k_train.h"
 
 // --------------------------------------------------------------------------
@@ -1107,4 +1108,53 @@ extern "C" int fno_pino_loss_backward(int B, int n, int T, const float* u, const
                    (const float*)w.dws, (const float*)(w.fields + 4 * np), (const float*)w.coef_f, (const float*)w.coef_ic,
                    g_f, g_ic, B, n * n, T, a.inv2dt, du));
   return FNO_OK;
+}
+
+// ===========================================================================
+// RNO cell gates (neuralop/models/rno.py:254-260)
+// ===========================================================================
+static const int kGateGrid = 2048;
+extern "C" int fno_rno_gate_partials(void) { return kGateGrid; }
+static int gate_check(size_t n, std::initializer_list<const void*> ptrs) {
+  if (n == 0 || n % 4 != 0) return fail(FNO_EINVAL, "rno gates: element count must be a positive multiple of 4 (got %zu)", n);
+  for (const void* p : ptrs)
+    if (!p || ((uintptr_t)p & 15)) return fail(FNO_EINVAL, "rno gates: null or unaligned (16 B) tensor");
+  return FNO_OK;
+}
+extern "C" int fno_rno_reset_gate_forward(size_t n, const float* a3, const float* a4, const float* b2, const float* h,
+                                          float* r, float* rh, void* stream) {
+  LAUNCHCHK(gate_check(n, {a3, a4, h, r, rh}));
+  if (!b2) return fail(FNO_EINVAL, "rno gates: null bias");
+  return launch("k_rno_reset_fwd", k_rno_reset_fwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, (const float4*)a3,
+                (const float4*)a4, b2, (const float4*)h, (float4*)r, (float4*)rh, n / 4);
+}
+extern "C" int fno_rno_reset_gate_backward(size_t n, const float* d_rh, const float* r, const float* h, float* d_s,
+                                           float* d_h, float* db_partials, void* stream) {
+  LAUNCHCHK(gate_check(n, {d_rh, r, h, d_s, d_h}));
+  if (!db_partials) return fail(FNO_EINVAL, "rno gates: null partial buffer");
+  return launch("k_rno_reset_bwd", k_rno_reset_bwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, (const float4*)d_rh,
+                (const float4*)r, (const float4*)h, (float4*)d_s, (float4*)d_h, db_partials, n / 4);
+}
+extern "C" int fno_rno_output_gate_forward(size_t n, const float* a1, const float* a2, const float* b1, const float* a7,
+                                           const float* a8, const float* b4, const float* a5, const float* a6,
+                                           const float* b3, const float* h, float* z, float* z2, float* s3, float* h_new,
+                                           void* stream) {
+  LAUNCHCHK(gate_check(n, {a1, a2, a7, a8, a5, a6, h, z, z2, s3, h_new}));
+  if (!b1 || !b4 || !b3) return fail(FNO_EINVAL, "rno gates: null bias");
+  RnoOutArgs a;
+  a.a1 = (const float4*)a1; a.a2 = (const float4*)a2; a.a7 = (const float4*)a7; a.a8 = (const float4*)a8;
+  a.a5 = (const float4*)a5; a.a6 = (const float4*)a6; a.h = (const float4*)h; a.b1 = b1; a.b4 = b4; a.b3 = b3;
+  a.z = (float4*)z; a.z2 = (float4*)z2; a.s3 = (float4*)s3; a.hn = (float4*)h_new; a.n4 = n / 4;
+  return launch("k_rno_out_fwd", k_rno_out_fwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, a);
+}
+extern "C" int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const float* z2, const float* s3,
+                                            const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h,
+                                            float* db_partials, void* stream) {
+  LAUNCHCHK(gate_check(n, {g, z, z2, s3, h, d_s1, d_s7, d_s3, d_h}));
+  if (!db_partials) return fail(FNO_EINVAL, "rno gates: null partial buffer");
+  RnoOutBwdArgs a;
+  a.g = (const float4*)g; a.z = (const float4*)z; a.z2 = (const float4*)z2; a.s3 = (const float4*)s3; a.h = (const float4*)h;
+  a.ds1 = (float4*)d_s1; a.ds7 = (float4*)d_s7; a.ds3 = (float4*)d_s3; a.dh = (float4*)d_h; a.db_part = db_partials;
+  a.n4 = n / 4;
+  return launch("k_rno_out_bwd", k_rno_out_bwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, a);
 }

@@ -455,3 +455,70 @@ def pino_loss(u, u0, forcing, visc, t_interval=1.0):
     u (B, n, n, nt) model output, u0 (B, n, n), forcing (n, n) or (1, n, n, 1), visc (B,) = 1 / Re.
     Differentiable w.r.t. u.  n in {32, 64, 128}."""
     return _PinoLossFn.apply(u, u0, forcing, visc, t_interval)
+
+
+# ----------------------------------------------------------------------------
+# RNO cell gates (neuralop/models/rno.py:254-260)
+# ----------------------------------------------------------------------------
+def gates_supported(*tensors):
+    t0 = tensors[0]
+    return all(t.is_cuda and t.dtype == torch.float32 and t.shape == t0.shape for t in tensors) and t0.numel() % 4 == 0
+
+
+class _RnoResetGateFn(torch.autograd.Function):
+    """rh = sigmoid(a3 + a4 + b2) * h."""
+
+    @staticmethod
+    def forward(ctx, a3, a4, b2, h):
+        a3, a4, h = a3.contiguous(), a4.contiguous(), h.contiguous()
+        r, rh = torch.empty_like(h), torch.empty_like(h)
+        _lib.check(_lib.lib().fno_rno_reset_gate_forward(h.numel(), _ptr(a3), _ptr(a4), _ptr(b2), _ptr(h), _ptr(r), _ptr(rh),
+                                                         _stream()), "rno_reset_gate_forward")
+        ctx.save_for_backward(r, h)
+        return rh
+
+    @staticmethod
+    def backward(ctx, d_rh):
+        r, h = ctx.saved_tensors
+        L = _lib.lib()
+        d_rh = d_rh.contiguous()
+        ds, dh = torch.empty_like(h), torch.empty_like(h)
+        part = torch.empty(L.fno_rno_gate_partials(), dtype=torch.float32, device=h.device)
+        _lib.check(L.fno_rno_reset_gate_backward(h.numel(), _ptr(d_rh), _ptr(r), _ptr(h), _ptr(ds), _ptr(dh), _ptr(part),
+                                                 _stream()), "rno_reset_gate_backward")
+        return ds, ds, part.sum().reshape(()), dh
+
+
+class _RnoOutputGateFn(torch.autograd.Function):
+    """h_new = (1 - sigmoid(a1 + a2 + b1)) * h + sigmoid(a7 + a8 + b4) * selu(a5 + a6 + b3)."""
+
+    @staticmethod
+    def forward(ctx, a1, a2, b1, a7, a8, b4, a5, a6, b3, h):
+        a1, a2, a7, a8, a5, a6, h = [t.contiguous() for t in (a1, a2, a7, a8, a5, a6, h)]
+        z, z2, s3, hn = (torch.empty_like(h) for _ in range(4))
+        _lib.check(_lib.lib().fno_rno_output_gate_forward(h.numel(), _ptr(a1), _ptr(a2), _ptr(b1), _ptr(a7), _ptr(a8), _ptr(b4),
+                                                          _ptr(a5), _ptr(a6), _ptr(b3), _ptr(h), _ptr(z), _ptr(z2), _ptr(s3),
+                                                          _ptr(hn), _stream()), "rno_output_gate_forward")
+        ctx.save_for_backward(z, z2, s3, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, g):
+        z, z2, s3, h = ctx.saved_tensors
+        L = _lib.lib()
+        g = g.contiguous()
+        d1, d7, d3, dh = (torch.empty_like(h) for _ in range(4))
+        P = L.fno_rno_gate_partials()
+        part = torch.empty(3, P, dtype=torch.float32, device=h.device)
+        _lib.check(L.fno_rno_output_gate_backward(h.numel(), _ptr(g), _ptr(z), _ptr(z2), _ptr(s3), _ptr(h), _ptr(d1), _ptr(d7),
+                                                  _ptr(d3), _ptr(dh), _ptr(part), _stream()), "rno_output_gate_backward")
+        db = part.sum(dim=1)
+        return d1, d1, db[0].reshape(()), d7, d7, db[1].reshape(()), d3, d3, db[2].reshape(()), dh
+
+
+def rno_reset_gate(a3, a4, b2, h):
+    return _RnoResetGateFn.apply(a3, a4, b2, h)
+
+
+def rno_output_gate(a1, a2, b1, a7, a8, b4, a5, a6, b3, h):
+    return _RnoOutputGateFn.apply(a1, a2, b1, a7, a8, b4, a5, a6, b3, h)

@@ -110,6 +110,11 @@ class RNO_cell(nn.Module):
             setattr(self, f"b{i}", nn.Parameter(torch.normal(torch.tensor(0.), torch.tensor(1.))))
 
     def forward(self, x, h):
+        if F.gates_supported(x, h):
+            # two fused engine kernels for everything between the eight Fourier layers (fno_rno_*_gate_*)
+            rh = F.rno_reset_gate(self.f3(x), self.f4(h), self.b2, h)
+            return F.rno_output_gate(self.f1(x), self.f2(h), self.b1, self.f7(x), self.f8(h), self.b4,
+                                     self.f5(x), self.f6(rh), self.b3, h)
         z = torch.sigmoid(self.f1(x) + self.f2(h) + self.b1)
         z2 = torch.sigmoid(self.f7(x) + self.f8(h) + self.b4)
         r = torch.sigmoid(self.f3(x) + self.f4(h) + self.b2)

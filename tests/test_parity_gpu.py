@@ -600,3 +600,33 @@ def test_graphed_train_step_equals_eager(dev):
         assert float(l1) == float(l2), i
     assert torch.equal(o1.flat_param, o2.flat_param)
     assert o2.state_dict()["step"] == 4
+
+
+def test_rno_gates_match_torch_formulas(dev):
+    """fno_rno_*_gate_* vs the torch expressions of rno.py:254-260 (values and every gradient, incl. the scalar biases)."""
+    from pde_policylearning_amd import functional as F
+    torch.manual_seed(9)
+    shp = (2, 8, 12, 10)
+    ts = [torch.randn(shp, device=dev, requires_grad=True) for _ in range(9)]     # a1 a2 a7 a8 a5 a6 a3 a4 h
+    bs = [torch.randn((), device=dev, requires_grad=True) for _ in range(4)]      # b1 b4 b3 b2
+    def ref():
+        a1, a2, a7, a8, a5, a6, a3, a4, h = ts
+        b1, b4, b3, b2 = bs
+        r = torch.sigmoid(a3 + a4 + b2)
+        z, z2 = torch.sigmoid(a1 + a2 + b1), torch.sigmoid(a7 + a8 + b4)
+        return (1. - z) * h + z2 * torch.nn.functional.selu(a5 + a6 + b3) + 0.5 * (r * h)
+    def eng():
+        a1, a2, a7, a8, a5, a6, a3, a4, h = ts
+        b1, b4, b3, b2 = bs
+        return F.rno_output_gate(a1, a2, b1, a7, a8, b4, a5, a6, b3, h) + 0.5 * F.rno_reset_gate(a3, a4, b2, h)
+    gy = torch.randn(shp, device=dev)
+    out = []
+    for fn in (ref, eng):
+        for t in ts + bs:
+            t.grad = None
+        y = fn()
+        y.backward(gy)
+        out.append([_cpu(y)] + [_cpu(t.grad) for t in ts + bs])
+    for i, (a, b) in enumerate(zip(*out)):
+        # the four scalar-bias gradients are sums of ~2000 signed terms: fp32 summation order shows at ~1e-6
+        assert rel_l2(b, a) < (2e-5 if i >= 10 else 2e-6), i
