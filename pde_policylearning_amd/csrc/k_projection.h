@@ -609,27 +609,33 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
 
     FNO_STAMP(tslot + 12);
     // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
-    if (hm == 1) {
+    // C = 64: wave (hm, nt) finalises channel block m = hm of its 32 pixels and hands the other block to its
+    // partner; C = 32: the hm = 0 wave finalises the single block
+    {
       float* pp = part + (4 * half) * PITCH + n0 + l31;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
+        if (!((MT == 2) ? (m == hm) : (hm == 0))) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
+          for (int r = 0; r < 16; ++r) pp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
+        }
     }
     __syncthreads();
-    if (hm == 0) {
+    {
       const float* pp = part + (4 * half) * PITCH + n0 + l31;
       float* xp = tmpf + (4 * half) * PITCH + n0 + l31;
       const size_t goff = ((size_t)b * C + 4 * half) * a.PW + px0 + n0 + l31;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
+        if ((MT == 2) ? (m == hm) : (hm == 0)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc2[m][r] + pp[ro * PITCH];
-          if (a.act_in) v *= gelu_grad_f(a.x[goff + (size_t)ro * a.PW]);
-          a.gout[goff + (size_t)ro * a.PW] = v;
-          if (a.x1g) xp[ro * PITCH] = v;
+          for (int r = 0; r < 16; ++r) {
+            const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc2[m][r] + pp[ro * PITCH];
+            if (a.act_in) v *= gelu_grad_f(a.x[goff + (size_t)ro * a.PW]);
+            a.gout[goff + (size_t)ro * a.PW] = v;
+            if (a.x1g) xp[ro * PITCH] = v;
+          }
         }
     }
     FNO_STAMP(tslot + 13);
