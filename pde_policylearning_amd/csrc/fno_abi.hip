@@ -461,8 +461,14 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, int B, 
     if (C == 32) return launch("k_rowdft_tile", k_rowdft_tile<32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowdft_tile", k_rowdft_tile<64, 128>, dim3(grid), dim3(256), lds, st, a);
   }
-  return launch("k_rowdft_generic", k_rowdft_generic, dim3(B * g.P), dim3(256), (size_t)C * (g.W + 1) * 4, st, x,
-                (float2*)x1, tfwd, C, g.P, g.W, g.Klast);
+  // rows per workgroup: as many as keep the tile + table under 64 KB (several workgroups per CU), at most 8
+  const int k2e = (g.Klast + 1) & ~1;
+  int rb = 8;
+  while (rb > 1 && ((size_t)C * (rb * g.W + 1) + (size_t)g.W * 2 * k2e) * 4 > 64 * 1024) rb >>= 1;
+  const size_t lds = ((size_t)C * (rb * g.W + 1) + (size_t)g.W * 2 * k2e) * 4;
+  if (lds > 160 * 1024) return fail(FNO_EUNSUPPORTED, "row tile of %d channels x %d floats exceeds LDS", C, g.W);
+  return launch("k_rowdft_generic", k_rowdft_generic, dim3(B * ((g.P + rb - 1) / rb)), dim3(256), lds, st, x, (float2*)x1,
+                tfwd, C, g.P, g.W, g.Klast, rb);
 }
 static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, int C, const float* z, const float* bias,
                        float* y) {
@@ -477,8 +483,12 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, 
     if (C == 32) return launch("k_rowidft_tile", k_pw_fwd<2, 32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowidft_tile", k_pw_fwd<2, 64, 128>, dim3(grid), dim3(512), lds, st, a);
   }
-  return launch("k_rowidft_generic", k_rowidft_generic, dim3(B * g.P), dim3(256), (size_t)g.Klast * C * 8, st,
-                (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
+  int rb = 8;
+  auto need = [&](int r) { return (((size_t)2 * g.Klast * g.W + 1) & ~(size_t)1) * 4 + (size_t)r * g.Klast * C * 8; };
+  while (rb > 1 && need(rb) > 64 * 1024) rb >>= 1;
+  if (need(rb) > 160 * 1024) return fail(FNO_EUNSUPPORTED, "row spectra of %d channels x %d bins exceed LDS", C, g.Klast);
+  return launch("k_rowidft_generic", k_rowidft_generic, dim3(B * ((g.P + rb - 1) / rb)), dim3(256), need(rb), st,
+                (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast, rb);
 }
 
 extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, const float* const* wc, const float* bias,

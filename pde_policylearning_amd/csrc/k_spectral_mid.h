@@ -381,52 +381,89 @@ __global__ void __launch_bounds__(256) k_mode_gemm_dw(const float2* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// generic last-dim passes (any W, any C): one workgroup per (b, plane-row)
+// generic last-dim passes (any W, any C: odd row lengths such as PINO's padded T, 34-channel RNO).
+// A workgroup owns RB consecutive rows of one sample for all channels (rows are adjacent in memory, so the
+// channel segments it reads / writes are RB*W floats long); twiddle tables and the tile live in LDS.
 // x (B, C, P, W) -> x1 (B, P, K2, C, 2);  tfwd (>= 2*K2 rows, W)
+//   LDS: table [W][2*K2] | tile [C][RB*W + 1]
 __global__ void __launch_bounds__(256) k_rowdft_generic(const float* __restrict__ x, float2* __restrict__ x1,
-                                                        const float* __restrict__ tfwd, int C, int P, int W, int K2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // C x (W+1)
-  const int row = blockIdx.x;  // b * P + p
-  const int b = row / P, p = row % P;
-  const int pitch = W + 1;
-  for (int idx = threadIdx.x; idx < C * W; idx += blockDim.x) {
-    const int c = idx / W, w = idx % W;
-    smem[c * pitch + w] = x[(((size_t)b * C + c) * P + p) * W + w];
+                                                        const float* __restrict__ tfwd, int C, int P, int W, int K2,
+                                                        int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K2E = (K2 + 1) & ~1;                   // table rows padded to a multiple of 4 floats
+  float* tab = smem;                                // [w][2*K2E]: (re, im) pairs of every kept bin
+  float* xs = smem + W * 2 * K2E;                   // [c][RB*W + 1]
+  const int nblk = (P + RB - 1) / RB;
+  const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
+  const int nr = min(RB, P - p0);
+  const int pitch = RB * W + 1;
+  for (int i = threadIdx.x; i < W * 2 * K2E; i += blockDim.x) {
+    const int w = i / (2 * K2E), j = i % (2 * K2E);
+    tab[i] = j < 2 * K2 ? tfwd[(size_t)j * W + w] : 0.f;
+  }
+  const int seg = nr * W;
+  const size_t cstride = (size_t)P * W;
+  const float* xb = x + ((size_t)b * C * P + p0) * W;
+  for (int base = threadIdx.x; base < C * seg; base += 8 * blockDim.x) {    // eight loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * blockDim.x;
+      v[j] = idx < C * seg ? xb[(size_t)(idx / seg) * cstride + idx % seg] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * blockDim.x;
+      if (idx < C * seg) xs[(idx / seg) * pitch + idx % seg] = v[j];
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < C * K2; idx += blockDim.x) {
-    const int c = idx % C, k2 = idx / C;
-    const float* tr = tfwd + (size_t)(2 * k2) * W;
-    const float* ti = tr + W;
-    float sr = 0.f, si = 0.f;
+  // item = (row r, bin pair kp, channel c): two bins = 4 accumulators, channel fastest (lanes <-> channels)
+  const int nkp = K2E / 2;
+  for (int it = threadIdx.x; it < nr * nkp * C; it += blockDim.x) {
+    const int c = it % C, kp = (it / C) % nkp, r = it / (C * nkp);
+    const float* xr = xs + c * pitch + r * W;
+    const float* tp = tab + 4 * kp;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int w = 0; w < W; ++w) {
-      const float v = smem[c * pitch + w];
-      sr = fmaf(v, tr[w], sr);
-      si = fmaf(v, ti[w], si);
+      const float v = xr[w];
+      const float4 t = ld4(tp + w * 2 * K2E);       // wave-uniform address: LDS broadcast
+      a0 = fmaf(v, t.x, a0); a1 = fmaf(v, t.y, a1); a2 = fmaf(v, t.z, a2); a3 = fmaf(v, t.w, a3);
     }
-    x1[((size_t)row * K2 + k2) * C + c] = make_float2(sr, si);
+    const size_t row = (size_t)b * P + p0 + r;
+    x1[(row * K2 + 2 * kp) * C + c] = make_float2(a0, a1);
+    if (2 * kp + 1 < K2) x1[(row * K2 + 2 * kp + 1) * C + c] = make_float2(a2, a3);
   }
 }
 
 // z (B, P, K2, C, 2) -> y (B, C, P, W) (+ bias[c]);  tinv (2*K2, W)
+//   LDS: table [2*K2][W] | spectra [RB][K2][C][2]
 __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restrict__ z, float* __restrict__ y,
                                                          const float* __restrict__ tinv,
                                                          const float* __restrict__ bias, int C, int P, int W,
-                                                         int K2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // K2 x C x 2
-  const int row = blockIdx.x;
-  const int b = row / P, p = row % P;
-  const float* zr = reinterpret_cast<const float*>(z + (size_t)row * K2 * C);
-  for (int idx = threadIdx.x; idx < K2 * C * 2; idx += blockDim.x) smem[idx] = zr[idx];
+                                                         int K2, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tab = smem;                                            // [2*K2][W]
+  float2* zs = reinterpret_cast<float2*>(smem + ((2 * K2 * W + 1) & ~1));   // [r][k2][c]
+  const int nblk = (P + RB - 1) / RB;
+  const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
+  const int nr = min(RB, P - p0);
+  for (int i = threadIdx.x; i < 2 * K2 * W; i += blockDim.x) tab[i] = tinv[i];
+  const float2* zr = z + ((size_t)b * P + p0) * K2 * C;
+  for (int i = threadIdx.x; i < nr * K2 * C; i += blockDim.x) zs[i] = zr[i];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < C * W; idx += blockDim.x) {
-    const int c = idx / W, w = idx % W;
+  // element (c, r, w): lanes <-> consecutive w (coalesced stores, conflict-free table reads, broadcast spectra)
+  const int seg = nr * W;
+  for (int idx = threadIdx.x; idx < C * seg; idx += blockDim.x) {
+    const int c = idx / seg, o = idx % seg, r = o / W, w = o % W;
     float s = bias ? bias[c] : 0.f;
+    const float2* zc = zs + (size_t)r * K2 * C + c;
     for (int k2 = 0; k2 < K2; ++k2) {
-      s = fmaf(smem[(k2 * C + c) * 2], tinv[(size_t)(2 * k2) * W + w], s);
-      s = fmaf(smem[(k2 * C + c) * 2 + 1], tinv[(size_t)(2 * k2 + 1) * W + w], s);
+      const float2 v = zc[k2 * C];
+      s = fmaf(v.x, tab[(2 * k2) * W + w], s);
+      s = fmaf(v.y, tab[(2 * k2 + 1) * W + w], s);
     }
-    y[(((size_t)b * C + c) * P + p) * W + w] = s;
+    y[(((size_t)b * C + c) * P + p0) * W + o] = s;
   }
 }
 
