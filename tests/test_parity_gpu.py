@@ -630,3 +630,59 @@ def test_rno_gates_match_torch_formulas(dev):
     for i, (a, b) in enumerate(zip(*out)):
         # the four scalar-bias gradients are sums of ~2000 signed terms: fp32 summation order shows at ~1e-6
         assert rel_l2(b, a) < (2e-5 if i >= 10 else 2e-6), i
+
+
+# ---------------------------------------------------------------------------------------------
+# channel-count and layer-count edges of the fused model; 3-D block stack
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,cin,cout,L,S,B", [(32, 1, 1, 1, 32, 1),      # single layer, single sample, one input channel
+                                              (64, 2, 2, 3, 64, 2),      # two outputs: the NCO = 4 projection kernels
+                                              (32, 4, 4, 6, 32, 2)])     # widest lifting / projection, six layers (gate: l < L - l)
+def test_fno2d_channel_and_layer_edges_vs_oracle(dev, C, cin, cout, L, S, B):
+    from pde_policylearning_amd import functional as F
+    modes = (8, 6)
+    half = [m // 2 for m in modes]
+    p = _fno_params(C, L, half, cin=cin, cout=cout, seed_tag="e")
+    x = torch.from_numpy(fill_named("xe", (B, cin, S, S), 1.0))
+    tgt = torch.from_numpy(fill_named("te", (B, cout, S, S), 1.0))
+    pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    yc = O.fno_forward(pc, x, modes, n_layers=L)
+    O.lp_loss_rel_sum(yc, tgt).backward()
+    y, pg = _run_fused(p, x, modes, dev, n_layers=L)
+    assert y.shape == (B, cout, S, S)
+    assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    for k in p:
+        assert rel_l2(_cpu(pg[k].grad), pc[k].grad.numpy()) < TOL_G, k
+
+
+def test_block_stack_3d_vs_oracle(dev):
+    """3-D block stack (PINO layer form, pinobserver.py:221-226: SpectralConv3d + Conv1d(k=1), GELU except last) on a
+    grid whose last dimension the fused kernels cover; engine corner order (lo,lo),(lo,hi),(hi,lo),(hi,hi)."""
+    from pde_policylearning_amd import functional as F
+    B, C, dims, modes, L = 1, 32, (8, 16, 32), (3, 4, 5), 2
+    x = torch.from_numpy(fill_named("x3", (B, C) + dims, 1.0))
+    dy = torch.from_numpy(fill_named("dy3", (B, C) + dims, 1.0))
+    skips = [torch.from_numpy(fill_named(f"s3{l}", (C, C, 1), 0.1)) for l in range(L)]
+    specs = [torch.from_numpy(fill_named(f"w3{i}", (C, C) + modes + (2,), 0.02)) for i in range(4 * L)]   # per layer: w1..w4
+    bias = torch.from_numpy(fill_named("b3", (L, C), 0.1))
+    leaves = [t.clone().requires_grad_(True) for t in [x] + skips + specs + [bias]]
+    xo, so, wo, bo = leaves[0], leaves[1:1 + L], leaves[1 + L:1 + 5 * L], leaves[-1]
+    h = xo
+    for l in range(L):
+        wc = [torch.view_as_complex(w) for w in wo[4 * l:4 * l + 4]]
+        h = O.spectral_conv_C3d(h, *wc, *modes) + O.conv1x1(h, so[l].view(C, C, 1, 1, 1), bo[l])
+        if l < L - 1:
+            h = torch.nn.functional.gelu(h)
+    h.backward(dy)
+    dl = [t.to(dev).requires_grad_(True) for t in [x] + skips + specs + [bias]]
+    # basics.py:127-134 numbers the corners w1 (lo,lo), w2 (hi,lo), w3 (lo,hi), w4 (hi,hi); the engine wants (lo,hi) before (hi,lo)
+    eng_specs = []
+    for l in range(L):
+        w1, w2, w3, w4 = dl[1 + L + 4 * l:1 + L + 4 * l + 4]
+        eng_specs += [w1, w3, w2, w4]
+    ye = F.fno_blocks(dl[0], dl[1:1 + L], eng_specs, dl[-1], modes, "backward", gelu_mask=(1 << (L - 1)) - 1)
+    assert rel_l2(_cpu(ye), h.detach().numpy()) < TOL_Y
+    ye.backward(dy.to(dev))
+    for a, b in zip(dl, leaves):
+        assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, (a.shape,)
