@@ -208,6 +208,20 @@ int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const
                                  const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h, float* db_partials,
                                  void* stream);
 
+/* ------------------------------------------------------------------------
+ * Pointwise channel mix  y[b, o, p] = sum_i w[o, i] x[b, i, p] + bias[o] + addend[b, o, p]  and its autograd:
+ * the Conv1d(k=1) beside every spectral convolution of the observer models
+ * (libs/models/pino_models/pinobserver.py:221-226 `sp_convs[i](x) + ws[i](x)`; neuralop/models/rno.py:224-228),
+ * for grids the fused block stacks do not cover (odd last dimension).  x, y, addend, dy, dx: (B, C, PW) fp32,
+ * C in {32, 64}, PW % 128 == 0; w (C, C) row-major [o][i]; bias / addend / dx / dbias nullable.
+ * The gradient w.r.t. `addend` is dy itself.
+ * ---------------------------------------------------------------------- */
+size_t fno_pointwise_workspace_bytes(int channels);
+int fno_pointwise_forward(int batch, int channels, size_t plane, const float* x, const float* w, const float* bias,
+                          const float* addend, float* y, void* stream);
+int fno_pointwise_backward(int batch, int channels, size_t plane, const float* x, const float* w, const float* dy,
+                           float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

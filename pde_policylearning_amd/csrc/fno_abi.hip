@@ -1168,3 +1168,66 @@ extern "C" int fno_rno_output_gate_backward(size_t n, const float* g, const floa
   a.n4 = n / 4;
   return launch("k_rno_out_bwd", k_rno_out_bwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, a);
 }
+
+// ===========================================================================
+// Pointwise (1x1) channel mix with fused bias / residual add, forward and backward: the Conv1d(k=1) next to every
+// spectral convolution of the observer models (libs/models/pino_models/pinobserver.py:183-184, 221-226:
+// `sp_convs[i](x) + ws[i](x)`; neuralop/models/rno.py:222-228) for shapes the block stacks do not cover
+// (odd last dimension).  Same tile kernels as the FNO block, without any spectral row pass.
+// ===========================================================================
+static int pw_check(int B, int C, size_t PW) {
+  if (B < 1 || PW < 1) return fail(FNO_EINVAL, "pointwise: bad shape");
+  if (C != 32 && C != 64) return fail(FNO_EUNSUPPORTED, "pointwise: 32 or 64 channels (got %d)", C);
+  if (PW % 128 != 0) return fail(FNO_EUNSUPPORTED, "pointwise: plane of %zu elements does not tile by 128", PW);
+  if (PW > (size_t)1 << 30 || (size_t)B * (PW / 128) > (size_t)1 << 30) return fail(FNO_EUNSUPPORTED, "pointwise: tensor too large");
+  return FNO_OK;
+}
+// a FnoModelPlan shell carrying what the launch helpers read (tile size, CU count, width)
+static FnoModelPlan pw_shell(int C) {
+  FnoModelPlan p;
+  memset(&p.d, 0, sizeof(p.d));
+  p.d.C = C;
+  p.NPX = 128;
+  p.ncu = dev_ncu();
+  return p;
+}
+extern "C" size_t fno_pointwise_workspace_bytes(int C) {
+  const int grid = 2 * dev_ncu();
+  return ((size_t)grid * 2 * C * C + (size_t)grid * C) * sizeof(float) + 1024;
+}
+extern "C" int fno_pointwise_forward(int B, int C, size_t PW, const float* x, const float* w, const float* bias,
+                                     const float* addend, float* y, void* stream) {
+  LAUNCHCHK(pw_check(B, C, PW));
+  if (!x || !w || !y) return fail(FNO_EINVAL, "fno_pointwise_forward: null argument");
+  FnoModelPlan p = pw_shell(C);
+  PwFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.bias = bias; a.add = addend; a.u = y;
+  a.PW = (int)PW; a.W = 128; a.P = (int)(PW / 128);
+  a.tiles_per_plane = (int)(PW / 128); a.ntiles = B * a.tiles_per_plane;
+  return launch_block(&p, (hipStream_t)stream, std::min(a.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p.ncu), a);
+}
+extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, const float* w, const float* dy, float* dx,
+                                      float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  LAUNCHCHK(pw_check(B, C, PW));
+  if (!x || !w || !dy || !dw || !ws) return fail(FNO_EINVAL, "fno_pointwise_backward: null argument");
+  if (ws_bytes < fno_pointwise_workspace_bytes(C)) return fail(FNO_ENOMEM, "workspace too small");
+  FnoModelPlan p = pw_shell(C);
+  hipStream_t st = (hipStream_t)stream;
+  const int tiles = (int)(PW / 128), ntiles = B * tiles;
+  const int grid = std::min(ntiles, 2 * p.ncu);
+  const int ks = bbwd_ksplit(&p);
+  Carver c(ws, ws_bytes);
+  float* dw_part = c.take<float>((size_t)grid * ks * C * C);
+  float* db_part = c.take<float>((size_t)grid * C);
+  if (!c.ok) return fail(FNO_ENOMEM, "workspace too small");
+  BlkBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = dy; a.uin = x; a.w = w; a.gout = dx; a.dw_part = dw_part; a.db_part = db_part;
+  a.PW = (int)PW; a.W = 128; a.P = tiles; a.tiles_per_plane = tiles; a.ntiles = ntiles;
+  LAUNCHCHK(launch_bbwd(&p, st, grid, a));
+  JobList jobs;
+  jobs.add(dw_part, dw, grid * ks, C, C, C, C);
+  if (dbias) jobs.add(db_part, dbias, grid, 1, C, C, C);
+  return jobs.run(st);
+}

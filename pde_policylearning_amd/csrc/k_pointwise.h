@@ -40,6 +40,7 @@ struct PwFwdArgs {
   float* u;           // (B, COUT, PW) output (pre-activation), or null
   float* x1;          // (B, P, K2out, COUT, 2) row spectra of act_out(u), or null
   const float* tfwd;  // (16*NJ, W) row forward table, zero rows past 2*K2out
+  const float* add;   // (B, COUT, PW) tensor added to the output before it is stored, or null
   int PW, W, P, K2in, K2out, NJ;
   int act_in, act_out;
   int tiles_per_plane, ntiles;
@@ -137,6 +138,11 @@ __global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, CIN <= 4 ? 6 : 
       if (bp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += bp[(r & 3) + 8 * (r >> 2)];   // row acc_row32(r, half)
+      }
+      if (a.add) {
+        const float* ap = a.add + ((size_t)b * COUT + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
       }
       if (up) {
 #pragma unroll
@@ -319,6 +325,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
         float* xp = xs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] += bv[r];
+        if (a.add) {
+          const float* ap = a.add + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
+        }
         if (up) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[q][r];

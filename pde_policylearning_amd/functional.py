@@ -522,3 +522,56 @@ def rno_reset_gate(a3, a4, b2, h):
 
 def rno_output_gate(a1, a2, b1, a7, a8, b4, a5, a6, b3, h):
     return _RnoOutputGateFn.apply(a1, a2, b1, a7, a8, b4, a5, a6, b3, h)
+
+
+# ----------------------------------------------------------------------------
+# pointwise channel mix + bias + residual add (the Conv1d(k=1) beside a spectral convolution)
+# ----------------------------------------------------------------------------
+def pointwise_supported(x):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3):
+        return False
+    pw = 1
+    for s in x.shape[2:]:
+        pw *= s
+    return x.shape[1] in (32, 64) and pw % 128 == 0
+
+
+class _PointwiseAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, addend):
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        pw = x.numel() // (B * Cc)
+        w2 = w.reshape(Cc, Cc).contiguous()
+        add_c = addend.contiguous() if addend is not None else None
+        b_c = bias.contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().fno_pointwise_forward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(b_c), _ptr(add_c), _ptr(y),
+                                                        _stream()), "pointwise_forward")
+        ctx.save_for_backward(x, w2)
+        ctx.meta = (B, Cc, pw, w.shape, bias is not None, addend is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        B, Cc, pw, wshape, has_b, has_add = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2)
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device) if has_b else None
+        nws = L.fno_pointwise_workspace_bytes(Cc)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_pointwise_backward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                                nws, _stream()), "pointwise_backward")
+        return dx, dw.view(wshape), db, (dy if has_add else None)
+
+
+def pointwise_conv_add(x, w, bias=None, addend=None):
+    """y = conv1x1(x; w) + bias + addend  (x, addend (B, C, ...), w (C, C[, 1..]), C in {32, 64}) in one engine
+    kernel each way; the gradient of `addend` is the incoming gradient itself."""
+    return _PointwiseAddFn.apply(x, w, bias, addend)

@@ -10,6 +10,7 @@ from torch import nn
 from torch.nn import init
 
 from .basics import SpectralConv3d
+from .... import functional as F
 
 
 def _activation(name):
@@ -64,7 +65,11 @@ class _SpectralStack(nn.Module):
         sx, sy, sz = x.shape[-3:]
         last = len(self.ws) - 1
         for i, (conv, w) in enumerate(zip(self.sp_convs, self.ws)):
-            x = conv(x) + w(x.reshape(b, self.layers[i], -1)).view(b, self.layers[i + 1], sx, sy, sz)
+            if self.layers[i] == self.layers[i + 1] and F.pointwise_supported(x):
+                # Conv1d(k=1) + bias + the residual add in one engine kernel each way (fno_pointwise_*)
+                x = F.pointwise_conv_add(x, w.weight, w.bias, conv(x))
+            else:
+                x = conv(x) + w(x.reshape(b, self.layers[i], -1)).view(b, self.layers[i + 1], sx, sy, sz)
             if i != last:
                 x = self.act(x)
         return x

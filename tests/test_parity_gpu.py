@@ -686,3 +686,23 @@ def test_block_stack_3d_vs_oracle(dev):
     ye.backward(dy.to(dev))
     for a, b in zip(dl, leaves):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, (a.shape,)
+
+
+@pytest.mark.parametrize("C,shape", [(64, (2, 64, 8, 16, 73)), (32, (3, 32, 4, 96))])
+def test_pointwise_conv_add_vs_torch(dev, C, shape):
+    """fno_pointwise_* (Conv1d(k=1) + bias + residual add, pinobserver.py:221-226) vs the torch ops, odd row lengths."""
+    from pde_policylearning_amd import functional as F
+    x = torch.from_numpy(fill_named("pwx", shape, 1.0))
+    add = torch.from_numpy(fill_named("pwa", shape, 1.0))
+    w = torch.from_numpy(fill_named("pww", (C, C, 1), 0.1))
+    bias = torch.from_numpy(fill_named("pwb", (C,), 0.1))
+    dy = torch.from_numpy(fill_named("pwd", shape, 1.0))
+    ref = [t.clone().requires_grad_(True) for t in (x, w, bias, add)]
+    yr = torch.nn.functional.conv1d(ref[0].reshape(shape[0], C, -1), ref[1], ref[2]).view(shape) + ref[3]
+    yr.backward(dy)
+    eng = [t.to(dev).requires_grad_(True) for t in (x, w, bias, add)]
+    ye = F.pointwise_conv_add(eng[0], eng[1], eng[2], eng[3])
+    assert rel_l2(_cpu(ye), yr.detach().numpy()) < TOL_COMP
+    ye.backward(dy.to(dev))
+    for a, b in zip(eng, ref):
+        assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_COMP, tuple(a.shape)
