@@ -4,7 +4,33 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pde_policylearning_amd import functional as F, _lib
-from oracle import pino_loss_oracle as P       # torch ops = the reference's op sequence; timing leg only
+import math
+
+
+class P:
+    """The reference's op sequence (libs/envs/diff_control_env.py:5-60) in torch ops, for the timing comparison only."""
+
+    @staticmethod
+    def forcing(n, device=None):
+        y = torch.arange(n, device=device, dtype=torch.float32) * (2 * math.pi / n)
+        return (-4 * torch.cos(4 * y)).reshape(1, 1, n, 1).repeat(1, n, 1, 1)
+
+    @staticmethod
+    def pino_loss(u, u0, f, visc, t_interval):
+        B, n, _, nt = u.shape
+        k = torch.cat((torch.arange(0, n // 2, device=u.device), torch.arange(-(n // 2), 0, device=u.device))).float()
+        kx, ky = k.reshape(1, n, 1, 1), k.reshape(1, 1, n, 1)
+        lap = (kx ** 2 + ky ** 2).clone()
+        lap[0, 0, 0, 0] = 1.0
+        w_h = torch.fft.fft2(u, dim=[1, 2])
+        psi = w_h / lap
+        back = lambda sp: torch.fft.irfft2(sp[:, :, :n // 2 + 1], dim=[1, 2])
+        ux, uy = back(1j * ky * psi), back(-1j * kx * psi)
+        wx, wy, wlap = back(1j * kx * w_h), back(1j * ky * w_h), back(-lap * w_h)
+        dt = t_interval / (nt - 1)
+        du = (u[..., 2:] - u[..., :-2]) / (2 * dt) + (ux * wx + uy * wy - visc.reshape(B, 1, 1, 1) * wlap)[..., 1:-1]
+        rel = lambda a, b: torch.mean(torch.norm((a - b).reshape(B, -1), 2, 1) / torch.norm(b.reshape(B, -1), 2, 1))
+        return rel(u[..., 0], u0), rel(du, f.repeat(B, 1, 1, nt - 2))
 dev = torch.device("cuda", 0)
 def timeit(fn, n=20, w=3):
     for _ in range(w): fn()

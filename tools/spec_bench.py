@@ -5,7 +5,44 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pde_policylearning_amd import functional as F
-from oracle import fno_oracle as O     # torch ops; used here as the "reference op sequence on GPU" timing leg
+
+
+# The op sequence the reference executes (torch.fft + einsum), restated here for the timing comparison only
+# (neuralop/models/rno.py:60-77, libs/models/pino_models/basics.py:79-96, 114-143).
+class O:
+    @staticmethod
+    def _mul(a, w):
+        return torch.einsum("bi...,io...->bo...", a, w)
+
+    @staticmethod
+    def spectral_conv_B(x, w0, w1, m1, m2):
+        B, _, n, _ = x.shape
+        xf = torch.fft.rfft2(x, s=(n, n), norm="ortho")
+        out = torch.zeros(B, w0.shape[1], n, n // 2 + 1, dtype=xf.dtype, device=x.device)
+        out[:, :, :m1, :m2] = O._mul(xf[:, :, :m1, :m2], torch.view_as_complex(w0))
+        out[:, :, -m1:, :m2] = O._mul(xf[:, :, -m1:, :m2], torch.view_as_complex(w1))
+        return torch.fft.irfft2(out, s=(n, n), norm="ortho")
+
+    @staticmethod
+    def spectral_conv_C2d(x, w1, w2, m1, m2):
+        B = x.shape[0]
+        xf = torch.fft.rfftn(x, dim=[2, 3])
+        out = torch.zeros(B, w1.shape[1], x.size(-2), x.size(-1) // 2 + 1, dtype=torch.cfloat, device=x.device)
+        out[:, :, :m1, :m2] = O._mul(xf[:, :, :m1, :m2], w1)
+        out[:, :, -m1:, :m2] = O._mul(xf[:, :, -m1:, :m2], w2)
+        return torch.fft.irfftn(out, s=(x.size(-2), x.size(-1)), dim=[2, 3])
+
+    @staticmethod
+    def spectral_conv_C3d(x, w1, w2, w3, w4, m1, m2, m3):
+        B = x.shape[0]
+        xf = torch.fft.rfftn(x, dim=[2, 3, 4])
+        z = xf.shape[-1]
+        k3 = min(z, m3)
+        out = torch.zeros(B, w1.shape[1], x.size(2), x.size(3), m3, dtype=torch.cfloat, device=x.device)
+        for sl, w in ((((slice(None, m1)), slice(None, m2)), w1), ((slice(-m1, None), slice(None, m2)), w2),
+                      ((slice(None, m1), slice(-m2, None)), w3), ((slice(-m1, None), slice(-m2, None)), w4)):
+            out[:, :, sl[0], sl[1], :k3] = O._mul(xf[:, :, sl[0], sl[1], :k3], w[..., :k3])
+        return torch.fft.irfftn(out, s=(x.size(2), x.size(3), x.size(4)), dim=[2, 3, 4])
 
 dev = torch.device("cuda", 0)
 
