@@ -560,6 +560,10 @@ static const int kHID = 256;
 #ifndef FNO_GRID_PW
 #define FNO_GRID_PW 2
 #endif
+#ifndef FNO_GRID_BWD
+#define FNO_GRID_BWD 1   // persistent workgroups per CU of the backward kernels: their LDS footprint allows one resident
+                         // workgroup, and every extra one adds a partial slab to reduce
+#endif
 #ifndef FNO_BBWD_X3
 #define FNO_BBWD_X3 1
 #endif
@@ -630,7 +634,7 @@ static ModelSizes model_sizes(const FnoModelPlan* p, int B) {
   s.n_wp = (size_t)g.Ktot * C * C * 2;
   s.tiles_per_plane = g.PW / p->NPX;
   s.ntiles = B * s.tiles_per_plane;
-  s.grid = std::min(s.ntiles, 2 * p->ncu);
+  s.grid = std::min(s.ntiles, FNO_GRID_BWD * p->ncu);
   return s;
 }
 
