@@ -1219,7 +1219,7 @@ extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, c
   FnoModelPlan p = pw_shell(C);
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (int)(PW / 128), ntiles = B * tiles;
-  const int grid = std::min(ntiles, 2 * p.ncu);
+  const int grid = std::min(ntiles, FNO_GRID_BWD * p.ncu);
   const int ks = bbwd_ksplit(&p);
   Carver c(ws, ws_bytes);
   float* dw_part = c.take<float>((size_t)grid * ks * C * C);
