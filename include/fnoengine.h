@@ -222,6 +222,20 @@ int fno_pointwise_forward(int batch, int channels, size_t plane, const float* x,
 int fno_pointwise_backward(int batch, int channels, size_t plane, const float* x, const float* w, const float* dy,
                            float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Projection head on its own:  y = W2 gelu(W1 x + b1) + b2, x (B, C, PW), C in {32, 64}, hidden 128 or 256,
+ * Cout = 1, PW % 128 == 0: the `fc1 -> act -> fc2` tail of the observer models
+ * (libs/models/pino_models/pinobserver.py:231-233, 270-273; neuralop/models/tfno.py:23-38), with the FNO
+ * projection kernels (hidden tensor never materialised; backward recomputes it).  w1 (hidden, C), w2 (1, hidden).
+ * backward writes dx and all four parameter gradients.  Needs the split-precision GEMM mode (default).
+ * ---------------------------------------------------------------------- */
+size_t fno_projection_workspace_bytes(int channels, int hidden);
+int fno_projection_forward(int batch, int channels, int hidden, int cout, size_t plane, const float* x, const float* w1,
+                           const float* b1, const float* w2, const float* b2, float* y, void* stream);
+int fno_projection_backward(int batch, int channels, int hidden, int cout, size_t plane, const float* x,
+                            const float* w1, const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
+                            float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

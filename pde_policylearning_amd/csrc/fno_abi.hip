@@ -1235,3 +1235,87 @@ extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, c
   if (dbias) jobs.add(db_part, dbias, grid, 1, C, C, C);
   return jobs.run(st);
 }
+
+// ===========================================================================
+// Projection head on its own:  y = W2 gelu(W1 x + b1) + b2  (x (B, C, PW), hidden 128 or 256, one output channel).
+// The observer models end in exactly this MLP (libs/models/pino_models/pinobserver.py:231-233, 270-273:
+// fc1 -> act -> fc2), applied there on channels-last tensors through nn.Linear; the kernels are the FNO
+// projection kernels (hidden tensor kept in MFMA accumulators, backward recomputes it).
+// ===========================================================================
+struct ProjWs { unsigned short *wa1, *wa3; float *dw1_part, *db1_part, *dw2_part, *db2_part; size_t total; bool ok; };
+static ProjWs carve_proj(int C, int HID, void* ws, size_t ws_bytes) {
+  Carver c(ws, ws_bytes);
+  const int grid = FNO_GRID_BWD * dev_ncu();
+  ProjWs w;
+  w.wa1 = c.take<unsigned short>((size_t)(HID / 32) * (C / 16) * 3 * 64 * 8);
+  w.wa3 = c.take<unsigned short>((size_t)(HID / 32) * 2 * (C / 32) * 3 * 64 * 8);
+  w.dw1_part = c.take<float>((size_t)grid * HID * C);
+  w.db1_part = c.take<float>((size_t)grid * 4 * HID);
+  w.dw2_part = c.take<float>((size_t)grid * 4 * HID);
+  w.db2_part = c.take<float>(64);
+  w.total = c.off;
+  w.ok = c.ok;
+  return w;
+}
+static int proj_check(int B, int C, int HID, int CO, size_t PW) {
+  LAUNCHCHK(pw_check(B, C, PW));
+  if (HID != 128 && HID != 256) return fail(FNO_EUNSUPPORTED, "projection: hidden width 128 or 256 (got %d)", HID);
+  if (CO != 1) return fail(FNO_EUNSUPPORTED, "projection: one output channel (got %d)", CO);
+  if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "projection entry points need the split-precision GEMM mode");
+  return FNO_OK;
+}
+extern "C" size_t fno_projection_workspace_bytes(int C, int hidden) {
+  if ((C != 32 && C != 64) || (hidden != 128 && hidden != 256)) return 0;
+  return carve_proj(C, hidden, nullptr, 0).total;
+}
+template <int C, int HID>
+static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
+  const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(HID / 32) * (C / 16) * 3 * 64 * 16 + (size_t)(HID + HID + 128) * 4;
+  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, 1>, dim3(grid), dim3(512), lds, st, a);
+}
+template <int C, int HID>
+static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
+  const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
+  return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1>, dim3(grid), dim3(512), lds, st, a);
+}
+extern "C" int fno_projection_forward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                      const float* b1, const float* w2, const float* b2, float* y, void* stream) {
+  LAUNCHCHK(proj_check(B, C, hidden, Cout, PW));
+  if (!x || !w1 || !b1 || !w2 || !b2 || !y) return fail(FNO_EINVAL, "fno_projection_forward: null argument");
+  ProjFwdArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.x = x; pa.w1 = w1; pa.b1 = b1; pa.w2 = w2; pa.b2 = b2; pa.y = y; pa.PW = (int)PW; pa.CO = 1;
+  pa.tiles_per_plane = (int)(PW / 128); pa.ntiles = B * pa.tiles_per_plane;
+  const int grid = std::min(pa.ntiles, FNO_GRID_PF * dev_ncu());
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 32) return hidden == 128 ? proj_fwd_launch<32, 128>(st, grid, pa) : proj_fwd_launch<32, 256>(st, grid, pa);
+  return hidden == 128 ? proj_fwd_launch<64, 128>(st, grid, pa) : proj_fwd_launch<64, 256>(st, grid, pa);
+}
+extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                       const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
+                                       float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream) {
+  LAUNCHCHK(proj_check(B, C, hidden, Cout, PW));
+  if (!x || !w1 || !b1 || !w2 || !dy || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws)
+    return fail(FNO_EINVAL, "fno_projection_backward: null argument");
+  ProjWs w = carve_proj(C, hidden, ws, ws_bytes);
+  if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int nitems = (hidden / 32) * (C / 16) * 64 + (hidden / 32) * 2 * (C / 32) * 64;
+  LAUNCHCHK(launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, w.wa1, w.wa3, hidden, C));
+  ProjBwdArgs pb;
+  memset(&pb, 0, sizeof(pb));
+  pb.x = x; pb.dy = dy; pb.w1 = w1; pb.b1 = b1; pb.w2 = w2; pb.gout = dx; pb.wa1 = w.wa1; pb.wa3 = w.wa3;
+  pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;
+  pb.PW = (int)PW; pb.W = 128; pb.P = (int)(PW / 128); pb.CO = 1;
+  pb.tiles_per_plane = (int)(PW / 128); pb.ntiles = B * pb.tiles_per_plane;
+  const int grid = std::min(pb.ntiles, FNO_GRID_BWD * dev_ncu());
+  if (C == 32) LAUNCHCHK((hidden == 128 ? proj_bwd_launch<32, 128>(st, grid, pb) : proj_bwd_launch<32, 256>(st, grid, pb)));
+  else LAUNCHCHK((hidden == 128 ? proj_bwd_launch<64, 128>(st, grid, pb) : proj_bwd_launch<64, 256>(st, grid, pb)));
+  LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, 1), dim3(256), 0, st, dy, w.db2_part, B, 1, (int)PW));
+  JobList jobs;
+  jobs.add(w.dw1_part, dw1, grid, hidden, C, C, C);
+  jobs.add(w.db1_part, db1, grid * 4, 1, hidden, hidden, hidden);
+  jobs.add(w.dw2_part, dw2, grid * 4, 1, hidden, hidden, hidden);
+  jobs.add(w.db2_part, db2, 64, 1, 1, 1, 1);
+  return jobs.run(st);
+}

@@ -575,3 +575,51 @@ def pointwise_conv_add(x, w, bias=None, addend=None):
     """y = conv1x1(x; w) + bias + addend  (x, addend (B, C, ...), w (C, C[, 1..]), C in {32, 64}) in one engine
     kernel each way; the gradient of `addend` is the incoming gradient itself."""
     return _PointwiseAddFn.apply(x, w, bias, addend)
+
+
+# ----------------------------------------------------------------------------
+# projection head  y = W2 gelu(W1 x + b1) + b2  on (B, C, ...) tensors
+# ----------------------------------------------------------------------------
+def projection_supported(x, hidden, cout):
+    return pointwise_supported(x) and hidden in (128, 256) and cout == 1 and _lib.lib().fno_get_gemm_mode() == 1
+
+
+class _ProjectionHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        pw = x.numel() // (B * Cc)
+        hid = w1.shape[0]
+        w1c, b1c = w1.reshape(hid, Cc).contiguous(), b1.contiguous()
+        w2c, b2c = w2.reshape(1, hid).contiguous(), b2.contiguous()
+        y = torch.empty((B, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().fno_projection_forward(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(b2c),
+                                                         _ptr(y), _stream()), "projection_forward")
+        ctx.save_for_backward(x, w1c, b1c, w2c)
+        ctx.meta = (B, Cc, hid, pw, w1.shape, w2.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1c, b1c, w2c = ctx.saved_tensors
+        B, Cc, hid, pw, w1shape, w2shape = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw1, db1, dw2 = torch.empty_like(w1c), torch.empty_like(b1c), torch.empty_like(w2c)
+        db2 = torch.empty(1, dtype=torch.float32, device=x.device)
+        nws = L.fno_projection_workspace_bytes(Cc, hid)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_projection_backward(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(dy), _ptr(dx),
+                                                 _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nws, _stream()),
+                       "projection_backward")
+        return dx, dw1.view(w1shape), db1, dw2.view(w2shape), db2
+
+
+def projection_head(x, w1, b1, w2, b2):
+    """(B, C, ...) -> (B, 1, ...): fc2(gelu(fc1(x))) with fc1.weight (hidden, C), fc2.weight (1, hidden)."""
+    return _ProjectionHeadFn.apply(x, w1, b1, w2, b2)

@@ -105,9 +105,16 @@ class PINObserver2d(_SpectralStack):
         size_z = x.shape[-2]
         num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
         x = self.multiplicative_net1(self.fc0(x), re).permute(0, 4, 1, 2, 3)
-        x = self._run_stack(_pad_last(x, num_pad).contiguous())
-        x = _unpad_last(x, num_pad).permute(0, 2, 3, 4, 1)
-        x = self.multiplicative_net2(x, re)
+        x = _unpad_last(self._run_stack(_pad_last(x, num_pad).contiguous()), num_pad)
+        if (self.act is TF.gelu and self.layers[-1] in (32, 64)
+                and F.projection_supported(x, self.fc1.out_features, self.fc2.out_features)):
+            # channels-first tail on the engine: the Re-conditioning affine as a pointwise mix, then the projection kernels
+            mn = self.multiplicative_net2
+            code = (re if re.dim() >= 2 else re.unsqueeze(-1)) @ mn.A.t()                     # (B, C)
+            h = F.pointwise_conv_add(x.contiguous(), mn.B, mn.bias, None) + code[:, :, None, None, None]
+            y = F.projection_head(h, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            return y.permute(0, 2, 3, 4, 1)
+        x = self.multiplicative_net2(x.permute(0, 2, 3, 4, 1), re)
         return self.fc2(self.act(self.fc1(x)))
 
 

@@ -706,3 +706,58 @@ def test_pointwise_conv_add_vs_torch(dev, C, shape):
     ye.backward(dy.to(dev))
     for a, b in zip(eng, ref):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_COMP, tuple(a.shape)
+
+
+@pytest.mark.parametrize("C,hid,shape", [(64, 128, (2, 64, 8, 16, 65)), (32, 256, (1, 32, 16, 24))])
+def test_projection_head_vs_torch(dev, C, hid, shape):
+    """fno_projection_* (fc1 -> gelu -> fc2, pinobserver.py:231-233) vs the torch ops in fp64-free fp32 on CPU."""
+    from pde_policylearning_amd import functional as F
+    x = torch.from_numpy(fill_named("phx", shape, 1.0))
+    w1 = torch.from_numpy(fill_named("phw1", (hid, C), 0.15))
+    b1 = torch.from_numpy(fill_named("phb1", (hid,), 0.1))
+    w2 = torch.from_numpy(fill_named("phw2", (1, hid), 0.1))
+    b2 = torch.from_numpy(fill_named("phb2", (1,), 0.1))
+    dy = torch.from_numpy(fill_named("phd", (shape[0], 1) + shape[2:], 1.0))
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xr = ref[0].movedim(1, -1)                                                   # channels-last as the reference applies it
+    yr = (torch.nn.functional.gelu(xr @ ref[1].t() + ref[2]) @ ref[3].t() + ref[4]).movedim(-1, 1)
+    yr.backward(dy)
+    eng = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ye = F.projection_head(*eng)
+    assert rel_l2(_cpu(ye), yr.detach().numpy()) < TOL_Y
+    ye.backward(dy.to(dev))
+    for a, b in zip(eng, ref):
+        assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, tuple(a.shape)
+
+
+def test_pinobserver2d_engine_tail_matches_torch_tail(dev):
+    """PINObserver2d at the shipped width (64 channels, fc_dim 128): the channels-first engine tail (pointwise mix + projection
+    kernels) and the engine pointwise layers must agree with the torch composition they replace (pinobserver.py:221-233)."""
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.libs.models.pino_models import PINObserver2d
+    torch.manual_seed(6)
+    model = PINObserver2d(modes1=[4] * 4, modes2=[4] * 4, modes3=[4] * 4, fc_dim=128, layers=[64] * 5, in_dim=4, out_dim=1,
+                          act="gelu", pad_ratio=[0.0, 0.125]).to(dev)
+    x = torch.randn(2, 16, 16, 16, 4, device=dev)          # T = 16 -> padded to 18: odd tiling for the spectral rows
+    re = torch.tensor([[180.0], [395.0]], device=dev)
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        y = model(x, re)
+        y.square().sum().backward()
+        return [y.detach().clone()] + [torch.view_as_real(p.grad).clone() if p.grad.is_complex() else p.grad.clone()
+                                       for p in model.parameters()]
+    a = run()
+    orig = (F.projection_supported, F.pointwise_supported)
+    F.projection_supported = lambda *args, **kw: False
+    F.pointwise_supported = lambda *args, **kw: False
+    try:
+        b = run()
+    finally:
+        F.projection_supported, F.pointwise_supported = orig
+    assert rel_l2(_cpu(a[0]), _cpu(b[0])) < TOL_Y
+    for (name, _), u, v in zip(model.named_parameters(), a[1:], b[1:]):
+        # wiring check between two fp32 evaluations (the kernels themselves are held to 5e-6 / 1e-4 against torch above).  The
+        # spectral weights' gradients are ~1e-8 of the others here (init scale 1/(64*64)) and carry the rounding noise of both.
+        tol = 2e-2 if "sp_convs" in name else 5e-4
+        assert rel_l2(_cpu(u), _cpu(v)) < tol, name
