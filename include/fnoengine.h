@@ -236,6 +236,18 @@ int fno_projection_backward(int batch, int channels, int hidden, int cout, size_
                             const float* w1, const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
                             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Lifting layer on its own:  y = W x + b,  x (B, Cin <= 4, PW) -> y (B, C, PW), C in {32, 64}, PW % 128 == 0
+ * (neuralop/models/tfno.py:11-20; also the `fc0` + Re-conditioning front of the PINO observers,
+ * libs/models/pino_models/pinobserver.py:205-207, once its two linear maps are composed).  backward gives the
+ * parameter gradients only (x is data).
+ * ---------------------------------------------------------------------- */
+size_t fno_lifting_workspace_bytes(int channels);
+int fno_lifting_forward(int batch, int cin, int channels, size_t plane, const float* x, const float* w, const float* bias,
+                        float* y, void* stream);
+int fno_lifting_backward(int batch, int cin, int channels, size_t plane, const float* x, const float* dy, float* dw,
+                         float* dbias, void* ws, size_t ws_bytes, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

@@ -1319,3 +1319,45 @@ extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_
   jobs.add(w.db2_part, db2, 64, 1, 1, 1, 1);
   return jobs.run(st);
 }
+
+// ===========================================================================
+// Lifting layer on its own:  y = W x + b,  x (B, Cin <= 4, PW) -> y (B, C, PW), and its parameter gradients.
+// (neuralop/models/tfno.py:11-20; the composed fc0 + Re-conditioning front of the PINO observers.)
+// ===========================================================================
+static int lift_check(int B, int Cin, int C, size_t PW) {
+  LAUNCHCHK(pw_check(B, C, PW));
+  if (Cin < 1 || Cin > 4) return fail(FNO_EUNSUPPORTED, "lifting: 1..4 input channels (got %d)", Cin);
+  return FNO_OK;
+}
+extern "C" size_t fno_lifting_workspace_bytes(int C) { return (size_t)3 * dev_ncu() * C * 16 * sizeof(float) + 256; }
+extern "C" int fno_lifting_forward(int B, int Cin, int C, size_t PW, const float* x, const float* w, const float* bias,
+                                   float* y, void* stream) {
+  LAUNCHCHK(lift_check(B, Cin, C, PW));
+  if (!x || !w || !y) return fail(FNO_EINVAL, "fno_lifting_forward: null argument");
+  FnoModelPlan p = pw_shell(C);
+  p.d.Cin = Cin;
+  PwFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.bias = bias; a.u = y;
+  a.PW = (int)PW; a.W = 128; a.P = (int)(PW / 128);
+  a.tiles_per_plane = (int)(PW / 128); a.ntiles = B * a.tiles_per_plane;
+  return launch_lift(&p, (hipStream_t)stream, std::min(a.ntiles, FNO_GRID_LIFT * p.ncu), a);
+}
+extern "C" int fno_lifting_backward(int B, int Cin, int C, size_t PW, const float* x, const float* dy, float* dw,
+                                    float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  LAUNCHCHK(lift_check(B, Cin, C, PW));
+  if (!x || !dy || !dw || !ws) return fail(FNO_EINVAL, "fno_lifting_backward: null argument");
+  if (ws_bytes < fno_lifting_workspace_bytes(C)) return fail(FNO_ENOMEM, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  LiftBwdArgs a;
+  a.dy = dy; a.xin = x; a.dwl_part = (float*)ws; a.CL = Cin; a.PW = (int)PW;
+  a.tiles_per_plane = (int)(PW / 128); a.ntiles = B * a.tiles_per_plane;
+  const int grid = std::min(a.ntiles, 3 * dev_ncu());
+  const size_t lds = ((size_t)C * 132 + 8 * 132) * 4;
+  if (C == 32) LAUNCHCHK(launch("k_lift_bwd", k_lift_bwd<32, 128>, dim3(grid), dim3(256), lds, st, a));
+  else LAUNCHCHK(launch("k_lift_bwd", k_lift_bwd<64, 128>, dim3(grid), dim3(256), lds, st, a));
+  JobList jobs;
+  jobs.add(a.dwl_part, dw, grid, C, Cin, 16, Cin);
+  if (dbias) jobs.add(a.dwl_part + Cin, dbias, grid, C, 1, 16, 1);
+  return jobs.run(st);
+}

@@ -518,6 +518,57 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   }
 }
 
+// ---------------------------------------------------------------------------
+// Gradients of a lifting layer on its own (y = W x + b, x (B, CL <= 4, PW) -> y (B, C, PW); tfno.py:11-20,
+// and the composed `fc0` + Re-conditioning front of the PINO observers, pinobserver.py:205-207):
+//   dW[c][i] = sum_{b,px} dy[c][px] x[i][px],  db[c] = sum dy[c][px]      (no input gradient: x is data)
+// Same MFMA 16x16x4 scheme as the block-0 epilogue of k_block_bwd: B operand = [x rows | ones | 0..].
+struct LiftBwdArgs {
+  const float* dy;       // (B, C, PW)
+  const float* xin;      // (B, CL, PW)
+  float* dwl_part;       // (gridDim, C, 16): col i < CL = dW, col CL = db
+  int CL, PW, tiles_per_plane, ntiles;
+};
+template <int C, int NPX>
+__global__ void __launch_bounds__(256) k_lift_bwd(LiftBwdArgs a) {
+  constexpr int NW = 4, NT = NW * 64, PITCH = NPX + 4;
+  static_assert(C / 16 <= NW, "one 16-channel job per wave");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gs = smem;                 // C x PITCH
+  float* xls = gs + C * PITCH;      // 8 x PITCH
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f};
+  TilePrefetch<NPX, NT, C, C> pf;
+  auto issue = [&](int tile) {
+    pf.issue(a.dy + (size_t)(tile / a.tiles_per_plane) * C * a.PW + (tile % a.tiles_per_plane) * NPX, a.PW, tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    pf.commit(gs, false, tid);
+    stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    if (wave < C / 16) {
+      const float* ar = gs + (wave * 16 + l15) * PITCH + quad;
+      const float* br = xls + (l15 < a.CL ? l15 : 0) * PITCH + quad;
+      const float cst = l15 == a.CL ? 1.0f : 0.0f;
+#pragma unroll 8
+      for (int s = 0; s < NPX / 4; ++s) {
+        const float bf = (l15 < a.CL) ? br[4 * s] : cst;
+        dl = mfma16(ar[4 * s], bf, dl);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave < C / 16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.dwl_part[((size_t)blockIdx.x * C + wave * 16 + quad * 4 + r) * 16 + l15] = dl[r];
+  }
+}
+
 // out[row][col] = sum_s part[s][row][col]: deterministic two-level slab reduction.
 // block = (64 elements, 16 slab lanes); element e = (row, col), col < ncols.
 __global__ void __launch_bounds__(1024) k_reduce_slabs(const float* __restrict__ part, float* __restrict__ out,

@@ -623,3 +623,56 @@ class _ProjectionHeadFn(torch.autograd.Function):
 def projection_head(x, w1, b1, w2, b2):
     """(B, C, ...) -> (B, 1, ...): fc2(gelu(fc1(x))) with fc1.weight (hidden, C), fc2.weight (1, hidden)."""
     return _ProjectionHeadFn.apply(x, w1, b1, w2, b2)
+
+
+# ----------------------------------------------------------------------------
+# lifting layer  y = W x + b,  (B, Cin <= 4, ...) -> (B, C, ...)
+# ----------------------------------------------------------------------------
+def lifting_supported(x, c_out):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and 1 <= x.shape[1] <= 4 and c_out in (32, 64)):
+        return False
+    pw = 1
+    for s in x.shape[2:]:
+        pw *= s
+    return pw % 128 == 0
+
+
+class _LiftingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_cuda(x, "x")
+        if x.requires_grad:
+            raise RuntimeError("fnoengine lifting: the input field is data (no gradient is produced for it)")
+        x = x.contiguous()
+        B, cin = x.shape[0], x.shape[1]
+        cout = w.shape[0]
+        pw = x.numel() // (B * cin)
+        wc = w.reshape(cout, cin).contiguous()
+        bc = bias.contiguous() if bias is not None else None
+        y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().fno_lifting_forward(B, cin, cout, pw, _ptr(x), _ptr(wc), _ptr(bc), _ptr(y), _stream()),
+                       "lifting_forward")
+        ctx.save_for_backward(x)
+        ctx.meta = (B, cin, cout, pw, w.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, cin, cout, pw, wshape, has_b = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_b else None
+        nws = L.fno_lifting_workspace_bytes(cout)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_lifting_backward(B, cin, cout, pw, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), nws, _stream()),
+                       "lifting_backward")
+        return None, dw.view(wshape), db
+
+
+def lifting(x, w, bias=None):
+    """conv1x1 from <= 4 input channels: x (B, Cin, ...) data, w (C, Cin[, 1..]), bias (C)."""
+    return _LiftingFn.apply(x, w, bias)

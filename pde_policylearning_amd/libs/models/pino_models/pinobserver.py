@@ -52,6 +52,19 @@ class MultiplicativeNet(nn.Module):
         return input1 @ self.B.t() + code + self.bias
 
 
+def _lift_front(fc0, mn, x, re, width):
+    """multiplicative_net1(fc0(x), re) as a channels-first tensor (pinobserver.py:205-207, 356-358).  fc0 followed by the
+    Re-conditioning affine is ONE linear map of the <= 4 input channels: when the shape allows it the two small matrices are
+    composed (autograd differentiates the composition) and applied by the engine's lifting kernels."""
+    xc = x.permute(0, 4, 1, 2, 3)
+    if not x.requires_grad and F.lifting_supported(xc, width):
+        w = mn.B @ fc0.weight                                             # (C, in_dim)
+        bias = mn.B @ fc0.bias + mn.bias
+        code = (re if re.dim() >= 2 else re.unsqueeze(-1)) @ mn.A.t()     # (B, C)
+        return F.lifting(xc.contiguous(), w, bias) + code[:, :, None, None, None]
+    return mn(fc0(x), re).permute(0, 4, 1, 2, 3)
+
+
 class _SpectralStack(nn.Module):
     """layers of  x <- act(SpectralConv3d(x) + Conv1d_{k=1}(x)), no activation after the last."""
 
@@ -104,7 +117,7 @@ class PINObserver2d(_SpectralStack):
         re = re.float()
         size_z = x.shape[-2]
         num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
-        x = self.multiplicative_net1(self.fc0(x), re).permute(0, 4, 1, 2, 3)
+        x = _lift_front(self.fc0, self.multiplicative_net1, x, re, self.layers[0])
         x = _unpad_last(self._run_stack(_pad_last(x, num_pad).contiguous()), num_pad)
         if (self.act is TF.gelu and self.layers[-1] in (32, 64)
                 and F.projection_supported(x, self.fc1.out_features, self.fc2.out_features)):
@@ -153,6 +166,6 @@ class PINObserverFullField(nn.Module):
         re = re.float() / self.max_re
         size_z = x.shape[-2]                  # the reference takes the pad size from dim -2 (:353)
         num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
-        x = self.multiplicative_net1(self.fc0(x), re).permute(0, 4, 1, 2, 3)
+        x = _lift_front(self.fc0, self.multiplicative_net1, x, re, self.layers[0])
         pred = self.observer_head(_pad_last(x, num_pad).contiguous(), num_pad, re, self.multiplicative_net2)
         return pred.permute(0, 4, 1, 2, 3)     # (B, planes, X, Y, T)

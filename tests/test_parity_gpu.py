@@ -748,16 +748,36 @@ def test_pinobserver2d_engine_tail_matches_torch_tail(dev):
         return [y.detach().clone()] + [torch.view_as_real(p.grad).clone() if p.grad.is_complex() else p.grad.clone()
                                        for p in model.parameters()]
     a = run()
-    orig = (F.projection_supported, F.pointwise_supported)
+    orig = (F.projection_supported, F.pointwise_supported, F.lifting_supported)
     F.projection_supported = lambda *args, **kw: False
     F.pointwise_supported = lambda *args, **kw: False
+    F.lifting_supported = lambda *args, **kw: False
     try:
         b = run()
     finally:
-        F.projection_supported, F.pointwise_supported = orig
+        F.projection_supported, F.pointwise_supported, F.lifting_supported = orig
     assert rel_l2(_cpu(a[0]), _cpu(b[0])) < TOL_Y
     for (name, _), u, v in zip(model.named_parameters(), a[1:], b[1:]):
         # wiring check between two fp32 evaluations (the kernels themselves are held to 5e-6 / 1e-4 against torch above).  The
         # spectral weights' gradients are ~1e-8 of the others here (init scale 1/(64*64)) and carry the rounding noise of both.
         tol = 2e-2 if "sp_convs" in name else 5e-4
         assert rel_l2(_cpu(u), _cpu(v)) < tol, name
+
+
+@pytest.mark.parametrize("cin,C,shape", [(4, 64, (2, 4, 8, 16, 65)), (1, 32, (3, 1, 16, 32))])
+def test_lifting_layer_vs_torch(dev, cin, C, shape):
+    """fno_lifting_* vs conv1x1 in torch (value, dW, db)."""
+    from pde_policylearning_amd import functional as F
+    x = torch.from_numpy(fill_named("lfx", shape, 1.0))
+    w = torch.from_numpy(fill_named("lfw", (C, cin), 0.3))
+    b = torch.from_numpy(fill_named("lfb", (C,), 0.1))
+    dy = torch.from_numpy(fill_named("lfd", (shape[0], C) + shape[2:], 1.0))
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.einsum("oi,bi...->bo...", wr, x) + br.view(1, C, *([1] * (len(shape) - 2)))
+    yr.backward(dy)
+    we, be = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    ye = F.lifting(x.to(dev), we, be)
+    assert rel_l2(_cpu(ye), yr.detach().numpy()) < TOL_COMP
+    ye.backward(dy.to(dev))
+    assert rel_l2(_cpu(we.grad), wr.grad.numpy()) < TOL_COMP
+    assert rel_l2(_cpu(be.grad), br.grad.numpy()) < TOL_COMP
