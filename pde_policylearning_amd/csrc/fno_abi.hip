@@ -487,8 +487,18 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, 
   auto need = [&](int r) { return (((size_t)2 * g.Klast * g.W + 1) & ~(size_t)1) * 4 + (size_t)r * g.Klast * C * 8; };
   while (rb > 1 && need(rb) > 64 * 1024) rb >>= 1;
   if (need(rb) > 160 * 1024) return fail(FNO_EUNSUPPORTED, "row spectra of %d channels x %d bins exceed LDS", C, g.Klast);
-  return launch("k_rowidft_generic", k_rowidft_generic, dim3(B * ((g.P + rb - 1) / rb)), dim3(256), need(rb), st,
-                (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast, rb);
+  const dim3 grid(B * ((g.P + rb - 1) / rb));
+  if (g.Klast <= 8)
+    return launch("k_rowidft_generic", k_rowidft_generic<8>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
+                  C, g.P, g.W, g.Klast, rb);
+  if (g.Klast <= 16)
+    return launch("k_rowidft_generic", k_rowidft_generic<16>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
+                  C, g.P, g.W, g.Klast, rb);
+  if (g.Klast <= 32)
+    return launch("k_rowidft_generic", k_rowidft_generic<32>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
+                  C, g.P, g.W, g.Klast, rb);
+  return launch("k_rowidft_generic", k_rowidft_generic<0>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias, C,
+                g.P, g.W, g.Klast, rb);
 }
 
 extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, const float* const* wc, const float* bias,

@@ -397,25 +397,40 @@ __global__ void __launch_bounds__(256) k_rowdft_generic(const float* __restrict_
   const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
   const int nr = min(RB, P - p0);
   const int pitch = RB * W + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < W * 2 * K2E; i += blockDim.x) {
     const int w = i / (2 * K2E), j = i % (2 * K2E);
     tab[i] = j < 2 * K2 ? tfwd[(size_t)j * W + w] : 0.f;
   }
+  // staging: a wave owns channels wave, wave + 4, ...; lanes run along the nr*W contiguous floats of a channel.
+  // Four channels (up to 4 x ceil(seg/64) loads per lane) are in flight before the first LDS write; no divisions.
   const int seg = nr * W;
   const size_t cstride = (size_t)P * W;
   const float* xb = x + ((size_t)b * C * P + p0) * W;
-  for (int base = threadIdx.x; base < C * seg; base += 8 * blockDim.x) {    // eight loads in flight per thread
-    float v[8];
+  for (int c0 = wave; c0 < C; c0 += 16) {
+    float v[4][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int idx = base + j * blockDim.x;
-      v[j] = idx < C * seg ? xb[(size_t)(idx / seg) * cstride + idx % seg] : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + 4 * k;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = lane + 64 * j;
+        v[k][j] = (c < C && o < seg) ? xb[(size_t)c * cstride + o] : 0.f;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int idx = base + j * blockDim.x;
-      if (idx < C * seg) xs[(idx / seg) * pitch + idx % seg] = v[j];
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + 4 * k;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = lane + 64 * j;
+        if (c < C && o < seg) xs[c * pitch + o] = v[k][j];
+      }
     }
+    for (int o = lane + 256; o < seg; o += 64)        // rows longer than 256 floats in total: plain tail
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c0 + 4 * k < C) xs[(c0 + 4 * k) * pitch + o] = xb[(size_t)(c0 + 4 * k) * cstride + o];
   }
   __syncthreads();
   // item = (row r, bin pair kp, channel c): two bins = 4 accumulators, channel fastest (lanes <-> channels)
@@ -425,6 +440,7 @@ __global__ void __launch_bounds__(256) k_rowdft_generic(const float* __restrict_
     const float* xr = xs + c * pitch + r * W;
     const float* tp = tab + 4 * kp;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
     for (int w = 0; w < W; ++w) {
       const float v = xr[w];
       const float4 t = ld4(tp + w * 2 * K2E);       // wave-uniform address: LDS broadcast
@@ -438,6 +454,7 @@ __global__ void __launch_bounds__(256) k_rowdft_generic(const float* __restrict_
 
 // z (B, P, K2, C, 2) -> y (B, C, P, W) (+ bias[c]);  tinv (2*K2, W)
 //   LDS: table [2*K2][W] | spectra [RB][K2][C][2]
+template <int K2C>
 __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restrict__ z, float* __restrict__ y,
                                                          const float* __restrict__ tinv,
                                                          const float* __restrict__ bias, int C, int P, int W,
@@ -448,22 +465,53 @@ __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restric
   const int nblk = (P + RB - 1) / RB;
   const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
   const int nr = min(RB, P - p0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 2 * K2 * W; i += blockDim.x) tab[i] = tinv[i];
   const float2* zr = z + ((size_t)b * P + p0) * K2 * C;
   for (int i = threadIdx.x; i < nr * K2 * C; i += blockDim.x) zs[i] = zr[i];
   __syncthreads();
-  // element (c, r, w): lanes <-> consecutive w (coalesced stores, conflict-free table reads, broadcast spectra)
+  // a wave owns channels wave, wave + 4, ...; lanes run along the nr*W contiguous output floats of the channel
+  // (coalesced stores, conflict-free table reads, broadcast spectra); the row of an element comes from compares.
   const int seg = nr * W;
-  for (int idx = threadIdx.x; idx < C * seg; idx += blockDim.x) {
-    const int c = idx / seg, o = idx % seg, r = o / W, w = o % W;
-    float s = bias ? bias[c] : 0.f;
-    const float2* zc = zs + (size_t)r * K2 * C + c;
-    for (int k2 = 0; k2 < K2; ++k2) {
-      const float2 v = zc[k2 * C];
-      s = fmaf(v.x, tab[(2 * k2) * W + w], s);
-      s = fmaf(v.y, tab[(2 * k2 + 1) * W + w], s);
+  const size_t cstride = (size_t)P * W;
+  float* yb = y + ((size_t)b * C * P + p0) * W;
+  for (int o = lane; o < seg; o += 64) {
+    int r = 0;
+    for (int k = 1; k < nr; ++k) r += (o >= k * W);
+    const int w = o - r * W;
+    const float2* zrow = zs + (size_t)r * K2 * C;
+    if constexpr (K2C > 0) {
+      // this lane's table column stays in registers for all channels (K2 <= K2C bins, zero beyond K2)
+      float tr[K2C], ti[K2C];
+#pragma unroll
+      for (int k2 = 0; k2 < K2C; ++k2) {
+        tr[k2] = k2 < K2 ? tab[(2 * k2) * W + w] : 0.f;
+        ti[k2] = k2 < K2 ? tab[(2 * k2 + 1) * W + w] : 0.f;
+      }
+      for (int c = wave; c < C; c += 4) {
+        float s0 = bias ? bias[c] : 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < K2C; ++k2) {
+          // wave-uniform address: LDS broadcast; bins past K2 re-read the last one against a zero table entry (no branch)
+          const float2 v = zrow[(k2 < K2 ? k2 : K2 - 1) * C + c];
+          s0 = fmaf(v.x, tr[k2], s0);
+          s1 = fmaf(v.y, ti[k2], s1);
+        }
+        yb[(size_t)c * cstride + o] = s0 + s1;
+      }
+    } else {
+      // many kept bins (full-spectrum plans): table column from LDS
+      for (int c = wave; c < C; c += 4) {
+        float s0 = bias ? bias[c] : 0.f, s1 = 0.f;
+#pragma unroll 4
+        for (int k2 = 0; k2 < K2; ++k2) {
+          const float2 v = zrow[k2 * C + c];
+          s0 = fmaf(v.x, tab[(2 * k2) * W + w], s0);
+          s1 = fmaf(v.y, tab[(2 * k2 + 1) * W + w], s1);
+        }
+        yb[(size_t)c * cstride + o] = s0 + s1;
+      }
     }
-    y[(((size_t)b * C + c) * P + p0) * W + o] = s;
   }
 }
 
