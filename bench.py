@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--config", default="fno2d_128x128_w64_m12_b64", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: exchange all gradients in one all-reduce after the backward pass instead of starting "
+                         "the late layers' segment while the early layers are still being differentiated")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step once into a hipGraph and replay it (single GPU; pays off on the "
                          "launch-bound small configurations)")
@@ -81,7 +84,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # FNO_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, broadcast, overlapped all-reduce, barriers)
+    # with a single rank - a self-test of the N > 1 path on a one-GPU box
+    force_dist = os.environ.get("FNO_BENCH_FORCE_DIST") == "1" and world == 1
+    dist_on = world > 1 or force_dist
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus != world:
@@ -90,7 +101,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
 
     from pde_policylearning_amd import _lib
@@ -130,7 +141,13 @@ def main():
         with torch.no_grad():
             tgt = torch.randn(model(*inputs).shape, generator=gen).to(dev)
     broadcast_parameters(model)
-    bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
+    overlap = fused_model and dist_on and not args.no_overlap
+    if overlap:
+        # [projection | blocks L-1..1] go on the wire (async RCCL all-reduce) while block 0 and the lifting are differentiated
+        bucket = FlatGradBucket.for_fno(model, split_layer=1)
+        bucket.force_collective = force_dist
+    else:
+        bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
     opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
     if not fused_model:
@@ -141,7 +158,7 @@ def main():
 
     eager_step = step
     if args.graph:
-        if world > 1:
+        if dist_on:
             sys.exit("bench.py --graph is a single-GPU mode")
         from pde_policylearning_amd.trainer import GraphedTrainStep
         graphed = GraphedTrainStep(model, bucket, opt, inputs, tgt, loss_fn)
@@ -151,7 +168,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -163,7 +180,7 @@ def main():
         loss = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -277,15 +294,24 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
-                       "step": "zero_grad+fwd+LpLoss(sum)+bwd" + ("+allreduce(sum)" if world > 1 else "") + "+Adam",
+                       "step": "zero_grad+fwd+LpLoss(sum)+bwd" +
+                               ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,
         }
-        print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer: flush it first so that the JSON line
+        # is the last thing this rank writes
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -139,6 +139,13 @@ int fno_model_backward(const FnoModelPlan* plan, int batch, const FnoModelParams
 int fno_model_backward_dx(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
                           const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
                           size_t ws_bytes, void* stream);
+/* The same pass in parts: layers l_hi .. l_lo (descending; l_hi = n_layers-1 includes the projection, l_lo = 0 the
+ * lifting).  Calls over a partition of the layers with the SAME workspace reproduce the full pass bit for bit, and each
+ * call finishes the gradients of its own layers - a data-parallel caller starts the all-reduce of the late layers'
+ * gradients while the early layers are still being differentiated (trainer.FlatGradBucket.for_fno). */
+int fno_model_backward_part(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
+                            const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
+                            size_t ws_bytes, void* stream, int l_hi, int l_lo);
 
 /* ------------------------------------------------------------------------
  * Training-step tail (run_pde_observers.py:185-193), SURVEY.md section 8(f) rank 2.

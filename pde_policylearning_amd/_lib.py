@@ -108,6 +108,8 @@ def lib():
     L.fno_pino_loss_backward.argtypes = [ci, ci, ci, vp, vp, vp, vp, fl, vp, vp, vp, vp, sz, vp]
     L.fno_model_backward_dx.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp,
                                         C.POINTER(FnoModelGrads), vp, vp, sz, vp]
+    L.fno_model_backward_part.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp,
+                                          C.POINTER(FnoModelGrads), vp, vp, sz, vp, ci, ci]
     L.fno_profile_enable.argtypes = [ci]
     L.fno_profile_enable.restype = None
     L.fno_profile_reset.restype = None
@@ -128,7 +130,7 @@ EXPORTED_SYMBOLS = [
     "fno_spec_plan_create", "fno_spec_plan_destroy", "fno_spec_workspace_bytes", "fno_spec_xhat_bytes",
     "fno_spec_forward", "fno_spec_backward",
     "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",
-    "fno_model_forward", "fno_model_backward", "fno_model_backward_dx",
+    "fno_model_forward", "fno_model_backward", "fno_model_backward_dx", "fno_model_backward_part",
     "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
     "fno_pointwise_workspace_bytes", "fno_pointwise_forward", "fno_pointwise_backward",
     "fno_projection_workspace_bytes", "fno_projection_forward", "fno_projection_backward",

@@ -887,8 +887,19 @@ extern "C" int fno_model_backward(const FnoModelPlan* p, int B, const FnoModelPa
 extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
                                      const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
                                      size_t ws_bytes, void* stream) {
+  if (!p) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
+  return fno_model_backward_part(p, B, prm, x, dy, saved, gr, dx, ws, ws_bytes, stream, p->d.n_layers - 1, 0);
+}
+// Layers l_hi .. l_lo (descending) of the backward pass; l_hi == n_layers-1 includes the projection, l_lo == 0 the
+// lifting.  Consecutive calls over a partition of the layers with the SAME workspace reproduce the full pass bit for
+// bit (the running gradient and its row spectrum live in the workspace); every call finishes the gradients of its own
+// layers (slab reduction + weight unpack), so a data-parallel caller can start exchanging them while the rest runs.
+extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                                       const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
+                                       size_t ws_bytes, void* stream, int l_hi, int l_lo) {
   if (!p || !prm || !x || !dy || !saved || !gr || B < 1) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
   if (dx && p->d.Cin > 0) return fail(FNO_EUNSUPPORTED, "input gradient is produced for block stacks (Cin == 0) only");
+  if (l_lo < 0 || l_hi >= p->d.n_layers || l_lo > l_hi) return fail(FNO_EINVAL, "fno_model_backward_part: layers %d..%d", l_hi, l_lo);
   hipStream_t st = (hipStream_t)stream;
   const Geom& g = p->g;
   const FnoModelDesc& d = p->d;
@@ -906,7 +917,9 @@ extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoMode
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
-  if (!has_proj) {
+  if (l_hi < L - 1) {
+    // a later part: the running gradient and its row spectrum were left in the workspace by the previous call
+  } else if (!has_proj) {
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
   if (g_gemm_x3) {
@@ -933,8 +946,12 @@ extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoMode
   const float* gcur = has_proj ? w.ga : dy;   // dL/du_{l+1}
   float* gnext = has_proj ? w.gb : w.ga;
   float* gspare = has_proj ? w.ga : w.gb;
+  for (int l = L - 1; l > l_hi; --l) {        // replay the buffer rotation of the layers done by earlier parts
+    gcur = gnext;
+    float* t = gnext; gnext = gspare; gspare = t;
+  }
   const int ks = bbwd_ksplit(p);
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= l_lo; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
     float* dwp_l = w.dwp + (size_t)l * s.n_wp;
     float* dw_part_l = w.dw_part + (size_t)l * s.grid * ks * C * C;
@@ -970,14 +987,14 @@ extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoMode
   {
     CornerPtrsMutL cp;
     memset(&cp, 0, sizeof(cp));
-    for (int l = 0; l < L; ++l)
-      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (float2*)gr->spec_w[l][c];
+    for (int l = l_lo; l <= l_hi; ++l)
+      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l - l_lo][c] = (float2*)gr->spec_w[l][c];
     const ModeMap mm = make_modemap(g, C, C);
     size_t per = (size_t)g.modes[0] * g.wl_stride;
     if (g.nlead == 2) per *= g.modes[1];
     const size_t n = (size_t)(1 << g.nlead) * C * C * per;
-    LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st,
-                     (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C));
+    LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), l_hi - l_lo + 1), dim3(256),
+                     0, st, (const float2*)(w.dwp + (size_t)l_lo * s.n_wp), cp, mm, (size_t)g.Ktot * C * C));
   }
   return FNO_OK;
 }

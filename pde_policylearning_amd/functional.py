@@ -154,8 +154,9 @@ class _FNOModelFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *rest):
-        n_layers, modes, norm, gelu_mask, direct = cfg
+        n_layers, modes, norm, gelu_mask, direct, overlap = cfg
         ctx.direct = direct
+        ctx.overlap = overlap
         _require_cuda(x, "x")
         if x.requires_grad:
             raise RuntimeError("fnoengine fused FNO: gradient w.r.t. the input field is not produced "
@@ -218,16 +219,28 @@ class _FNOModelFn(torch.autograd.Function):
         _fill_params(grd, nl, nc, g[0], g[1], g_skip, g_spec, g_sb, g[2], g[3], g[4], g[5])
         nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
         ws = _bytes(nws, dy.device)
+        ov = ctx.overlap
         with torch.cuda.device(dy.device):
-            _lib.check(L.fno_model_backward(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
-                                            C.byref(grd), _ptr(ws), nws, _stream()), "model_backward")
+            if ov is not None and ctx.direct is not None and 0 < ov.split_layer < nl:
+                # late layers first; their finished gradients go on the wire while the early layers are differentiated
+                k = ov.split_layer
+                _lib.check(L.fno_model_backward_part(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                     C.byref(grd), None, _ptr(ws), nws, _stream(), nl - 1, k),
+                           "model_backward_part")
+                ov.late_gradients_ready()
+                _lib.check(L.fno_model_backward_part(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                     C.byref(grd), None, _ptr(ws), nws, _stream(), k - 1, 0),
+                           "model_backward_part")
+            else:
+                _lib.check(L.fno_model_backward(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                C.byref(grd), _ptr(ws), nws, _stream()), "model_backward")
         if ctx.direct is not None:
             return (None,) * (9 + len(skip_ws) + len(spec_ws))
         return (None, None, g[0], g[1], g_sb, g[2], g[3], g[4], g[5]) + tuple(g_skip) + tuple(g_spec)
 
 
 def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, modes, norm="forward",
-              gelu_mask=None, direct_grads=False):
+              gelu_mask=None, direct_grads=False, overlap=None):
     """Fused neuralop.models.FNO forward (default configuration).  `modes` = kept per
     corner per dim (n_modes // 2); `spec_ws` real-view corner weights, layer-major."""
     n_layers = len(skip_ws)
@@ -243,7 +256,7 @@ def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, mo
             direct = dict(lift_w=lift_w.grad, lift_b=lift_b.grad, w1=w1.grad, b1=b1.grad, w2=w2.grad, b2=b2.grad,
                           skip=[p.grad for p in skip_ws], spec=[p.grad for p in spec_ws],
                           spec_bias=spec_bias.grad if spec_bias is not None else None)
-    cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
+    cfg = (n_layers, tuple(int(m) for m in modes), norm, int(gelu_mask), direct, overlap if direct is not None else None)
     return _FNOModelFn.apply(cfg, x, lift_w, lift_b, spec_bias, w1, b1, w2, b2, *skip_ws, *spec_ws)
 
 

@@ -93,7 +93,8 @@ class FNO(nn.Module):
         if self.fused_supported(x):
             # direct_grads: set by trainer.FlatGradBucket(model, direct=True); the engine then writes
             # parameter gradients straight into the flat bucket (one use of each parameter per step)
-            return F.fno_model(x, direct_grads=getattr(self, "_direct_grads", False), **self.engine_args())
+            return F.fno_model(x, direct_grads=getattr(self, "_direct_grads", False),
+                               overlap=getattr(self, "_grad_overlap", None), **self.engine_args())
         # other widths / grids: spectral convolutions on the engine, pointwise glue in torch
         x = self.lifting(x)
         for l in range(self.n_layers):

@@ -121,10 +121,52 @@ class FlatGradBucket(object):
                 p.grad = v
 
     def all_reduce(self):
-        """SUM over ranks, no division (sum-reduced loss)."""
+        """SUM over ranks, no division (sum-reduced loss).  With an overlapped bucket (for_fno) the late
+        layers' part is already in flight: wait for it and exchange the rest."""
         self.check_views()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if not self._collective_needed():
+            self._inflight = None
+            return
+        work, self._inflight = getattr(self, "_inflight", None), None
+        if work is not None:
+            dist.all_reduce(self.flat[self._late_numel:], op=dist.ReduceOp.SUM, group=self.group)
+            work.wait()
+        else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- overlap of the gradient exchange with the backward pass (engine FNO only) -------------------------
+    @classmethod
+    def for_fno(cls, model, split_layer=1, process_group=None):
+        """Bucket laid out for comm / compute overlap: [projection | blocks L-1 .. split_layer | rest].  The engine
+        differentiates the late layers first (fno_model_backward_part) and calls late_gradients_ready(), which starts
+        an ASYNC all-reduce of the first segment; the blocks below `split_layer`, the lifting and the shared bias
+        tensor follow in all_reduce().  Same sums as the single exchange (each gradient element is reduced once)."""
+        fno = next(m for m in model.modules() if hasattr(m, "fused_supported"))
+        L = fno.n_layers
+        nc = 2 ** (fno.n_dim - 1)
+        blocks = fno.fno_blocks
+        late = list(fno.projection.parameters())
+        for l in range(L - 1, split_layer - 1, -1):
+            late += [blocks.fno_skips[l].weight] + [blocks.convs.weight[nc * l + c].tensor for c in range(nc)]
+        late_ids = {id(p) for p in late}
+        rest = [p for p in model.parameters() if id(p) not in late_ids and p.requires_grad]
+        bucket = cls([p for p in late if p.requires_grad] + rest, process_group=process_group, direct_module=model)
+        bucket._late_numel = sum(cls._nfloat(p) for p in late if p.requires_grad)
+        bucket._inflight = None
+        bucket.split_layer = split_layer
+        fno._grad_overlap = bucket
+        return bucket
+
+    def _collective_needed(self):
+        """More than one rank (or `force_collective`, used by the single-rank GPU test of the async path)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or getattr(self, "force_collective", False)
+
+    def late_gradients_ready(self):
+        if self._collective_needed():
+            self._inflight = dist.all_reduce(self.flat[:self._late_numel], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True)
 
 
 class FusedAdam(object):
