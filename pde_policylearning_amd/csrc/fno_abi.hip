@@ -100,9 +100,13 @@ static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 bloc
                   Args... args) {
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return FNO_OK;
   if (lds > 64 * 1024) {
+    if (lds > 160 * 1024) return fail(FNO_EUNSUPPORTED, "%s needs %zu bytes of LDS (160 KB per CU)", name, lds);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail(FNO_EHIP, "%s: set LDS %zu: %s", name, lds, hipGetErrorString(e));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();      // do not leave a sticky error for the next launch
+      return fail(FNO_EHIP, "%s: set LDS %zu: %s", name, lds, hipGetErrorString(e));
+    }
   }
   ProfRec rec;
   if (g_prof) {
@@ -610,6 +614,23 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
         rc = fail(FNO_EUNSUPPORTED, "plane of %d pixels (W=%d) does not tile by %d", p->g.PW, W, p->NPX);
     }
     if (rc == FNO_OK && p->g.NJ > 4) rc = fail(FNO_EUNSUPPORTED, "too many last-dim modes (%d)", p->g.Klast);
+    if (rc == FNO_OK) {
+      // every kernel of the plan must fit its tile + twiddle tables in 160 KB of LDS (256-pixel tiles with many
+      // kept last-dim modes do not: such shapes take the unfused composition)
+      const Geom& g = p->g;
+      const int npx = p->NPX, C = d->C;
+      const size_t tz = ((size_t)2 * g.Klast * g.W + (size_t)(npx / g.W) * g.Klast * C * 2) * 4;   // inverse table + Z rows
+      const size_t tf = (size_t)16 * g.NJ * (g.W + 4) * 4;                                          // forward table
+      const bool many = d->n_layers > 1;                   // blocks above 0 also carry the forward table
+      const size_t xin = d->Cin > 0 ? (size_t)8 * (npx + 4) * 4 : 0;                                // block 0: lifting rows
+      const size_t bbwd_f32 = (size_t)2 * C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
+      const size_t bbwd_x3 = (size_t)6 * C * (npx + 8) * 2 + (size_t)C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
+      const size_t bbwd = (npx == 128 && bbwd_x3 <= 160 * 1024) ? bbwd_x3 : bbwd_f32;
+      const size_t pwx3 = (size_t)3 * npx * (C + 8) * 2 + tz + (many ? tf : 0), pwf32 = (size_t)C * (npx + 4) * 4 + tz + (many ? tf : 0);
+      if (bbwd > 160 * 1024 || pwx3 > 160 * 1024 || pwf32 > 160 * 1024)
+        rc = fail(FNO_EUNSUPPORTED, "tile of %d pixels x %d channels with %d kept last-dim modes exceeds LDS", npx, C,
+                  g.Klast);
+    }
   }
   if (rc == FNO_OK) {
     int dev = 0;

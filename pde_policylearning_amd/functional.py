@@ -137,6 +137,21 @@ def model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gel
     return plan
 
 
+def model_plan_available(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gelu_mask, device):
+    """True when fno_model_plan_create accepts the configuration (result cached; an unsupported shape is not an error
+    for callers that have an unfused path)."""
+    key = ("avail", ndim, cin, c, cout, hidden_proj, n_layers, tuple(dims), tuple(modes), norm, gelu_mask, device.index)
+    ok = _model_plans.get(key)
+    if ok is None:
+        try:
+            model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gelu_mask, device)
+            ok = True
+        except RuntimeError:
+            ok = False
+        _model_plans[key] = ok
+    return ok
+
+
 def _fill_params(struct, n_layers, ncorner, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2):
     struct.lift_w, struct.lift_b = lift_w.data_ptr(), lift_b.data_ptr()
     for l in range(n_layers):
@@ -400,9 +415,10 @@ class _FNOBlocksFn(torch.autograd.Function):
         return (None, dx, g_sb) + tuple(g_skip) + tuple(g_spec)
 
 
-def blocks_supported(x, n_layers=1):
+def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
     """Shapes the fused block kernels cover (fno_model_plan_create): 32 / 64 channels, last dim a
-    multiple of 32 (<= 256), planes that tile by 128 (256) pixels."""
+    multiple of 32 (<= 256), planes that tile by 128 (256) pixels; with `modes` the engine itself is asked
+    (tile + twiddle tables must fit LDS)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() in (4, 5)):
         return False
     c, w = x.shape[1], x.shape[-1]
@@ -410,7 +426,12 @@ def blocks_supported(x, n_layers=1):
     for s in x.shape[2:]:
         pw *= s
     npx = 256 if w > 128 else 128
-    return c in (32, 64) and w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0 and n_layers <= _lib.FNO_MAX_LAYERS
+    if not (c in (32, 64) and w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0 and n_layers <= _lib.FNO_MAX_LAYERS):
+        return False
+    if modes is None:
+        return True
+    return model_plan_available(x.dim() - 2, 0, c, 0, 0, n_layers, tuple(x.shape[2:]), tuple(int(m) for m in modes), norm,
+                                int(gelu_mask), x.device)
 
 
 def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0):

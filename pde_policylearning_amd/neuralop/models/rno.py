@@ -90,7 +90,7 @@ class FourierLayer2d(nn.Module):
 
     def forward(self, x):
         b, c, n1, n2 = x.shape
-        if n1 == n2 and F.blocks_supported(x):
+        if n1 == n2 and F.blocks_supported(x, 1, (self.spec_conv.modes1, self.spec_conv.modes2), self.spec_conv.norm):
             # one fused engine layer: spectral conv + Conv1d(k=1) + bias (fno_model_* block stack, L = 1)
             sc = self.spec_conv
             return F.fno_blocks(x, [self.norm_conv1d.weight], list(sc.fourier_weight), self.norm_conv1d.bias.view(1, c),

@@ -85,9 +85,18 @@ class FNO(nn.Module):
         plane = 1
         for s in x.shape[2:]:
             plane *= s
-        return (self.hidden_channels in (32, 64) and self.in_channels <= 4 and self.out_channels <= 4
+        if not (self.hidden_channels in (32, 64) and self.in_channels <= 4 and self.out_channels <= 4
                 and self.projection_channels == 256 and w % 32 == 0 and w <= 256
-                and npx % w == 0 and plane % npx == 0 and not x.requires_grad)
+                and npx % w == 0 and plane % npx == 0 and not x.requires_grad and x.is_cuda):
+            return False
+        # the engine has the last word (e.g. 256-pixel tiles with many kept modes do not fit LDS)
+        gelu_mask = 0
+        for l in range(self.n_layers):
+            if l < self.n_layers - l:
+                gelu_mask |= 1 << l
+        return F.model_plan_available(self.n_dim, self.in_channels, self.hidden_channels, self.out_channels,
+                                      self.projection_channels, self.n_layers, tuple(x.shape[2:]),
+                                      tuple(m // 2 for m in self.n_modes), self.fft_norm, gelu_mask, x.device)
 
     def forward(self, x):
         if self.fused_supported(x):
