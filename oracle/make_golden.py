@@ -381,6 +381,41 @@ def gen_pino_loss(outdir):
              forcing=f, loss_ic=loss_ic.detach(), loss_f=loss_f.detach(), du_residual=du.detach(), grad_u=u.grad)
 
 
+def gen_pde_dataset(outdir):
+    """Plane datasets read by the reference's own classes (libs/pde_data_loader.py) from a small folder in its on-disk
+    format.  The normaliser constructor calls `.cuda()` on its statistics (libs/utilities3.py:88-90); this container has
+    no GPU, so `.cuda()` is made the identity for the duration of the call (it only creates device copies)."""
+    import tempfile
+    import types
+    from libs.pde_data_loader import PDEDataset, SequentialPDEDataset
+    rng = np.random.default_rng(7)
+    n_files, full = 6, (12, 10)
+    planes = {"P_planes": rng.standard_normal((n_files,) + full).astype(np.float32) * 3 + 1,
+              "V_planes": rng.standard_normal((n_files,) + full).astype(np.float32) * 0.5 - 2}
+    meta = {k: dict(mean=v.mean(0), std=v.std(0)) for k, v in planes.items()}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            for k, v in planes.items():
+                for i in range(n_files):
+                    np.save(os.path.join(d, f"{k}_{i:06d}.npy"), v[i])
+            np.save(os.path.join(d, "metadata.npy"), meta, allow_pickle=True)
+            args = types.SimpleNamespace(model_timestep=2)
+            idx = [4, 0, 3, 5, 1, 2]
+            ds = PDEDataset(args, d, idx, 2, 5, 4)                       # downsample 2, crop to 5 x 4
+            items = [ds[i] for i in range(len(ds))]
+            ds_patch = PDEDataset(args, d, idx[:3], 1, 6, 5, use_patch=True)   # 12x10 -> four 6x5 patches
+            patch_items = [ds_patch[i] for i in range(len(ds_patch))]
+            # SequentialPDEDataset cannot be constructed in the reference (it reads self.p_plane_mean before anything
+            # sets it, pde_data_loader.py:97-105): no vectors for it
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save(os.path.join(outdir, "pde_dataset.npz"), p_raw=planes["P_planes"], v_raw=planes["V_planes"],
+         data_index=np.array(idx), p_items=torch.stack([a for a, _ in items]), v_items=torch.stack([b for _, b in items]),
+         p_patch=torch.stack([a for a, _ in patch_items]), v_patch=torch.stack([b for _, b in patch_items]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -391,7 +426,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

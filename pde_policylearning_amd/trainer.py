@@ -292,3 +292,50 @@ class GraphedTrainStep(object):
             self.target.copy_(target)
         self.graph.replay()
         return self.loss
+
+
+class DevicePrefetcher(object):
+    """Input staging for the training loop: batches of host tensors (e.g. a torch DataLoader over libs.pde_data_loader
+    datasets) are copied into PINNED buffers and sent to the GPU on a separate copy stream one batch ahead of the
+    consumer, cast to float32 on the device - the reference does a synchronous `.cuda().float()` per step
+    (run_pde_observers.py:173).  Iterating yields tuples of device tensors that are safe to use on the current stream."""
+
+    def __init__(self, loader, device, depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, depth)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        items = batch if isinstance(batch, (tuple, list)) else (batch,)
+        out = []
+        with torch.cuda.stream(self.stream):
+            for t in items:
+                t = torch.as_tensor(t)
+                pinned = t if t.is_pinned() else t.contiguous().pin_memory()
+                out.append(pinned.to(self.device, non_blocking=True).float())
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return tuple(out), ev
+
+    def __iter__(self):
+        import collections
+        q = collections.deque()
+        it = iter(self.loader)
+        try:
+            while len(q) < self.depth:
+                q.append(self._stage(next(it)))
+        except StopIteration:
+            it = None
+        while q:
+            tensors, ev = q.popleft()
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in tensors:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            if it is not None:
+                try:
+                    q.append(self._stage(next(it)))
+                except StopIteration:
+                    it = None
+            yield tensors

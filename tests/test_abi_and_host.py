@@ -97,3 +97,41 @@ def test_observer_grid_matches_reference_definition():
     assert g.shape == (2, 5, 7, 2)
     assert np.allclose(g[0, :, 0, 0].numpy(), np.linspace(0, 1, 5).astype(np.float32))
     assert np.allclose(g[1, 0, :, 1].numpy(), np.linspace(0, 1, 7).astype(np.float32))
+
+
+def _write_plane_folder(tmp_path, g):
+    import numpy as np
+    planes = {"P_planes": g["p_raw"], "V_planes": g["v_raw"]}
+    for k, v in planes.items():
+        for i in range(v.shape[0]):
+            np.save(tmp_path / f"{k}_{i:06d}.npy", v[i])
+    np.save(tmp_path / "metadata.npy", {k: dict(mean=v.mean(0), std=v.std(0)) for k, v in planes.items()}, allow_pickle=True)
+
+
+def test_plane_dataset_matches_reference_items(tmp_path):
+    """libs.pde_data_loader.PDEDataset on the reference's on-disk format (per-timestep .npy planes + pickled metadata.npy)
+    vs items produced by the reference class itself (tests/golden/pde_dataset.npz, oracle/make_golden.py::gen_pde_dataset)."""
+    import types
+    import numpy as np
+    from tests.util import load_golden
+    from pde_policylearning_amd.libs.pde_data_loader import PDEDataset, SequentialPDEDataset
+    g = load_golden("pde_dataset")
+    _write_plane_folder(tmp_path, g)
+    args = types.SimpleNamespace(model_timestep=2)
+    idx = [int(i) for i in g["data_index"]]
+    ds = PDEDataset(args, str(tmp_path), idx, 2, 5, 4)
+    assert len(ds) == 6
+    for i in range(len(ds)):
+        p, v = ds[i]
+        assert p.shape == (5, 4, 1) and np.array_equal(p.numpy(), g["p_items"][i]) and np.array_equal(v.numpy(), g["v_items"][i])
+    dsp = PDEDataset(args, str(tmp_path), idx[:3], 1, 6, 5, use_patch=True)
+    for i in range(len(dsp)):
+        p, v = dsp[i]
+        assert np.array_equal(p.numpy(), g["p_patch"][i]) and np.array_equal(v.numpy(), g["v_patch"][i])
+    seq = SequentialPDEDataset(args, str(tmp_path), idx, 2, 5, 4)
+    assert len(seq) == 3
+    ps, vs = seq[1]                                   # planes idx[2], idx[3]
+    assert ps.shape == (2, 5, 4) and np.array_equal(ps[0].numpy(), g["p_items"][2][..., 0]) and np.array_equal(vs[1].numpy(), g["v_items"][3][..., 0])
+    # decode(encode(x)) round trip of the normaliser
+    raw = torch.tensor(g["p_raw"][idx[0]][::2, ::2][:5, :4])
+    assert torch.allclose(ds.p_norm.decode(ds.p_norm.encode(raw)), raw, atol=1e-5)

@@ -816,3 +816,29 @@ def test_backward_in_parts_equals_full_backward(dev):
     finally:
         if started:
             dist.destroy_process_group()
+
+
+def test_device_prefetcher_feeds_the_training_loop(dev, tmp_path):
+    """trainer.DevicePrefetcher (pinned staging + copy stream, one batch ahead) over a DataLoader on the reference's on-disk
+    plane format: same tensors as a synchronous `.cuda().float()`, every batch delivered once, usable by the engine."""
+    import types
+    from torch.utils.data import DataLoader
+    from pde_policylearning_amd.libs.pde_data_loader import PDEDataset
+    from pde_policylearning_amd.libs.models.fno_models import FNO2dObserver
+    from pde_policylearning_amd.trainer import DevicePrefetcher
+    g = load_golden("pde_dataset")
+    planes = {"P_planes": np.tile(g["p_raw"], (1, 6, 7))[:, :64, :64], "V_planes": np.tile(g["v_raw"], (1, 6, 7))[:, :64, :64]}
+    for k, v in planes.items():
+        for i in range(v.shape[0]):
+            np.save(tmp_path / f"{k}_{i:06d}.npy", v[i])
+    np.save(tmp_path / "metadata.npy", {k: dict(mean=v.mean(0), std=v.std(0) + 0.1) for k, v in planes.items()}, allow_pickle=True)
+    ds = PDEDataset(types.SimpleNamespace(model_timestep=1), str(tmp_path), list(range(6)), 1, 64, 64)
+    loader = DataLoader(ds, batch_size=4, shuffle=False)
+    ref = [(p.to(dev).float(), v.to(dev).float()) for p, v in loader]
+    got = list(DevicePrefetcher(loader, dev))
+    assert len(got) == len(ref) == 2
+    for (p, v), (pr, vr) in zip(got, ref):
+        assert p.is_cuda and p.dtype == torch.float32 and torch.equal(p, pr) and torch.equal(v, vr)
+    model = FNO2dObserver(8, 8, 32).to(dev)
+    y = model(got[0][0], None)
+    assert y.shape[0] == 4 and torch.isfinite(y).all()
