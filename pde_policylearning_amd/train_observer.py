@@ -1,0 +1,116 @@
+"""Observer training loop: the counterpart of run_pde_observers.py:66-240 (dataset split, loaders, model choice, Adam,
+LpLoss on decoded fields, per-epoch train / test relative L2) for the `PDEDataset` path, with every hot step in the engine:
+asynchronous input staging (trainer.DevicePrefetcher), the fused FNO model or the engine-backed RNO, fused decode + loss,
+flat-bucket Adam, optional data parallelism (one process per GPU, overlapped RCCL all-reduce).  No W&B, no MATLAB control
+environment (out of scope).
+
+  python -m pde_policylearning_amd.train_observer --data-folder DIR --ntrain 800 --ntest 200 --modes 12 --width 64 \\
+         --x-range 128 --y-range 128 --batch-size 64 --epochs 5 [--model FNO2dObserver|RNO2dObserver]
+  (N GPUs: python -m torch.distributed.run --nproc-per-node N -m pde_policylearning_amd.train_observer ...)
+"""
+import argparse
+import os
+import time
+import types
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from .libs.models.fno_models import FNO2dObserver
+from .libs.models.rno_models import RNO2dObserver
+from .libs.pde_data_loader import PDEDataset
+from .trainer import (DevicePrefetcher, FlatGradBucket, FusedAdam, FusedLpLoss, MeanStdDecoder, broadcast_parameters,
+                      shard_batch, train_step)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data-folder", required=True)
+    ap.add_argument("--ntrain", type=int, required=True)
+    ap.add_argument("--ntest", type=int, required=True)
+    ap.add_argument("--random-split", action="store_true")          # run_pde_observers.py:69-72
+    ap.add_argument("--model", default="FNO2dObserver", choices=["FNO2dObserver", "RNO2dObserver"])
+    ap.add_argument("--modes", type=int, default=12)
+    ap.add_argument("--width", type=int, default=32)
+    ap.add_argument("--layer-num", type=int, default=1)
+    ap.add_argument("--downsample-rate", type=int, default=1)
+    ap.add_argument("--x-range", type=int, default=32)
+    ap.add_argument("--y-range", type=int, default=32)
+    ap.add_argument("--batch-size", type=int, default=20)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--learning-rate", type=float, default=1e-3)
+    ap.add_argument("--weight-decay", type=float, default=1e-4)
+    ap.add_argument("--seed", type=int, default=0)                  # run_pde_observers.py:25
+    return ap
+
+
+def run(args, log=print):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(args.seed)
+    n = args.ntrain + args.ntest
+    idx = torch.randperm(n) if args.random_split else torch.arange(n)
+    ds_args = types.SimpleNamespace(model_timestep=1)
+    train_ds = PDEDataset(ds_args, args.data_folder, idx[:args.ntrain].tolist(), args.downsample_rate, args.x_range, args.y_range)
+    test_ds = PDEDataset(ds_args, args.data_folder, idx[-args.ntest:].tolist(), args.downsample_rate, args.x_range, args.y_range)
+    train_loader = DataLoader(train_ds, batch_size=args.batch_size * world, shuffle=False, drop_last=True)
+    test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
+    if args.model == "FNO2dObserver":
+        model = FNO2dObserver(args.modes, args.modes, args.width).to(dev)
+        forward = lambda p: model(p, None)
+    else:
+        model = RNO2dObserver(args.modes, args.modes, args.width, recurrent_index=0, layer_num=args.layer_num).to(dev)
+        forward = lambda p: model(p.unsqueeze(1))                 # (B, T = 1, X, Y, 1)
+    broadcast_parameters(model)
+    fused = args.model == "FNO2dObserver"
+    if fused and world > 1:
+        bucket = FlatGradBucket.for_fno(model, split_layer=1)
+    else:
+        bucket = FlatGradBucket(model.parameters(), direct_module=model if fused else None)
+    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)
+    decoder = MeanStdDecoder(train_ds.v_norm.mean.numpy(), train_ds.v_norm.std.numpy(), eps=train_ds.v_norm.eps, device=dev)
+    loss_fn = FusedLpLoss(size_average=False, decoder=decoder)   # myloss = LpLoss(size_average=False), :138
+    history = []
+    for ep in range(args.epochs):
+        model.train()
+        t0 = time.perf_counter()
+        tot = torch.zeros((), device=dev)
+        cnt = 0
+        for p_plane, v_plane in DevicePrefetcher(train_loader, dev):
+            if world > 1:
+                p_plane, v_plane = shard_batch(p_plane, rank, world), shard_batch(v_plane, rank, world)
+            tgt = v_plane.squeeze(-1)
+            tot += train_step(forward, bucket, opt, (p_plane,), tgt, loss_fn)     # :185-193
+            cnt += tgt.shape[0]
+        if world > 1:
+            dist.all_reduce(tot)
+            cnt *= world
+        model.eval()
+        test_tot, test_cnt = torch.zeros((), device=dev), 0
+        with torch.no_grad():
+            for p_plane, v_plane in DevicePrefetcher(test_loader, dev):
+                tgt = v_plane.squeeze(-1)
+                test_tot += loss_fn(forward(p_plane).reshape(tgt.shape), tgt)
+                test_cnt += tgt.shape[0]
+        rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
+                   seconds=time.perf_counter() - t0)
+        history.append(rec)
+        if rank == 0:
+            log(f"epoch {ep}: train rel-L2 {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
+    return history
+
+
+def main():
+    run(build_parser().parse_args())
+
+
+if __name__ == "__main__":
+    main()

@@ -842,3 +842,27 @@ def test_device_prefetcher_feeds_the_training_loop(dev, tmp_path):
     model = FNO2dObserver(8, 8, 32).to(dev)
     y = model(got[0][0], None)
     assert y.shape[0] == 4 and torch.isfinite(y).all()
+
+
+def test_observer_training_loop_learns_on_disk_dataset(dev, tmp_path):
+    """train_observer.run (the run_pde_observers.py:66-240 counterpart) on a synthetic plane folder in the reference's format:
+    the target is a fixed smooth function of the input plane, so the relative L2 must drop over a few epochs."""
+    from pde_policylearning_amd import train_observer
+    rng = np.random.default_rng(3)
+    n, S = 48, 32
+    xs = np.linspace(0, 2 * np.pi, S, endpoint=False)
+    base = rng.standard_normal((n, 1, 1)).astype(np.float32) * np.sin(xs)[None, :, None] + rng.standard_normal((n, 1, 1)).astype(np.float32) * np.cos(2 * xs)[None, None, :]
+    p = (base + 0.1 * rng.standard_normal((n, S, S))).astype(np.float32)
+    v = (0.7 * np.roll(p, 3, axis=1) - 0.2 * p + 0.5).astype(np.float32)
+    for i in range(n):
+        np.save(tmp_path / f"P_planes_{i:06d}.npy", p[i])
+        np.save(tmp_path / f"V_planes_{i:06d}.npy", v[i])
+    np.save(tmp_path / "metadata.npy", {"P_planes": dict(mean=p.mean(0), std=p.std(0)), "V_planes": dict(mean=v.mean(0), std=v.std(0))},
+            allow_pickle=True)
+    args = train_observer.build_parser().parse_args(["--data-folder", str(tmp_path), "--ntrain", "40", "--ntest", "8", "--modes", "8",
+                                                      "--width", "32", "--x-range", "32", "--y-range", "32", "--batch-size", "8",
+                                                      "--epochs", "6", "--learning-rate", "0.003"])
+    hist = train_observer.run(args, log=lambda *_: None)
+    assert len(hist) == 6 and all(np.isfinite(h["train_l2"]) and np.isfinite(h["test_l2"]) for h in hist)
+    assert hist[-1]["train_l2"] < 0.6 * hist[0]["train_l2"]
+    assert hist[-1]["test_l2"] < hist[0]["test_l2"]
