@@ -416,6 +416,45 @@ def gen_pde_dataset(outdir):
          p_patch=torch.stack([a for a, _ in patch_items]), v_patch=torch.stack([b for _, b in patch_items]))
 
 
+def chanflow_inputs(tag, Nx, Ny, Nz, dtype=torch.float32):
+    """U, Vgt, V, W of one deterministic channel-flow sample (shared with the tests via oracle.detfill)."""
+    U = 1.0 + input_fill(f"chanflow.U.{tag}", (Nx, Ny + 1, Nz), 0.5)
+    Vgt = input_fill(f"chanflow.Vgt.{tag}", (Nx, Ny, Nz), 0.3)
+    V = Vgt + input_fill(f"chanflow.dV.{tag}", (Nx, Ny, Nz), 0.1)
+    W = input_fill(f"chanflow.W.{tag}", (Nx, Ny + 1, Nz), 0.3)
+    return [a.to(dtype) for a in (U, Vgt, V, W)]
+
+
+def gen_chanflow(outdir):
+    """Channel-flow RHS and physics-informed loss from the reference's own NSControlEnvMatlab.compute_rhs_py / pde_loss
+    (libs/envs/control_env.py:429-530, 627-633).  The class constructor starts MATLAB, so the two methods are called unbound
+    on a namespace carrying exactly the attributes they read (dx, dz, y, ym, yg, Ny, nu, dPdx); pde_loss's two
+    pdb.set_trace() calls are patched to no-ops.  dx, dz are numpy float64 scalars and y, ym, yg 1-D float64 arrays, so every
+    metric enters as a 0-dim float64 tensor and the arithmetic stays in the dtype of the fields (fp32 and fp64 runs are both
+    stored).  With the (N, 1) arrays scipy.io.loadmat hands the real constructor (control_env.py:151-165) the same code
+    promotes fp32 fields to fp64 at the first division."""
+    import pdb
+    from oracle.chanflow_oracle import tanh_grid
+    import libs.envs.control_env as ce
+    pdb.set_trace = lambda *a, **k: None
+    nu = 3.076923076923077e-04                                             # control_env.py:26
+    for tag, (Nx, Ny, Nz, stride) in {"small": (8, 10, 6, 1), "odd": (6, 7, 10, 1), "shipped": (32, 130, 32, 7)}.items():
+        y, ym, yg = tanh_grid(Ny)
+        ns = types.SimpleNamespace(dx=np.float64(2 * np.pi / Nx), dz=np.float64(2 * np.pi / Nz), y=y, ym=ym, yg=yg, Ny=Ny, nu=nu, dPdx=0.57231059E-01 ** 2)
+        ns.compute_rhs_py = lambda *a, **k: ce.NSControlEnvMatlab.compute_rhs_py(ns, *a, **k)
+        out = {"meta": np.array([Nx, Ny, Nz, stride]), "nu": np.float64(nu), "dpdx": np.float64(ns.dPdx)}
+        for dt, dn in ((torch.float32, "f32"), (torch.float64, "f64")):
+            U, Vgt, V, W = chanflow_inputs(tag, Nx, Ny, Nz, dt)
+            V.requires_grad_(True)
+            F = ce.NSControlEnvMatlab.compute_rhs_py(ns, U, V.detach(), W, torch.tensor(ns.dPdx, dtype=dt))
+            loss = ce.NSControlEnvMatlab.pde_loss(ns, U, Vgt, V, W, torch.tensor(ns.dPdx, dtype=dt))
+            loss.backward()
+            sub = lambda a: a.detach().reshape(-1)[::stride]
+            out.update({f"Fu_{dn}": sub(F[0]), f"Fv_{dn}": sub(F[1]), f"Fw_{dn}": sub(F[2]), f"loss_{dn}": loss.detach(),
+                        f"gradV_{dn}": sub(V.grad), f"norms_{dn}": np.array([float(a.norm()) for a in F])})
+        save(os.path.join(outdir, f"chanflow_{tag}.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -426,7 +465,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_chanflow]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

@@ -229,3 +229,33 @@ def test_pino_residual_loss_golden(tag):
     assert abs(float(lf) - float(g["loss_f"])) < 1e-6 * abs(float(g["loss_f"]))
     (5.0 * lic + lf).backward()
     assert rel_l2(u.grad.numpy(), g["grad_u"]) < 1e-5
+
+
+def chanflow_inputs(tag, Nx, Ny, Nz, dtype=torch.float32):
+    """the deterministic sample oracle/make_golden.py::chanflow_inputs fed to the reference"""
+    U = 1.0 + torch.from_numpy(fill_named(f"input:chanflow.U.{tag}", (Nx, Ny + 1, Nz), 0.5))
+    Vgt = torch.from_numpy(fill_named(f"input:chanflow.Vgt.{tag}", (Nx, Ny, Nz), 0.3))
+    V = Vgt + torch.from_numpy(fill_named(f"input:chanflow.dV.{tag}", (Nx, Ny, Nz), 0.1))
+    W = torch.from_numpy(fill_named(f"input:chanflow.W.{tag}", (Nx, Ny + 1, Nz), 0.3))
+    return [a.to(dtype) for a in (U, Vgt, V, W)]
+
+
+@pytest.mark.parametrize("tag", ["small", "odd", "shipped"])
+def test_chanflow_rhs_and_pde_loss_golden(tag):
+    """oracle/chanflow_oracle.py vs vectors produced by the reference's own NSControlEnvMatlab.compute_rhs_py / pde_loss
+    (libs/envs/control_env.py:429-530, 627-633), fp32 and fp64."""
+    from oracle import chanflow_oracle as C
+    g = load_golden("chanflow_" + tag)
+    Nx, Ny, Nz, stride = [int(v) for v in g["meta"]]
+    y, ym, yg = C.tanh_grid(Ny)
+    geo = (2 * np.pi / Nx, 2 * np.pi / Nz, y, ym, yg, float(g["nu"]))
+    for dt, dn, tol in ((torch.float32, "f32", 2e-6), (torch.float64, "f64", 1e-13)):
+        U, Vgt, V, W = chanflow_inputs(tag, Nx, Ny, Nz, dt)
+        V.requires_grad_(True)
+        F = C.compute_rhs(U, V.detach(), W, float(g["dpdx"]), *geo)
+        for a, n in zip(F, ("Fu", "Fv", "Fw")):
+            assert rel_l2(a.reshape(-1)[::stride].numpy(), g[f"{n}_{dn}"]) < tol, (n, dn)
+        loss = C.pde_loss(U, Vgt, V, W, float(g["dpdx"]), *geo)
+        assert abs(float(loss.detach()) - float(g[f"loss_{dn}"])) < 10 * tol * abs(float(g[f"loss_{dn}"]))
+        loss.backward()
+        assert rel_l2(V.grad.reshape(-1)[::stride].numpy(), g[f"gradV_{dn}"]) < 10 * tol, dn
