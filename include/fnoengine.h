@@ -255,6 +255,36 @@ int fno_lifting_forward(int batch, int cin, int channels, size_t plane, const fl
 int fno_lifting_backward(int batch, int cin, int channels, size_t plane, const float* x, const float* dy, float* dw,
                          float* dbias, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Channel-flow Navier-Stokes right-hand side on the staggered grid and the physics-informed loss built on it:
+ * NSControlEnvMatlab.compute_rhs_py (libs/envs/control_env.py:429-530) and NSControlEnvMatlab.pde_loss (:627-633),
+ * the `pde_loss_weight` branch of the observer training loop (run_pde_observers.py:226-231).
+ * One field: U, W (Nx, Ny+1, Nz), V (Nx, Ny, Nz), z contiguous; all calls take `batch` stacked fields.
+ *   fno_chanflow_pack_metrics: HOST helper.  From the wall-normal grid y[Ny] (faces), ym[Ny-1] (centres),
+ *     yg[Ny+1] (ghost-extended centres, control_env.py:165) fills packed[3*(Ny+2)] with the reciprocal spacings the
+ *     kernels index; the caller copies `packed` (doubles) to the device once and passes it as `metrics`.
+ *   fno_chanflow_rhs: Fu, Fv, Fw = compute_rhs_py(U, V, W, dPdx); dtype 0 = fp32, 1 = fp64 (the reference's RK3 stepper
+ *     runs it in fp64, the training loop on fp32 fields); dpdx = per-sample device array of that dtype or NULL for
+ *     `dpdx_default`.
+ *   fno_chanflow_pde_loss_forward: loss = sum_b ||Fu(U,Vgt,W)-Fu(U,V,W)|| + ||Fv..|| + ||Fw..|| (fp32, device scalar);
+ *     leaves the difference fields and per-sample norms in `ws`.
+ *   fno_chanflow_pde_loss_backward: dV = gloss * dloss/dV (gloss: device scalar, NULL = 1); Vgt is data.
+ * ---------------------------------------------------------------------- */
+typedef struct FnoChanflowGrid {
+  int Nx, Ny, Nz;        /* Ny = number of y faces (rows of V); U and W carry Ny+1 rows */
+  double dx, dz, nu;
+} FnoChanflowGrid;
+int fno_chanflow_pack_metrics(int Ny, const double* y, const double* ym, const double* yg, double* packed);
+int fno_chanflow_rhs(const FnoChanflowGrid* grid, int batch, int dtype, const double* metrics, const void* U, const void* V,
+                     const void* W, const void* dpdx, double dpdx_default, void* Fu, void* Fv, void* Fw, void* stream);
+size_t fno_chanflow_pde_loss_workspace_bytes(const FnoChanflowGrid* grid, int batch);
+int fno_chanflow_pde_loss_forward(const FnoChanflowGrid* grid, int batch, const double* metrics, const float* U,
+                                  const float* Vgt, const float* V, const float* W, float* loss, void* ws, size_t ws_bytes,
+                                  void* stream);
+int fno_chanflow_pde_loss_backward(const FnoChanflowGrid* grid, int batch, const double* metrics, const float* U,
+                                   const float* Vgt, const float* V, const float* W, const float* gloss, float* dV, void* ws,
+                                   size_t ws_bytes, void* stream);
+
 /* Names and average device time (ms, HIP events on `stream`) of the kernels launched
  * by the last fno_model_* call made with profiling enabled; used by bench.py for the
  * roofline line.  fno_profile_enable(1) makes every launch event-bracketed (slow path). */

@@ -40,6 +40,10 @@ class FnoModelParams(C.Structure):
 
 FnoModelGrads = FnoModelParams   # same layout, mutable pointers
 
+
+class FnoChanflowGrid(C.Structure):
+    _fields_ = [("Nx", C.c_int), ("Ny", C.c_int), ("Nz", C.c_int), ("dx", C.c_double), ("dz", C.c_double), ("nu", C.c_double)]
+
 _lib = None
 
 
@@ -102,6 +106,13 @@ def lib():
     L.fno_rno_reset_gate_backward.argtypes = [sz] + [vp] * 7
     L.fno_rno_output_gate_forward.argtypes = [sz] + [vp] * 15
     L.fno_rno_output_gate_backward.argtypes = [sz] + [vp] * 11
+    gp, dp = C.POINTER(FnoChanflowGrid), C.POINTER(C.c_double)
+    L.fno_chanflow_pack_metrics.argtypes = [ci, dp, dp, dp, dp]
+    L.fno_chanflow_rhs.argtypes = [gp, ci, ci, vp, vp, vp, vp, vp, C.c_double, vp, vp, vp, vp]
+    L.fno_chanflow_pde_loss_workspace_bytes.argtypes = [gp, ci]
+    L.fno_chanflow_pde_loss_workspace_bytes.restype = sz
+    L.fno_chanflow_pde_loss_forward.argtypes = [gp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.fno_chanflow_pde_loss_backward.argtypes = [gp, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.fno_pino_loss_workspace_bytes.argtypes = [ci, ci, ci]
     L.fno_pino_loss_workspace_bytes.restype = sz
     L.fno_pino_loss_forward.argtypes = [ci, ci, ci, vp, vp, vp, vp, fl, vp, vp, vp, sz, vp]
@@ -138,6 +149,8 @@ EXPORTED_SYMBOLS = [
     "fno_rno_gate_partials", "fno_rno_reset_gate_forward", "fno_rno_reset_gate_backward",
     "fno_rno_output_gate_forward", "fno_rno_output_gate_backward",
     "fno_pino_loss_workspace_bytes", "fno_pino_loss_forward", "fno_pino_loss_backward",
+    "fno_chanflow_pack_metrics", "fno_chanflow_rhs", "fno_chanflow_pde_loss_workspace_bytes",
+    "fno_chanflow_pde_loss_forward", "fno_chanflow_pde_loss_backward",
     "fno_profile_enable", "fno_profile_count", "fno_profile_get", "fno_profile_reset",
 ]
 

@@ -14,6 +14,7 @@
 
 #include "../../include/fnoengine.h"
 #include "k_block_bwd.h"
+#include "k_chanflow.h"
 #include "k_pointwise.h"
 #include "k_projection.h"
 #include "k_spectral_mid.h"
@@ -1170,6 +1171,100 @@ extern "C" int fno_pino_loss_backward(int B, int n, int T, const float* u, const
                    (const float*)w.dws, (const float*)(w.fields + 4 * np), (const float*)w.coef_f, (const float*)w.coef_ic,
                    g_f, g_ic, B, n * n, T, a.inv2dt, du));
   return FNO_OK;
+}
+
+// ===========================================================================
+// Channel-flow RHS + physics-informed loss (libs/envs/control_env.py:429-530, 627-633)
+// ===========================================================================
+extern "C" int fno_chanflow_pack_metrics(int Ny, const double* y, const double* ym, const double* yg, double* packed) {
+  if (Ny < 3 || !y || !ym || !yg || !packed) return fail(FNO_EINVAL, "fno_chanflow_pack_metrics: Ny >= 3 and non-null arrays");
+  const int MP = Ny + 2;
+  for (int t = 0; t < 3 * MP; ++t) packed[t] = 0.0;
+  for (int j = 1; j <= Ny - 1; ++j) packed[j] = 1.0 / (y[j] - y[j - 1]);
+  for (int j = 1; j <= Ny - 2; ++j) packed[MP + j] = 1.0 / (ym[j] - ym[j - 1]);
+  for (int j = 1; j <= Ny; ++j) packed[2 * MP + j] = 1.0 / (yg[j] - yg[j - 1]);
+  for (int t = 0; t < 3 * MP; ++t)
+    if (!std::isfinite(packed[t])) return fail(FNO_EINVAL, "fno_chanflow_pack_metrics: repeated grid point");
+  return FNO_OK;
+}
+static int chanflow_geo(const FnoChanflowGrid* g, int B, const double* metrics, ChanflowGeo* out) {
+  if (!g || !metrics) return fail(FNO_EINVAL, "chanflow: null grid or metrics");
+  if (B < 1 || g->Nx < 2 || g->Ny < 3 || g->Nz < 2) return fail(FNO_EINVAL, "chanflow: need batch >= 1, Nx, Nz >= 2, Ny >= 3");
+  if (!(g->dx > 0) || !(g->dz > 0)) return fail(FNO_EINVAL, "chanflow: dx and dz must be positive");
+  if ((size_t)B * g->Nx > 0x7fffffffull) return fail(FNO_EINVAL, "chanflow: batch * Nx exceeds the grid limit");
+  if ((size_t)(g->Ny + 1) * g->Nz > 0x3fffffffull) return fail(FNO_EINVAL, "chanflow: slab too large");
+  out->B = B; out->Nx = g->Nx; out->Ny = g->Ny; out->Nz = g->Nz;
+  out->rdx = 1.0 / g->dx; out->rdz = 1.0 / g->dz; out->nu = g->nu; out->metrics = metrics;
+  return FNO_OK;
+}
+template <typename T>
+static int chanflow_rhs_t(const ChanflowGeo& geo, const void* U, const void* V, const void* W, const void* dpdx,
+                          double dpdx_default, void* Fu, void* Fv, void* Fw, hipStream_t st) {
+  ChanflowRhsArgs<T> a;
+  a.U = (const T*)U; a.V = (const T*)V; a.W = (const T*)W; a.dPdx = (const T*)dpdx;
+  a.Fu = (T*)Fu; a.Fv = (T*)Fv; a.Fw = (T*)Fw; a.dPdx_default = (T)dpdx_default;
+  return launch("k_chanflow_rhs", k_chanflow_rhs<T>, dim3((unsigned)(geo.B * geo.Nx)), dim3(256), 0, st, geo, a);
+}
+extern "C" int fno_chanflow_rhs(const FnoChanflowGrid* grid, int B, int dtype, const double* metrics, const void* U,
+                                const void* V, const void* W, const void* dpdx, double dpdx_default, void* Fu, void* Fv,
+                                void* Fw, void* stream) {
+  ChanflowGeo geo;
+  LAUNCHCHK(chanflow_geo(grid, B, metrics, &geo));
+  if (!U || !V || !W || !Fu || !Fv || !Fw) return fail(FNO_EINVAL, "fno_chanflow_rhs: null field");
+  if (dtype == 0) return chanflow_rhs_t<float>(geo, U, V, W, dpdx, dpdx_default, Fu, Fv, Fw, (hipStream_t)stream);
+  if (dtype == 1) return chanflow_rhs_t<double>(geo, U, V, W, dpdx, dpdx_default, Fu, Fv, Fw, (hipStream_t)stream);
+  return fail(FNO_EINVAL, "fno_chanflow_rhs: dtype must be 0 (fp32) or 1 (fp64)");
+}
+struct ChanflowWs { float *Du, *Dv, *Dw, *partial, *inv_norm; size_t total; bool ok; };
+static ChanflowWs carve_chanflow(const FnoChanflowGrid* g, int B, void* ws, size_t ws_bytes) {
+  ChanflowWs w;
+  const size_t su = (size_t)B * g->Nx * (g->Ny + 1) * g->Nz, sv = (size_t)B * g->Nx * g->Ny * g->Nz;
+  auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  float* p = (float*)ws;
+  w.Du = p; p += up(su);
+  w.Dw = p; p += up(su);
+  w.Dv = p; p += up(sv);
+  w.partial = p; p += up((size_t)B * g->Nx * 3);
+  w.inv_norm = p; p += up((size_t)B * 3);
+  w.total = (size_t)((char*)p - (char*)ws);
+  w.ok = ws_bytes >= w.total;
+  return w;
+}
+extern "C" size_t fno_chanflow_pde_loss_workspace_bytes(const FnoChanflowGrid* grid, int B) {
+  if (!grid || B < 1 || grid->Nx < 1 || grid->Ny < 1 || grid->Nz < 1) return 0;
+  return carve_chanflow(grid, B, nullptr, 0).total;
+}
+extern "C" int fno_chanflow_pde_loss_forward(const FnoChanflowGrid* grid, int B, const double* metrics, const float* U,
+                                             const float* Vgt, const float* V, const float* W, float* loss, void* ws,
+                                             size_t ws_bytes, void* stream) {
+  ChanflowGeo geo;
+  LAUNCHCHK(chanflow_geo(grid, B, metrics, &geo));
+  if (!U || !Vgt || !V || !W || !loss || !ws) return fail(FNO_EINVAL, "fno_chanflow_pde_loss_forward: null argument");
+  ChanflowWs w = carve_chanflow(grid, B, ws, ws_bytes);
+  if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  ChanflowLossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.U = U; a.Vgt = Vgt; a.V = V; a.W = W; a.Du = w.Du; a.Dv = w.Dv; a.Dw = w.Dw; a.partial = w.partial;
+  LAUNCHCHK(launch("k_chanflow_diff", k_chanflow_diff, dim3((unsigned)(B * grid->Nx)), dim3(256), 0, st, geo, a));
+  LAUNCHCHK(launch("k_chanflow_finish", k_chanflow_finish, dim3(1), dim3(256), 0, st, B, grid->Nx, (const float*)w.partial,
+                   w.inv_norm, loss));
+  return FNO_OK;
+}
+extern "C" int fno_chanflow_pde_loss_backward(const FnoChanflowGrid* grid, int B, const double* metrics, const float* U,
+                                              const float* Vgt, const float* V, const float* W, const float* gloss, float* dV,
+                                              void* ws, size_t ws_bytes, void* stream) {
+  ChanflowGeo geo;
+  LAUNCHCHK(chanflow_geo(grid, B, metrics, &geo));
+  if (!U || !Vgt || !V || !W || !dV || !ws) return fail(FNO_EINVAL, "fno_chanflow_pde_loss_backward: null argument");
+  ChanflowWs w = carve_chanflow(grid, B, ws, ws_bytes);
+  if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  ChanflowLossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.U = U; a.Vgt = Vgt; a.V = V; a.W = W; a.Du = w.Du; a.Dv = w.Dv; a.Dw = w.Dw; a.inv_norm = w.inv_norm;
+  a.gloss = gloss; a.dV = dV;
+  return launch("k_chanflow_diff_bwd", k_chanflow_diff_bwd, dim3((unsigned)(B * grid->Nx)), dim3(256), 0, (hipStream_t)stream,
+                geo, a);
 }
 
 // ===========================================================================

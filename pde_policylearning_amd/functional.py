@@ -492,6 +492,125 @@ def pino_loss(u, u0, forcing, visc, t_interval=1.0):
 
 
 # ----------------------------------------------------------------------------
+# channel-flow RHS and the physics-informed loss (libs/envs/control_env.py:429-530, 627-633)
+# ----------------------------------------------------------------------------
+class ChannelGrid:
+    """The staggered channel grid the kernels need: sizes, uniform spacings dx, dz, viscosity nu and the wall-normal
+    metrics y (Ny faces), ym (Ny-1 centres), yg (Ny+1 ghost-extended centres).  Packs the reciprocal spacings once on the
+    host (fno_chanflow_pack_metrics) and keeps one device copy per GPU."""
+
+    def __init__(self, Nx, Nz, dx, dz, y, ym, yg, nu):
+        import numpy as np
+        y, ym, yg = (np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1)) for a in (y, ym, yg))
+        self.Nx, self.Ny, self.Nz = int(Nx), int(y.shape[0]), int(Nz)
+        if ym.shape[0] != self.Ny - 1 or yg.shape[0] != self.Ny + 1:
+            raise ValueError(f"channel grid: y has {self.Ny} faces, so ym needs {self.Ny - 1} and yg {self.Ny + 1} entries "
+                             f"(got {ym.shape[0]}, {yg.shape[0]})")
+        self.dx, self.dz, self.nu = float(dx), float(dz), float(nu)
+        self.y, self.ym, self.yg = y, ym, yg
+        self._packed = None
+        self._dev = {}
+
+    def desc(self):
+        return _lib.FnoChanflowGrid(self.Nx, self.Ny, self.Nz, self.dx, self.dz, self.nu)
+
+    def metrics(self, device):
+        import numpy as np
+        if self._packed is None:
+            packed = np.zeros(3 * (self.Ny + 2), dtype=np.float64)
+            dp = C.POINTER(C.c_double)
+            _lib.check(_lib.lib().fno_chanflow_pack_metrics(self.Ny, self.y.ctypes.data_as(dp), self.ym.ctypes.data_as(dp),
+                                                            self.yg.ctypes.data_as(dp), packed.ctypes.data_as(dp)),
+                       "chanflow_pack_metrics")
+            self._packed = packed
+        if device not in self._dev:
+            self._dev[device] = torch.from_numpy(self._packed).to(device)
+        return self._dev[device]
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_dev"] = {}
+        return st
+
+    def _check_fields(self, U, V, W, who):
+        B = U.shape[0]
+        su, sv = (B, self.Nx, self.Ny + 1, self.Nz), (B, self.Nx, self.Ny, self.Nz)
+        if tuple(U.shape) != su or tuple(W.shape) != su or tuple(V.shape) != sv:
+            raise RuntimeError(f"fnoengine {who}: expected U, W {su} and V {sv}, got {tuple(U.shape)}, {tuple(W.shape)}, "
+                               f"{tuple(V.shape)}")
+        for t, n in ((U, "U"), (V, "V"), (W, "W")):
+            if not t.is_cuda:
+                raise RuntimeError(f"fnoengine {who}: `{n}` must live on the GPU (got {t.device}); the engine has no CPU path")
+
+
+def chanflow_rhs(grid, U, V, W, dPdx):
+    """Fu, Fv, Fw = NSControlEnvMatlab.compute_rhs_py(U, V, W, dPdx) (libs/envs/control_env.py:429-530) for a batch of
+    fields: U, W (B, Nx, Ny+1, Nz), V (B, Nx, Ny, Nz), fp32 or fp64; dPdx a float or a (B,) tensor.  Not differentiable
+    (the reference uses it under autograd only through pde_loss -> chanflow_pde_loss)."""
+    grid._check_fields(U, V, W, "chanflow_rhs")
+    if U.dtype not in (torch.float32, torch.float64) or V.dtype != U.dtype or W.dtype != U.dtype:
+        raise RuntimeError("fnoengine chanflow_rhs: U, V, W must share one dtype, float32 or float64")
+    U, V, W = U.contiguous(), V.contiguous(), W.contiguous()
+    B = U.shape[0]
+    dp, dflt = None, 0.0
+    if torch.is_tensor(dPdx) and dPdx.numel() > 1:
+        dp = dPdx.to(device=U.device, dtype=U.dtype).reshape(B).contiguous()
+    else:
+        dflt = float(dPdx)
+    Fu, Fv, Fw = torch.empty_like(U), torch.empty_like(V), torch.empty_like(W)
+    g = grid.desc()
+    with torch.cuda.device(U.device):
+        _lib.check(_lib.lib().fno_chanflow_rhs(C.byref(g), B, 0 if U.dtype == torch.float32 else 1, _ptr(grid.metrics(U.device)),
+                                               _ptr(U), _ptr(V), _ptr(W), _ptr(dp), dflt, _ptr(Fu), _ptr(Fv), _ptr(Fw),
+                                               _stream()), "chanflow_rhs")
+    return Fu, Fv, Fw
+
+
+class _ChanflowPdeLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, U, Vgt, V, W):
+        B = U.shape[0]
+        U, Vgt, V, W = U.contiguous(), Vgt.contiguous(), V.contiguous(), W.contiguous()
+        L = _lib.lib()
+        g = grid.desc()
+        nws = L.fno_chanflow_pde_loss_workspace_bytes(C.byref(g), B)
+        ws = _bytes(nws, U.device)
+        loss = torch.empty(1, dtype=torch.float32, device=U.device)
+        m = grid.metrics(U.device)
+        with torch.cuda.device(U.device):
+            _lib.check(L.fno_chanflow_pde_loss_forward(C.byref(g), B, _ptr(m), _ptr(U), _ptr(Vgt), _ptr(V), _ptr(W), _ptr(loss),
+                                                       _ptr(ws), nws, _stream()), "chanflow_pde_loss_forward")
+        ctx.save_for_backward(U, Vgt, V, W, ws, m)
+        ctx.meta = (grid, B, nws)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        U, Vgt, V, W, ws, m = ctx.saved_tensors
+        grid, B, nws = ctx.meta
+        g = grid.desc()
+        dV = torch.empty_like(V)
+        glc = gl.contiguous().to(torch.float32).reshape(1)
+        with torch.cuda.device(V.device):
+            _lib.check(_lib.lib().fno_chanflow_pde_loss_backward(C.byref(g), B, _ptr(m), _ptr(U), _ptr(Vgt), _ptr(V), _ptr(W),
+                                                                 _ptr(glc), _ptr(dV), _ptr(ws), nws, _stream()),
+                       "chanflow_pde_loss_backward")
+        return None, None, None, dV, None
+
+
+def chanflow_pde_loss(grid, U, Vgt, V, W):
+    """sum_b ||Fu(U,Vgt,W) - Fu(U,V,W)|| + ||Fv ..|| + ||Fw ..||: NSControlEnvMatlab.pde_loss (libs/envs/control_env.py:627-633)
+    summed over the batch as the training loop does (run_pde_observers.py:226-230).  fp32 fields on the GPU;
+    differentiable w.r.t. V (the predicted wall-normal velocity); the pressure gradient cancels and is not an argument."""
+    grid._check_fields(U, V, W, "chanflow_pde_loss")
+    if tuple(Vgt.shape) != tuple(V.shape):
+        raise RuntimeError(f"fnoengine chanflow_pde_loss: Vgt {tuple(Vgt.shape)} must match V {tuple(V.shape)}")
+    for t, n in ((U, "U"), (Vgt, "Vgt"), (V, "V"), (W, "W")):
+        _require_cuda(t, n)
+    return _ChanflowPdeLossFn.apply(grid, U, Vgt, V, W)
+
+
+# ----------------------------------------------------------------------------
 # RNO cell gates (neuralop/models/rno.py:254-260)
 # ----------------------------------------------------------------------------
 def gates_supported(*tensors):

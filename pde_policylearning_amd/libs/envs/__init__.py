@@ -1,0 +1,1 @@
+from .control_env import ChannelFlowRHS  # noqa: F401

@@ -135,3 +135,38 @@ def test_plane_dataset_matches_reference_items(tmp_path):
     # decode(encode(x)) round trip of the normaliser
     raw = torch.tensor(g["p_raw"][idx[0]][::2, ::2][:5, :4])
     assert torch.allclose(ds.p_norm.decode(ds.p_norm.encode(raw)), raw, atol=1e-5)
+
+
+def test_chanflow_host_side_without_gpu(lib):
+    """fno_chanflow_pack_metrics is pure host code: check the packed reciprocal spacings against numpy, the argument
+    checks of the device entry points (refused before any HIP call), and that CPU tensors are refused loudly."""
+    import numpy as np
+    from pde_policylearning_amd import _lib
+    from pde_policylearning_amd.libs.envs.control_env import ChannelFlowRHS
+    env = ChannelFlowRHS.tanh_channel(8, 10, 6)
+    Ny, MP = 10, 12
+    assert env.yg.shape == (Ny + 1,) and env.yg[0] == -env.ym[0] and env.yg[-1] == 2 + env.ym[0]      # control_env.py:165
+    packed = np.zeros(3 * MP)
+    dp = ctypes.POINTER(ctypes.c_double)
+    assert lib.fno_chanflow_pack_metrics(Ny, env.y.ctypes.data_as(dp), env.ym.ctypes.data_as(dp), env.yg.ctypes.data_as(dp),
+                                         packed.ctypes.data_as(dp)) == 0
+    want = np.zeros(3 * MP)
+    want[1:Ny] = 1 / np.diff(env.y)
+    want[MP + 1:MP + Ny - 1] = 1 / np.diff(env.ym)
+    want[2 * MP + 1:2 * MP + Ny + 1] = 1 / np.diff(env.yg)
+    assert np.array_equal(packed, want)
+    y_bad = env.y.copy()
+    y_bad[3] = y_bad[2]
+    assert lib.fno_chanflow_pack_metrics(Ny, y_bad.ctypes.data_as(dp), env.ym.ctypes.data_as(dp), env.yg.ctypes.data_as(dp),
+                                         packed.ctypes.data_as(dp)) < 0
+    assert b"repeated" in lib.fno_last_error()
+    g = _lib.FnoChanflowGrid(8, 2, 6, 0.1, 0.1, 1e-3)                         # Ny < 3
+    assert lib.fno_chanflow_rhs(ctypes.byref(g), 1, 0, packed.ctypes.data, None, None, None, None, 0.0, None, None, None, None) < 0
+    assert ctypes.sizeof(_lib.FnoChanflowGrid) == 3 * 4 + 4 + 3 * 8           # 3 ints, padding, 3 doubles
+    U, V, W = torch.zeros(8, 11, 6), torch.zeros(8, 10, 6), torch.zeros(8, 11, 6)
+    with pytest.raises(RuntimeError, match="GPU"):
+        env.compute_rhs_py(U, V, W)
+    with pytest.raises(RuntimeError, match="GPU"):
+        env.pde_loss(U, V, V, W)
+    with pytest.raises(RuntimeError, match="expected U, W"):
+        env.pde_loss(U, V, V, W[:, :-1])
