@@ -416,6 +416,45 @@ def gen_pde_dataset(outdir):
          p_patch=torch.stack([a for a, _ in patch_items]), v_patch=torch.stack([b for _, b in patch_items]))
 
 
+def fullfield_folder(d, n_files=4, Nx=6, Ny=8, Nz=5, seed=11):
+    """A tiny folder in the FullFieldNSDataset on-disk format (U/W (Nx, Ny+1, Nz), V (Nx, Ny, Nz) per timestep + metadata.npy)."""
+    rng = np.random.default_rng(seed)
+    f = {"U_field": rng.standard_normal((n_files, Nx, Ny + 1, Nz)).astype(np.float32) + 1,
+         "V_field": rng.standard_normal((n_files, Nx, Ny, Nz)).astype(np.float32) * 0.4 - 0.1,
+         "W_field": rng.standard_normal((n_files, Nx, Ny + 1, Nz)).astype(np.float32) * 0.3}
+    meta = {k: dict(mean=v.mean(0), std=v.std(0)) for k, v in f.items()}
+    meta["U_field"]["dpdx"] = [float(x) for x in rng.uniform(0.002, 0.004, n_files)]
+    meta["re"] = 178.1899
+    p = rng.standard_normal((n_files, Nx, Nz)).astype(np.float32)
+    meta["P_planes"] = dict(mean=p.mean(0), std=p.std(0))
+    for k, v in f.items():
+        for i in range(n_files):
+            np.save(os.path.join(d, f"{k}_{i:06d}.npy"), v[i])
+    np.save(os.path.join(d, "metadata.npy"), meta, allow_pickle=True)
+    return f, meta
+
+
+def gen_fullfield_dataset(outdir):
+    """FullFieldNSDataset items from the reference's own class (libs/pde_data_loader.py:135-198); `.cuda()` patched to the
+    identity as in gen_pde_dataset."""
+    import tempfile
+    import types
+    from libs.pde_data_loader import FullFieldNSDataset
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            f, meta = fullfield_folder(d)
+            idx, planes = [2, 0, 3, 1], [-3, -2, 1]
+            ds = FullFieldNSDataset(types.SimpleNamespace(model_timestep=2), d, idx, planes, 1, 6, 5)
+            items = [ds[i] for i in range(len(ds))]
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    names = ["v_plane", "v_field", "u", "v", "w", "re", "dpdx"]
+    save(os.path.join(outdir, "fullfield_dataset.npz"), data_index=np.array(idx), plane_indexs=np.array(planes),
+         **{n: torch.stack([it[k] for it in items]) for k, n in enumerate(names)})
+
+
 def chanflow_inputs(tag, Nx, Ny, Nz, dtype=torch.float32):
     """U, Vgt, V, W of one deterministic channel-flow sample (shared with the tests via oracle.detfill)."""
     U = 1.0 + input_fill(f"chanflow.U.{tag}", (Nx, Ny + 1, Nz), 0.5)
@@ -465,7 +504,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_chanflow]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_chanflow]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

@@ -1,11 +1,14 @@
 """Observer training loop: the counterpart of run_pde_observers.py:66-240 (dataset split, loaders, model choice, Adam,
-LpLoss on decoded fields, per-epoch train / test relative L2) for the `PDEDataset` path, with every hot step in the engine:
+LpLoss on decoded fields, per-epoch train / test relative L2) for the `PDEDataset` path and the `FullFieldNSDataset` path
+(plane-prediction observer + physics-informed channel-flow term, :200-231), with every hot step in the engine:
 asynchronous input staging (trainer.DevicePrefetcher), the fused FNO model or the engine-backed RNO, fused decode + loss,
 flat-bucket Adam, optional data parallelism (one process per GPU, overlapped RCCL all-reduce).  No W&B, no MATLAB control
 environment (out of scope).
 
   python -m pde_policylearning_amd.train_observer --data-folder DIR --ntrain 800 --ntest 200 --modes 12 --width 64 \\
          --x-range 128 --y-range 128 --batch-size 64 --epochs 5 [--model FNO2dObserver|RNO2dObserver]
+  python -m pde_policylearning_amd.train_observer --data-folder DIR --ntrain 800 --ntest 200 --dataset FullFieldNSDataset \
+         --model PINObserverFullField --modes 12 --width 64 --plane-indexs -10 -8 -6 --pde-loss-weight 1.0 [--init-cond-path F.mat]
   (N GPUs: python -m torch.distributed.run --nproc-per-node N -m pde_policylearning_amd.train_observer ...)
 """
 import argparse
@@ -19,9 +22,9 @@ from torch.utils.data import DataLoader
 
 from .libs.models.fno_models import FNO2dObserver
 from .libs.models.rno_models import RNO2dObserver
-from .libs.pde_data_loader import PDEDataset
-from .trainer import (DevicePrefetcher, FlatGradBucket, FusedAdam, FusedLpLoss, MeanStdDecoder, broadcast_parameters,
-                      shard_batch, train_step)
+from .libs.pde_data_loader import FullFieldNSDataset, PDEDataset
+from .trainer import (DevicePrefetcher, FlatGradBucket, FullFieldObjective, FusedAdam, FusedLpLoss, MeanStdDecoder,
+                      broadcast_parameters, shard_batch, train_step)
 
 
 def build_parser():
@@ -30,7 +33,14 @@ def build_parser():
     ap.add_argument("--ntrain", type=int, required=True)
     ap.add_argument("--ntest", type=int, required=True)
     ap.add_argument("--random-split", action="store_true")          # run_pde_observers.py:69-72
-    ap.add_argument("--model", default="FNO2dObserver", choices=["FNO2dObserver", "RNO2dObserver"])
+    ap.add_argument("--model", default="FNO2dObserver", choices=["FNO2dObserver", "RNO2dObserver", "PINObserverFullField"])
+    ap.add_argument("--dataset", default="PDEDataset", choices=["PDEDataset", "FullFieldNSDataset"])   # configs/matlab_rno.yaml:21-22
+    ap.add_argument("--plane-indexs", type=int, nargs="+", default=[-10, -8, -6])                     # :62
+    ap.add_argument("--pde-loss-weight", type=float, default=0.0)                                     # :56
+    ap.add_argument("--init-cond-path", default=None, help=".mat initial condition holding the grid (x, y, z, ym); "
+                    "default: the analytic tanh channel grid matching the data's shape")
+    ap.add_argument("--Re", type=float, default=-1.0)
+    ap.add_argument("--model-timestep", type=int, default=1)
     ap.add_argument("--modes", type=int, default=12)
     ap.add_argument("--width", type=int, default=32)
     ap.add_argument("--layer-num", type=int, default=1)
@@ -58,6 +68,8 @@ def run(args, log=print):
     torch.manual_seed(args.seed)
     n = args.ntrain + args.ntest
     idx = torch.randperm(n) if args.random_split else torch.arange(n)
+    if args.dataset == "FullFieldNSDataset":
+        return run_full_field(args, idx, dev, rank, world, log)
     ds_args = types.SimpleNamespace(model_timestep=1)
     train_ds = PDEDataset(ds_args, args.data_folder, idx[:args.ntrain].tolist(), args.downsample_rate, args.x_range, args.y_range)
     test_ds = PDEDataset(ds_args, args.data_folder, idx[-args.ntest:].tolist(), args.downsample_rate, args.x_range, args.y_range)
@@ -105,6 +117,65 @@ def run(args, log=print):
         history.append(rec)
         if rank == 0:
             log(f"epoch {ep}: train rel-L2 {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
+    return history
+
+
+def run_full_field(args, idx, dev, rank, world, log):
+    """run_pde_observers.py:200-231 + its eval twin: PINObserverFullField predicts `plane_indexs` planes of v from the wall
+    plane; loss = LpLoss(decoded planes) + pde_loss_weight * channel-flow physics term."""
+    from .libs.envs.control_env import ChannelFlowRHS
+    from .libs.models.pino_models import PINObserverFullField
+    ds_args = types.SimpleNamespace(model_timestep=args.model_timestep)
+    mk = lambda ix: FullFieldNSDataset(ds_args, args.data_folder, ix.tolist(), args.plane_indexs, args.downsample_rate,
+                                       args.x_range, args.y_range)
+    train_ds, test_ds = mk(idx[:args.ntrain]), mk(idx[-args.ntest:])
+    train_loader = DataLoader(train_ds, batch_size=args.batch_size * world, shuffle=False, drop_last=True)
+    test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
+    P, L = len(args.plane_indexs), 4
+    model = PINObserverFullField(plane_num=P, modes1=[args.modes] * L, modes2=[args.modes] * L, modes3=[args.modes] * L,
+                                 fc_dim=128, layers=[args.width] * (L + 1), in_dim=1, out_dim=1, act="gelu",
+                                 pad_ratio=[0.0, 0.0625]).to(dev)                   # run_pde_observers.py:117-131
+    broadcast_parameters(model)
+    bucket = FlatGradBucket(model.parameters())
+    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)
+    env = None
+    if args.pde_loss_weight > 0:
+        Nx, Ny, Nz = train_ds[0][3].shape[1:]
+        env = (ChannelFlowRHS.from_mat(args.init_cond_path, Re=args.Re) if args.init_cond_path
+               else ChannelFlowRHS.tanh_channel(Nx, Ny, Nz, Re=args.Re))
+        if (env.Nx, env.Ny, env.Nz) != (Nx, Ny, Nz):
+            raise RuntimeError(f"grid {env.Nx, env.Ny, env.Nz} of {args.init_cond_path} does not match the fields {Nx, Ny, Nz}")
+    norm = train_ds.bound_v_norm
+    decoder = MeanStdDecoder(norm.mean.numpy(), norm.std.numpy(), eps=norm.eps, device=dev)
+    objective = FullFieldObjective(decoder, args.plane_indexs, env, args.pde_loss_weight)
+    forward = lambda plane, re: model(plane.permute(0, 2, 3, 1).unsqueeze(-1), re)     # 'btxy -> bxyt', + channel  (:204)
+    history = []
+    for ep in range(args.epochs):
+        model.train()
+        t0 = time.perf_counter()
+        tot, cnt = torch.zeros((), device=dev), 0
+        for batch in DevicePrefetcher(train_loader, dev):
+            if world > 1:
+                batch = [shard_batch(t, rank, world) for t in batch]
+            v_plane, v_field, U, V, W, re, _dpdx = [t.float() for t in batch]
+            tot += train_step(forward, bucket, opt, (v_plane, re), (v_field, U, V, W), objective)
+            cnt += v_plane.shape[0]
+        if world > 1:
+            dist.all_reduce(tot)
+            cnt *= world
+        model.eval()
+        test_tot, test_cnt = torch.zeros((), device=dev), 0
+        with torch.no_grad():
+            for batch in DevicePrefetcher(test_loader, dev):
+                v_plane, v_field, U, V, W, re, _dpdx = [t.float() for t in batch]
+                objective(forward(v_plane, re), (v_field, U, V, W))
+                test_tot += objective.last_terms[0]                                  # test metric: the data term
+                test_cnt += v_plane.shape[0]
+        rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
+                   seconds=time.perf_counter() - t0)
+        history.append(rec)
+        if rank == 0:
+            log(f"epoch {ep}: train loss {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
     return history
 
 

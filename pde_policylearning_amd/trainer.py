@@ -69,6 +69,39 @@ class MeanStdDecoder(object):
         return x * (self.std + self.eps) + self.mean
 
 
+class FullFieldObjective(object):
+    """Loss of the FullFieldNSDataset branch of the observer loop (run_pde_observers.py:207-231):
+    data term = LpLoss over the decoded target planes, physics term = pde_loss_weight * sum_b pde_loss(U_b, V_b, V_b with the
+    predicted planes written in, W_b) on the channel-flow RHS kernels (libs/envs/control_env.ChannelFlowRHS).
+
+    __call__(pred_raw, batch): pred_raw (B, P, X, Z, T) model output; batch = (v_field (B, T, P, X, Z) normalised targets,
+    U (B, T, Nx, Ny+1, Nz), V (B, T, Nx, Ny, Nz), W).  The reference squeezes T (only T = 1 runs there); here T folds into
+    the batch of the physics term."""
+
+    def __init__(self, decoder, plane_indexs, env=None, pde_loss_weight=0.0, data_loss=None):
+        self.decoder, self.plane_indexs = decoder, list(plane_indexs)
+        self.env, self.weight = env, float(pde_loss_weight)
+        self.data_loss = data_loss if data_loss is not None else FusedLpLoss(size_average=False)
+        if self.weight > 0 and env is None:
+            raise ValueError("pde_loss_weight > 0 needs the channel grid (ChannelFlowRHS)")
+        self.last_terms = None
+
+    def __call__(self, pred_raw, batch):
+        v_field, U, V, W = batch
+        B = pred_raw.shape[0]
+        pred = self.decoder.decode(pred_raw.permute(0, 4, 1, 2, 3))           # 'bpxzt -> btpxz', then x * (std + eps) + mean
+        target = self.decoder.decode(v_field)
+        loss = self.data_loss(pred.reshape(B, -1), target.reshape(B, -1))
+        self.last_terms = (loss.detach(), None)
+        if self.weight > 0:
+            full = V.clone()
+            full[:, :, :, self.plane_indexs, :] = pred.permute(0, 1, 3, 2, 4).to(full.dtype)      # (B, T, X, P, Z)
+            pde = self.env.pde_loss(U.flatten(0, 1), V.flatten(0, 1), full.flatten(0, 1), W.flatten(0, 1))
+            self.last_terms = (self.last_terms[0], pde.detach())
+            loss = loss + self.weight * pde
+        return loss
+
+
 class FlatGradBucket(object):
     """All parameter gradients live in ONE contiguous buffer (p.grad are views into it), so
     the data-parallel exchange is a single all-reduce(SUM) - sized for xGMI: one 9.6 MB message

@@ -170,3 +170,48 @@ def test_chanflow_host_side_without_gpu(lib):
         env.pde_loss(U, V, V, W)
     with pytest.raises(RuntimeError, match="expected U, W"):
         env.pde_loss(U, V, V, W[:, :-1])
+
+
+def _write_fullfield_folder(d, g):
+    """rebuild the folder the fixture was generated from out of the raw fields the reference's items carry"""
+    import numpy as np
+    idx = [int(i) for i in g["data_index"]]
+    T = g["u"].shape[1]
+    raw = {k: [None] * len(idx) for k in ("u", "v", "w")}
+    dpdx = [0.0] * len(idx)
+    for item in range(g["u"].shape[0]):
+        for t in range(T):
+            i = idx[item * T + t]
+            for k in raw:
+                raw[k][i] = g[k][item, t]
+            dpdx[i] = float(g["dpdx"][item, t])
+    f = {"U_field": np.stack(raw["u"]), "V_field": np.stack(raw["v"]), "W_field": np.stack(raw["w"])}
+    meta = {k: dict(mean=v.mean(0), std=v.std(0)) for k, v in f.items()}
+    meta["U_field"]["dpdx"] = dpdx
+    meta["re"] = float(g["re"][0, 0])
+    meta["P_planes"] = dict(mean=np.zeros(f["V_field"].shape[1::2], np.float32), std=np.ones(f["V_field"].shape[1::2], np.float32))
+    for k, v in f.items():
+        for i in range(v.shape[0]):
+            np.save(os.path.join(d, f"{k}_{i:06d}.npy"), v[i])
+    np.save(os.path.join(d, "metadata.npy"), meta, allow_pickle=True)
+    return idx
+
+
+def test_fullfield_dataset_matches_reference_items(tmp_path):
+    """libs.pde_data_loader.FullFieldNSDataset vs items of the reference class (tests/golden/fullfield_dataset.npz,
+    oracle/make_golden.py::gen_fullfield_dataset): wall plane + target planes normalised by the wall-plane statistics,
+    raw U / V / W, Re and dPdx per timestep."""
+    import types
+    import numpy as np
+    from tests.util import load_golden
+    from pde_policylearning_amd.libs.pde_data_loader import FullFieldNSDataset
+    g = load_golden("fullfield_dataset")
+    idx = _write_fullfield_folder(str(tmp_path), g)
+    ds = FullFieldNSDataset(types.SimpleNamespace(model_timestep=2), str(tmp_path), idx, [int(p) for p in g["plane_indexs"]], 1, 6, 5)
+    assert len(ds) == g["u"].shape[0]
+    for i in range(len(ds)):
+        item = ds[i]
+        for got, name in zip(item, ["v_plane", "v_field", "u", "v", "w", "re", "dpdx"]):
+            want = g[name][i]
+            assert tuple(got.shape) == want.shape, name
+            assert np.allclose(got.numpy(), want, rtol=0, atol=0 if name in ("u", "v", "w") else 1e-6), name
