@@ -36,6 +36,8 @@ CONFIGS = {
     "rno2d_128x128_w64_m12_b32": dict(kind="rno2d", batch=32, size=(128, 128)),            # cfg 3 as named (256 / 8 GPUs)
     "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32)),        # configs/matlab_rno.yaml values
     "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32)),     # the YAML's active model
+    # the same model with the loop's loss: decode + LpLoss on the planes + pde_loss_weight 1.0 * channel-flow term (matlab_rno.yaml:56,62)
+    "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32)),
     "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
 }
 
@@ -128,7 +130,7 @@ def main():
         inputs = (x,)
     else:
         from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
-        if cfg["kind"] == "pino_ff":     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
+        if cfg["kind"] in ("pino_ff", "pino_ff_pde"):     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
             model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
                                          layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
             x = torch.randn((B,) + cfg["size"] + (1, 1), generator=gen).to(dev)
@@ -150,6 +152,14 @@ def main():
         bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
     opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
+    if cfg["kind"] == "pino_ff_pde":                           # run_pde_observers.py:207-231 on a 32 x 130 x 32 channel
+        from pde_policylearning_amd.libs.envs.control_env import ChannelFlowRHS
+        from pde_policylearning_amd.trainer import FullFieldObjective, MeanStdDecoder
+        env = ChannelFlowRHS.tanh_channel(32, 130, 32)
+        rnd = lambda *sh: torch.randn(sh, generator=gen).to(dev)
+        decoder = MeanStdDecoder(0.1 * rnd(32, 32), 0.5 + torch.rand((32, 32), generator=gen).to(dev), device=dev)
+        loss_fn = FullFieldObjective(decoder, [-10, -8, -6], env, 1.0)
+        tgt = (rnd(B, 1, 3, 32, 32), 1 + 0.5 * rnd(B, 1, 32, 131, 32), 0.3 * rnd(B, 1, 32, 130, 32), 0.3 * rnd(B, 1, 32, 131, 32))
     if not fused_model:
         args.no_cpu_baseline = True
 
@@ -280,7 +290,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": {"2d": "FNO2d", "3d": "FNO3d", "rno2d": "RNO2d", "rno2d_shipped": "RNO2d", "pino_ff": "PINObserverFullField",
+            "metric": {"2d": "FNO2d", "3d": "FNO3d", "rno2d": "RNO2d", "rno2d_shipped": "RNO2d", "pino_ff": "PINObserverFullField", "pino_ff_pde": "PINObserverFullField+pde_loss",
                        "pino2d": "PINObserver2d"}[cfg["kind"]] + " fwd+bwd fields/sec",
             "value": round(fields_per_s, 2),
             "unit": "fields/s",
@@ -294,7 +304,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
-                       "step": "zero_grad+fwd+LpLoss(sum)+bwd" +
+                       "step": "zero_grad+fwd+" + ("decode+LpLoss(sum)+channel-flow pde_loss" if cfg["kind"] == "pino_ff_pde" else "LpLoss(sum)") + "+bwd" +
                                ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,

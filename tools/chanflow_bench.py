@@ -103,6 +103,12 @@ def loss_engine():
 fbytes = 4 * B * Nx * Nz
 rhs_bytes = fbytes * (3 * (Ny + 1) + 3 * Ny + 2)            # U, V, W in; Fu, Fv, Fw out
 loss_bytes = fbytes * ((4 * Ny + 2) + (3 * Ny + 2)) + fbytes * ((4 * Ny + 2) + (3 * Ny + 2) + Ny)   # fwd: 4 in, 3 D out; bwd: 4 + 3 D in, dV out
+if os.environ.get("ENGINE_ONLY"):          # for rocprofv3 --kernel-trace --stats: just the engine launches
+    with torch.no_grad():
+        timeit(lambda: F.chanflow_rhs(env.grid, U, V, W, env.dPdx), 50)
+        timeit(lambda: F.chanflow_rhs(env.grid, U.double(), V.double(), W.double(), env.dPdx), 10)
+    timeit(loss_engine, 50)
+    sys.exit(0)
 with torch.no_grad():
     t_e = timeit(lambda: F.chanflow_rhs(env.grid, U, V, W, env.dPdx), 50)
     t_v = timeit(lambda: rhs_vec(U, V, W, env.dPdx), 20)
