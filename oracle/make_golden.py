@@ -455,6 +455,30 @@ def gen_fullfield_dataset(outdir):
          **{n: torch.stack([it[k] for it in items]) for k, n in enumerate(names)})
 
 
+def gen_kf_dataset(outdir):
+    """MultipleReynoldsKFaDataset items from the reference's own class (libs/pino_utils/datasets.py:548-617) on a tiny
+    multi-Reynolds .npz; its leftover pdb.set_trace() (:588) is patched to a no-op."""
+    import pdb
+    import tempfile
+    from libs.pino_utils.datasets import MultipleReynoldsKFaDataset
+    pdb.set_trace = lambda *a, **k: None
+    rng = np.random.default_rng(3)
+    raw = rng.standard_normal((4, 9, 8, 8)).astype(np.float32)
+    res = np.array([300.0, 400.0, 500.0, 600.0], dtype=np.float32)
+    out = {"raw": raw, "re_file": res}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "multi_reynolds_tiny.npz")
+        np.savez(path, data1=raw, data2=res)
+        for tag, kw in {"half": dict(data_res=[8, 8, 9], pde_res=[8, 8, 9], t_duration=0.5, n_samples=2, offset=1),
+                        "quarter_sub": dict(data_res=[4, 4, 9], pde_res=[4, 4, 9], t_duration=0.25, n_samples=3, offset=0)}.items():
+            ds = MultipleReynoldsKFaDataset(paths=[path], raw_res=[8, 8, 9], **kw)
+            items = [ds[i] for i in range(len(ds))]
+            out[f"{tag}_u"] = torch.stack([it[0] for it in items])
+            out[f"{tag}_a"] = torch.stack([it[1] for it in items])
+            out[f"{tag}_re"] = np.array([float(it[2]) for it in items])
+    save(os.path.join(outdir, "kf_dataset.npz"), **out)
+
+
 def chanflow_inputs(tag, Nx, Ny, Nz, dtype=torch.float32):
     """U, Vgt, V, W of one deterministic channel-flow sample (shared with the tests via oracle.detfill)."""
     U = 1.0 + input_fill(f"chanflow.U.{tag}", (Nx, Ny + 1, Nz), 0.5)
@@ -504,7 +528,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_chanflow]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

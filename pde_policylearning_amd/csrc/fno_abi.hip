@@ -1197,13 +1197,21 @@ static int chanflow_geo(const FnoChanflowGrid* g, int B, const double* metrics, 
   out->rdx = 1.0 / g->dx; out->rdz = 1.0 / g->dz; out->nu = g->nu; out->metrics = metrics;
   return FNO_OK;
 }
+// slabs are split along y so that the launch carries ~8 waves per SIMD (one slab per workgroup leaves 4)
+static int chanflow_ysplit(int B, int Nx) {
+  static const int forced = getenv("FNO_CF_SPLIT") ? atoi(getenv("FNO_CF_SPLIT")) : 0;
+  if (forced > 0) return forced;
+  const long wgs = (long)B * Nx, want = (long)dev_ncu() * 8;
+  long s = (want + wgs - 1) / wgs;
+  return (int)std::max(1L, std::min(s, 16L));
+}
 template <typename T>
 static int chanflow_rhs_t(const ChanflowGeo& geo, const void* U, const void* V, const void* W, const void* dpdx,
                           double dpdx_default, void* Fu, void* Fv, void* Fw, hipStream_t st) {
   ChanflowRhsArgs<T> a;
   a.U = (const T*)U; a.V = (const T*)V; a.W = (const T*)W; a.dPdx = (const T*)dpdx;
   a.Fu = (T*)Fu; a.Fv = (T*)Fv; a.Fw = (T*)Fw; a.dPdx_default = (T)dpdx_default;
-  return launch("k_chanflow_rhs", k_chanflow_rhs<T>, dim3((unsigned)(geo.B * geo.Nx)), dim3(256), 0, st, geo, a);
+  return launch("k_chanflow_rhs", k_chanflow_rhs<T>, dim3((unsigned)(geo.B * geo.Nx), chanflow_ysplit(geo.B, geo.Nx)), dim3(256), 0, st, geo, a);
 }
 extern "C" int fno_chanflow_rhs(const FnoChanflowGrid* grid, int B, int dtype, const double* metrics, const void* U,
                                 const void* V, const void* W, const void* dpdx, double dpdx_default, void* Fu, void* Fv,
@@ -1224,7 +1232,7 @@ static ChanflowWs carve_chanflow(const FnoChanflowGrid* g, int B, void* ws, size
   w.Du = p; p += up(su);
   w.Dw = p; p += up(su);
   w.Dv = p; p += up(sv);
-  w.partial = p; p += up((size_t)B * g->Nx * 3);
+  w.partial = p; p += up((size_t)B * g->Nx * 16 * 3);
   w.inv_norm = p; p += up((size_t)B * 3);
   w.total = (size_t)((char*)p - (char*)ws);
   w.ok = ws_bytes >= w.total;
@@ -1246,8 +1254,9 @@ extern "C" int fno_chanflow_pde_loss_forward(const FnoChanflowGrid* grid, int B,
   ChanflowLossArgs a;
   memset(&a, 0, sizeof(a));
   a.U = U; a.Vgt = Vgt; a.V = V; a.W = W; a.Du = w.Du; a.Dv = w.Dv; a.Dw = w.Dw; a.partial = w.partial;
-  LAUNCHCHK(launch("k_chanflow_diff", k_chanflow_diff, dim3((unsigned)(B * grid->Nx)), dim3(256), 0, st, geo, a));
-  LAUNCHCHK(launch("k_chanflow_finish", k_chanflow_finish, dim3(1), dim3(256), 0, st, B, grid->Nx, (const float*)w.partial,
+  const int ys = chanflow_ysplit(B, grid->Nx);
+  LAUNCHCHK(launch("k_chanflow_diff", k_chanflow_diff, dim3((unsigned)(B * grid->Nx), ys), dim3(256), 0, st, geo, a));
+  LAUNCHCHK(launch("k_chanflow_finish", k_chanflow_finish, dim3(1), dim3(256), 0, st, B, grid->Nx * ys, (const float*)w.partial,
                    w.inv_norm, loss));
   return FNO_OK;
 }
@@ -1263,7 +1272,7 @@ extern "C" int fno_chanflow_pde_loss_backward(const FnoChanflowGrid* grid, int B
   memset(&a, 0, sizeof(a));
   a.U = U; a.Vgt = Vgt; a.V = V; a.W = W; a.Du = w.Du; a.Dv = w.Dv; a.Dw = w.Dw; a.inv_norm = w.inv_norm;
   a.gloss = gloss; a.dV = dV;
-  return launch("k_chanflow_diff_bwd", k_chanflow_diff_bwd, dim3((unsigned)(B * grid->Nx)), dim3(256), 0, (hipStream_t)stream,
+  return launch("k_chanflow_diff_bwd", k_chanflow_diff_bwd, dim3((unsigned)(B * grid->Nx), chanflow_ysplit(B, grid->Nx)), dim3(256), 0, (hipStream_t)stream,
                 geo, a);
 }
 

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void k_chanflow_rhs(ChanflowGeo g, ChanflowRhs
   const T half_dpdx = h * (a.dPdx ? a.dPdx[b] : a.dPdx_default);
   const double *rdy = g.metrics, *rdym = g.metrics + MP, *rdyg = g.metrics + 2 * MP;
 
-  for (int idx = threadIdx.x; idx < (Ny + 1) * Nz; idx += blockDim.x) {
+  const int npts = (Ny + 1) * Nz, per = (npts + gridDim.y - 1) / gridDim.y, hi = min(npts, (int)(blockIdx.y + 1) * per);
+  for (int idx = blockIdx.y * per + threadIdx.x; idx < hi; idx += blockDim.x) {
     const int j = idx / Nz, k = idx - j * Nz;
     const int kzm = k ? k - 1 : Nz - 1, kzp = (k + 1 == Nz) ? 0 : k + 1;
     const int r = j * Nz;                       // row offset (same for the U/W and V layouts)
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256) void k_chanflow_diff(ChanflowGeo g, ChanflowLo
   const double *rdy = g.metrics, *rdym = g.metrics + MP;
   float su2 = 0.f, sv2 = 0.f, sw2 = 0.f;
 
-  for (int idx = threadIdx.x; idx < (Ny + 1) * Nz; idx += blockDim.x) {
+  const int npts = (Ny + 1) * Nz, per = (npts + gridDim.y - 1) / gridDim.y, hi = min(npts, (int)(blockIdx.y + 1) * per);
+  for (int idx = blockIdx.y * per + threadIdx.x; idx < hi; idx += blockDim.x) {
     const int j = idx / Nz, k = idx - j * Nz;
     const int kzm = k ? k - 1 : Nz - 1, kzp = (k + 1 == Nz) ? 0 : k + 1;
     const int r = j * Nz;
@@ -205,11 +207,11 @@ __global__ __launch_bounds__(256) void k_chanflow_diff(ChanflowGeo g, ChanflowLo
   if ((threadIdx.x & 63) == 0) { red[0][wv] = su2; red[1][wv] = sv2; red[2][wv] = sw2; }
   __syncthreads();
   if (threadIdx.x < 3)
-    a.partial[(size_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    a.partial[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
 // one workgroup: per-sample norms (double accumulation over the Nx slab partials), their reciprocals for the backward, the loss
-__global__ __launch_bounds__(256) void k_chanflow_finish(int B, int Nx, const float* partial, float* inv_norm, float* loss) {
+__global__ __launch_bounds__(256) void k_chanflow_finish(int B, int Nx /* partials per sample */, const float* partial, float* inv_norm, float* loss) {
   double acc = 0.0;
   for (int t = threadIdx.x; t < B * 3; t += blockDim.x) {
     const int b = t / 3, c = t - 3 * b;
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(256) void k_chanflow_diff_bwd(ChanflowGeo g, Chanfl
   const float nx2 = nu * rdx * rdx, nz2 = nu * rdz * rdz;
   const double *rdy = g.metrics, *rdym = g.metrics + MP;
 
-  for (int idx = threadIdx.x; idx < Ny * Nz; idx += blockDim.x) {
+  const int npts = Ny * Nz, per = (npts + gridDim.y - 1) / gridDim.y, hi = min(npts, (int)(blockIdx.y + 1) * per);
+  for (int idx = blockIdx.y * per + threadIdx.x; idx < hi; idx += blockDim.x) {
     const int j = idx / Nz, k = idx - j * Nz;
     const int kzm = k ? k - 1 : Nz - 1, kzp = (k + 1 == Nz) ? 0 : k + 1;
     const int r = j * Nz;

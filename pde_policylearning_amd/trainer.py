@@ -102,6 +102,65 @@ class FullFieldObjective(object):
         return loss
 
 
+class MultiStepLR(object):
+    """torch.optim.lr_scheduler.MultiStepLR for FusedAdam (train_pino.py:201-203): lr = base * gamma ** #(milestones <= epoch)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, last_epoch=0):
+        self.optimizer, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.base_lr, self.last_epoch = optimizer.lr, last_epoch
+        self._apply()
+
+    def _apply(self):
+        self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+    def state_dict(self):
+        return dict(milestones=self.milestones, gamma=self.gamma, base_lr=self.base_lr, last_epoch=self.last_epoch)
+
+    def load_state_dict(self, sd):
+        self.milestones, self.gamma, self.base_lr, self.last_epoch = sd["milestones"], sd["gamma"], sd["base_lr"], sd["last_epoch"]
+        self._apply()
+
+
+class PinoObjective(object):
+    """Loss of the PINO fine-tuning step (train_pino.py:86-106): xy_weight * LpLoss(out, u) + f_weight * loss_f +
+    ic_weight * loss_ic, the last two from the Navier-Stokes vorticity residual of the model output (engine kernels,
+    libs.envs.diff_control_env.Channelflow_PINO_loss).  The reference evaluates the model twice when both the data and the
+    PDE term are on (same input, same weights: identical outputs); here it is evaluated once.
+
+    __call__(out, (u, a_in, re)): out (B, S, S, T, 1), u (B, S, S, T), a_in (B, S, S, T, 4) whose last channel at t = 0 is
+    the initial condition, re (B,)."""
+
+    def __init__(self, forcing, t_duration, ic_weight, f_weight, xy_weight, scale=1.0):
+        self.forcing, self.t_duration = forcing, t_duration
+        self.ic_weight, self.f_weight, self.xy_weight, self.scale = ic_weight, f_weight, xy_weight, scale
+        self.lploss = FusedLpLoss(size_average=True)
+        self.last_terms = {}
+
+    def __call__(self, out, batch):
+        from .libs.envs.diff_control_env import Channelflow_PINO_loss
+        u, a_in, re = batch
+        loss = 0.0
+        self.last_terms = {}
+        if self.xy_weight > 0:
+            data_loss = self.lploss(out.reshape(u.shape), u)
+            self.last_terms["data"] = data_loss.detach()
+            loss = loss + self.xy_weight * data_loss
+        if self.f_weight != 0.0:
+            loss_ic, loss_f = Channelflow_PINO_loss(out, a_in[:, :, :, 0, -1], self.forcing, 1.0 / re.float(), self.t_duration)
+            self.last_terms["IC"], self.last_terms["PDE"] = loss_ic.detach(), loss_f.detach()
+            loss = loss + self.f_weight * loss_f + self.ic_weight * loss_ic
+        if not torch.is_tensor(loss):
+            raise ValueError("PinoObjective: every loss weight is zero")
+        return loss * self.scale if self.scale != 1.0 else loss
+
+
 class FlatGradBucket(object):
     """All parameter gradients live in ONE contiguous buffer (p.grad are views into it), so
     the data-parallel exchange is a single all-reduce(SUM) - sized for xGMI: one 9.6 MB message

@@ -215,3 +215,45 @@ def test_fullfield_dataset_matches_reference_items(tmp_path):
             want = g[name][i]
             assert tuple(got.shape) == want.shape, name
             assert np.allclose(got.numpy(), want, rtol=0, atol=0 if name in ("u", "v", "w") else 1e-6), name
+
+
+def test_kf_dataset_matches_reference_items(tmp_path):
+    """libs.pino_utils.datasets.MultipleReynoldsKFaDataset vs items of the reference class (tests/golden/kf_dataset.npz):
+    windowing by t_duration, spatial subsampling, the (x, y, t, u0) input grid, the per-window Reynolds number."""
+    import numpy as np
+    from tests.util import load_golden
+    from pde_policylearning_amd.libs.pino_utils.datasets import MultipleReynoldsKFaDataset, sample_data
+    g = load_golden("kf_dataset")
+    path = os.path.join(tmp_path, "multi_reynolds_tiny.npz")
+    np.savez(path, data1=g["raw"], data2=g["re_file"])
+    for tag, kw in {"half": dict(data_res=[8, 8, 9], pde_res=[8, 8, 9], t_duration=0.5, n_samples=2, offset=1),
+                    "quarter_sub": dict(data_res=[4, 4, 9], pde_res=[4, 4, 9], t_duration=0.25, n_samples=3, offset=0)}.items():
+        ds = MultipleReynoldsKFaDataset(paths=[path], raw_res=[8, 8, 9], **kw)
+        assert len(ds) == g[f"{tag}_u"].shape[0]
+        for i in range(len(ds)):
+            u, a, re = ds[i]
+            assert np.array_equal(u.numpy(), g[f"{tag}_u"][i]) and np.array_equal(a.numpy(), g[f"{tag}_a"][i])
+            assert float(re) == g[f"{tag}_re"][i]
+    it = sample_data([1, 2])
+    assert [next(it) for _ in range(5)] == [1, 2, 1, 2, 1]
+
+
+def test_multistep_lr_matches_torch():
+    """trainer.MultiStepLR (for FusedAdam) follows torch.optim.lr_scheduler.MultiStepLR step for step, including a resume."""
+    import types
+    from pde_policylearning_amd.trainer import MultiStepLR
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.Adam([p], lr=0.0025)
+    tsch = torch.optim.lr_scheduler.MultiStepLR(topt, milestones=[3, 5, 9], gamma=0.5)
+    opt = types.SimpleNamespace(lr=0.0025)
+    sch = MultiStepLR(opt, milestones=[5, 3, 9], gamma=0.5)
+    for i in range(12):
+        assert abs(opt.lr - topt.param_groups[0]["lr"]) < 1e-15, i
+        topt.step()
+        tsch.step()
+        sch.step()
+        if i == 6:
+            opt2 = types.SimpleNamespace(lr=123.0)
+            sch2 = MultiStepLR(opt2, milestones=[1], gamma=0.1)
+            sch2.load_state_dict(sch.state_dict())
+            assert opt2.lr == opt.lr and sch2.last_epoch == 7

@@ -1032,3 +1032,52 @@ def test_train_observer_full_field_branch(dev, tmp_path):
     hist = train_observer.run(args, log=lambda *_: None)
     assert all(np.isfinite(h["train_l2"]) and np.isfinite(h["test_l2"]) for h in hist)
     assert hist[-1]["train_l2"] < hist[0]["train_l2"]
+
+
+@pytest.mark.gpu
+def test_train_pino_loop(dev, tmp_path):
+    """train_pino.run (the train_pino.py counterpart) on a synthetic multi-Reynolds .npz with the reference's YAML keys:
+    one objective evaluation agrees with the CPU oracle's residual loss on the same model output, then the loop trains
+    (data + PDE + IC terms, MultiStepLR) and the loss goes down."""
+    import types
+    from oracle import pino_loss_oracle as P
+    from pde_policylearning_amd import train_pino
+    from pde_policylearning_amd.libs.pino_utils.losses import get_forcing
+    from pde_policylearning_amd.trainer import PinoObjective
+    rng = np.random.default_rng(2)
+    S, Tr, N = 32, 17, 6
+    xs = np.linspace(0, 2 * np.pi, S, endpoint=False)
+    X, Y = np.meshgrid(xs, xs, indexing="ij")
+    raw = np.stack([[np.sin(X + 0.1 * t + p) * np.cos(2 * Y - 0.05 * t) + 0.3 * np.cos(4 * Y) for t in range(Tr)]
+                    for p in rng.uniform(0, 6, N)]).astype(np.float32)
+    path = os.path.join(tmp_path, "multi_reynolds_synth.npz")
+    np.savez(path, data1=raw, data2=np.linspace(300, 500, N).astype(np.float32))
+    config = {
+        "data": dict(train_paths=[path], test_paths=[path], offset=0, testoffset=4, n_data_samples=4, n_test_samples=2,
+                     t_duration=0.5, raw_res=[S, S, Tr], data_res=[S, S, Tr], pde_res=[S, S, Tr]),
+        "model": dict(layers=[16] * 5, modes1=[4] * 4, modes2=[4] * 4, modes3=[3] * 4, fc_dim=32, act="gelu", pad_ratio=0.0625),
+        "train": dict(start_iter=0, batchsize=4, num_iter=40, milestones=[20, 30], base_lr=0.004, scheduler_gamma=0.5,
+                      ic_loss=5.0, f_loss=1.0, xy_loss=1.0, save_step=1000, eval_step=39),
+        "test": dict(batchsize=2, data_res=[S, S, Tr]),
+        "log": dict(logdir=str(tmp_path / "exp")),
+    }
+    # one objective evaluation vs the oracle
+    torch.manual_seed(0)
+    model = train_pino.build_model(config, dev)
+    ds = train_pino._dataset(config, [path], [S, S, Tr], 4, 0)
+    assert len(ds) == 8 and ds[0][0].shape == (S, S, 9) and ds[0][1].shape == (S, S, 9, 4)
+    u, a, re = (torch.stack([torch.as_tensor(ds[i][k], dtype=torch.float32) for i in range(4)]).to(dev) for k in range(3))
+    obj = PinoObjective(get_forcing(S).to(dev), 0.5, 5.0, 1.0, 1.0)
+    out = model(a, re)
+    got = float(obj(out, (u, a, re)).detach())
+    oc = out.detach().cpu().reshape(4, S, S, 9)
+    lic, lf = P.pino_loss(oc, a[:, :, :, 0, -1].cpu(), P.forcing(S), 1.0 / re.cpu(), 0.5)
+    data = ((oc - u.cpu()).reshape(4, -1).norm(dim=1) / u.cpu().reshape(4, -1).norm(dim=1)).mean()
+    want = float(data + lf + 5.0 * lic)
+    assert abs(got - want) < 1e-5 * abs(want)
+    # the loop
+    args = types.SimpleNamespace(seed=0, ckpt=None, test=False, log_every=1)
+    hist = train_pino.run(config, args, log=lambda *_: None)
+    assert len(hist) == 40 and all(np.isfinite(h["train loss"]) for h in hist)
+    assert {"data", "IC", "PDE", "val error"} <= set(hist[-1])
+    assert np.mean([h["train loss"] for h in hist[-5:]]) < 0.7 * np.mean([h["train loss"] for h in hist[:5]])

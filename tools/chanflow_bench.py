@@ -105,9 +105,10 @@ rhs_bytes = fbytes * (3 * (Ny + 1) + 3 * Ny + 2)            # U, V, W in; Fu, Fv
 loss_bytes = fbytes * ((4 * Ny + 2) + (3 * Ny + 2)) + fbytes * ((4 * Ny + 2) + (3 * Ny + 2) + Ny)   # fwd: 4 in, 3 D out; bwd: 4 + 3 D in, dV out
 if os.environ.get("ENGINE_ONLY"):          # for rocprofv3 --kernel-trace --stats: just the engine launches
     with torch.no_grad():
-        timeit(lambda: F.chanflow_rhs(env.grid, U, V, W, env.dPdx), 50)
-        timeit(lambda: F.chanflow_rhs(env.grid, U.double(), V.double(), W.double(), env.dPdx), 10)
-    timeit(loss_engine, 50)
+        Ud, Vd, Wd = U.double(), V.detach().double(), W.double()
+        t32 = timeit(lambda: F.chanflow_rhs(env.grid, U, V, W, env.dPdx), 50)
+        t64 = timeit(lambda: F.chanflow_rhs(env.grid, Ud, Vd, Wd, env.dPdx), 10)
+    print(f"engine only: rhs f32 {t32*1e3:.1f} us, rhs f64 {t64*1e3:.1f} us, pde_loss fwd+bwd {timeit(loss_engine, 50)*1e3:.1f} us")
     sys.exit(0)
 with torch.no_grad():
     t_e = timeit(lambda: F.chanflow_rhs(env.grid, U, V, W, env.dPdx), 50)
