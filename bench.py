@@ -39,6 +39,8 @@ CONFIGS = {
     # the same model with the loop's loss: decode + LpLoss on the planes + pde_loss_weight 1.0 * channel-flow term (matlab_rno.yaml:56,62)
     "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32)),
     "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
+    # the fine-tuning step of that YAML as train_pino.py runs it: batch 4, loss = 5 * IC + 1 * PDE residual (xy_loss 0)
+    "pino_finetune_128x128x65_w64_m8_b4": dict(kind="pino2d_train", batch=4, size=(128, 128, 65)),
 }
 
 
@@ -130,13 +132,21 @@ def main():
         inputs = (x,)
     else:
         from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
-        if cfg["kind"] in ("pino_ff", "pino_ff_pde"):     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
+        if cfg["kind"] == "pino2d_train":   # train_pino.py:79-106; a = (x, y, t, u0) grid as libs/pino_utils/datasets.py:612-617 builds it
+            from pde_policylearning_amd.libs.pino_utils.utils import get_grid3d
+            S, T = cfg["size"][0], cfg["size"][2]
+            model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+                                  out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)
+            u0 = torch.randn((B, S, S, 1, 1), generator=gen)
+            grid = torch.cat([g[0] for g in get_grid3d(S, T)], dim=-1)
+            x = torch.cat((grid.expand(B, -1, -1, -1, -1), u0.repeat(1, 1, 1, T, 1)), dim=-1).to(dev)
+        elif cfg["kind"] in ("pino_ff", "pino_ff_pde"):     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
             model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
                                          layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
             x = torch.randn((B,) + cfg["size"] + (1, 1), generator=gen).to(dev)
         else:                             # train_pino.py:154-160: x (B, X, Y, T, 4), T padded by round(T * 0.0625)
             model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
-                                  out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+                                  out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)      # YAML: a float pads both ends, T 65 -> 73
             x = torch.randn((B,) + cfg["size"] + (4,), generator=gen).to(dev)
         re = (torch.rand((B, 1), generator=gen) * 100 + 100).to(dev)
         inputs = (x, re)
@@ -152,6 +162,11 @@ def main():
         bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model else None)
     opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
+    if cfg["kind"] == "pino2d_train":
+        from pde_policylearning_amd.libs.pino_utils.losses import get_forcing
+        from pde_policylearning_amd.trainer import PinoObjective
+        loss_fn = PinoObjective(get_forcing(cfg["size"][0]).to(dev), 0.5, 5.0, 1.0, 0.0)     # ic_loss 5, f_loss 1, xy_loss 0
+        tgt = (tgt.reshape(tgt.shape[:4]), x, inputs[1].reshape(B))
     if cfg["kind"] == "pino_ff_pde":                           # run_pde_observers.py:207-231 on a 32 x 130 x 32 channel
         from pde_policylearning_amd.libs.envs.control_env import ChannelFlowRHS
         from pde_policylearning_amd.trainer import FullFieldObjective, MeanStdDecoder
@@ -291,7 +306,7 @@ def main():
     if rank == 0:
         out = {
             "metric": {"2d": "FNO2d", "3d": "FNO3d", "rno2d": "RNO2d", "rno2d_shipped": "RNO2d", "pino_ff": "PINObserverFullField", "pino_ff_pde": "PINObserverFullField+pde_loss",
-                       "pino2d": "PINObserver2d"}[cfg["kind"]] + " fwd+bwd fields/sec",
+                       "pino2d": "PINObserver2d", "pino2d_train": "PINObserver2d+PINO_loss"}[cfg["kind"]] + " fwd+bwd fields/sec",
             "value": round(fields_per_s, 2),
             "unit": "fields/s",
             "n_gpus": world,
@@ -304,7 +319,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
-                       "step": "zero_grad+fwd+" + ("decode+LpLoss(sum)+channel-flow pde_loss" if cfg["kind"] == "pino_ff_pde" else "LpLoss(sum)") + "+bwd" +
+                       "step": "zero_grad+fwd+" + {"pino_ff_pde": "decode+LpLoss(sum)+channel-flow pde_loss", "pino2d_train": "5*IC+PDE residual loss"}.get(cfg["kind"], "LpLoss(sum)") + "+bwd" +
                                ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,

@@ -144,6 +144,8 @@ struct Tables {
   float* tfwd_b = nullptr;   // same, gamma-weighted (transform of gradients)
   float* tinv_f = nullptr;   // (J, W) gamma * s_i * (cos, -sin)
   float* tinv_b = nullptr;   // (J, W) s_f * (cos, -sin)
+  float* tT[4] = {nullptr, nullptr, nullptr, nullptr};   // tfwd_f, tfwd_b, tinv_f, tinv_b transposed to [W][2*K2P], zero-padded bins
+  int K2P = 0;               // kept bins rounded up to 8 / 16 / 32 (0: more than 32, no transposed tables)
   float2* tw_fwd_sf[2] = {nullptr, nullptr};  // leading dim d: TRANSPOSED (N, Klead) e^{-i}, d==0 scaled by s_f
   float2* tw_fwd_si[2] = {nullptr, nullptr};  // d==0 scaled by s_i (gradient direction)
   float2* tw_inv[2] = {nullptr, nullptr};     // (N, Klead) e^{+i}
@@ -217,6 +219,16 @@ static int make_tables(const Geom& g, Tables& t) {
   if ((rc = upload(t, fb.data(), fb.size() * 4, (void**)&t.tfwd_b))) return rc;
   if ((rc = upload(t, vf.data(), vf.size() * 4, (void**)&t.tinv_f))) return rc;
   if ((rc = upload(t, vb.data(), vb.size() * 4, (void**)&t.tinv_b))) return rc;
+  t.K2P = g.Klast <= 8 ? 8 : g.Klast <= 16 ? 16 : g.Klast <= 32 ? 32 : 0;
+  if (t.K2P) {
+    const std::vector<float>* src[4] = {&ff, &fb, &vf, &vb};
+    for (int q = 0; q < 4; ++q) {
+      std::vector<float> tr((size_t)W * 2 * t.K2P, 0.f);
+      for (int j = 0; j < J; ++j)
+        for (int w = 0; w < W; ++w) tr[(size_t)w * 2 * t.K2P + j] = (*src[q])[(size_t)j * W + w];
+      if ((rc = upload(t, tr.data(), tr.size() * 4, (void**)&t.tT[q]))) return rc;
+    }
+  }
   for (int d = 0; d < g.nlead; ++d) {
     const int N = g.dims[d], K = g.Klead[d], m = g.modes[d];
     std::vector<float2> a((size_t)K * N), b((size_t)K * N), inv((size_t)N * K);
@@ -456,7 +468,8 @@ static int dev_ncu() {
   }
   return ncu;
 }
-static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, int B, int C, const float* x, float* x1) {
+static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const float* tT, int K2P, int B, int C,
+                       const float* x, float* x1) {
   if (row_fast_ok(g, C)) {
     RowDftArgs a;
     a.x = x; a.x1 = x1; a.tfwd = tfwd; a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2out = g.Klast; a.NJ = g.NJ;
@@ -465,6 +478,22 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, int B, 
     const int grid = std::min(a.ntiles, 3 * dev_ncu());
     if (C == 32) return launch("k_rowdft_tile", k_rowdft_tile<32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowdft_tile", k_rowdft_tile<64, 128>, dim3(grid), dim3(256), lds, st, a);
+  }
+  static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
+  static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 320;
+  if (chan && K2P) {
+    // lanes <-> channels, persistent workgroups with a register-prefetched tile: <= 64 channels, <= 320 floats per channel run
+    int rb = std::max(1, std::min(chan_rb, 320 / g.W));
+    while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
+    const size_t lds = (size_t)C * (rb * g.W + 1) * 4;
+    if (C <= 64 && g.W <= 320 && lds <= 160 * 1024) {
+      const int ntiles = B * ((g.P + rb - 1) / rb);
+      const int per_cu = std::max(1, (int)std::min<size_t>(4, (160 * 1024) / lds));
+      const dim3 grid(std::min(ntiles, per_cu * dev_ncu())), blk(256);
+      if (K2P == 8) return launch("k_rowdft_chan", k_rowdft_chan<8>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
+      if (K2P == 16) return launch("k_rowdft_chan", k_rowdft_chan<16>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
+      return launch("k_rowdft_chan", k_rowdft_chan<32>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
+    }
   }
   // rows per workgroup: as many as keep the tile + table under 64 KB (several workgroups per CU), at most 8
   const int k2e = (g.Klast + 1) & ~1;
@@ -475,7 +504,8 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, int B, 
   return launch("k_rowdft_generic", k_rowdft_generic, dim3(B * ((g.P + rb - 1) / rb)), dim3(256), lds, st, x, (float2*)x1,
                 tfwd, C, g.P, g.W, g.Klast, rb);
 }
-static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, int C, const float* z, const float* bias,
+static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, const float* tT, int K2P, int B, int C,
+                       const float* z, const float* bias,
                        float* y) {
   const size_t lds = pw_fwd_lds_bytes(2, C, 128, g.W, g.Klast, g.NJ, true, false);
   if (row_fast_ok(g, C) && lds <= 64 * 1024) {
@@ -487,6 +517,21 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, int B, 
     const int grid = std::min(a.ntiles, 2 * dev_ncu());
     if (C == 32) return launch("k_rowidft_tile", k_pw_fwd<2, 32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowidft_tile", k_pw_fwd<2, 64, 128>, dim3(grid), dim3(512), lds, st, a);
+  }
+  static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
+  static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 4;
+  if (chan && K2P) {
+    // rows per workgroup: runs of <= 320 floats per channel, tile <= 78 KB (two workgroups per CU), >= 4 tiles per CU
+    int rb = std::max(1, std::min(chan_rb, 320 / g.W));
+    while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
+    const size_t lds2 = (size_t)C * (rb * g.W + 1) * 4;
+    if (lds2 <= 160 * 1024) {
+      const dim3 grid(B * ((g.P + rb - 1) / rb));
+      const dim3 blk(std::min(256, ((rb * C + 63) / 64) * 64));
+      if (K2P == 8) return launch("k_rowidft_chan", k_rowidft_chan<8>, grid, blk, lds2, st, (const float2*)z, y, tT, bias, C, g.P, g.W, g.Klast, rb);
+      if (K2P == 16) return launch("k_rowidft_chan", k_rowidft_chan<16>, grid, blk, lds2, st, (const float2*)z, y, tT, bias, C, g.P, g.W, g.Klast, rb);
+      return launch("k_rowidft_chan", k_rowidft_chan<32>, grid, blk, lds2, st, (const float2*)z, y, tT, bias, C, g.P, g.W, g.Klast, rb);
+    }
   }
   int rb = 8;
   auto need = [&](int r) { return (((size_t)2 * g.Klast * g.W + 1) & ~(size_t)1) * 4 + (size_t)r * g.Klast * C * 8; };
@@ -516,12 +561,12 @@ extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, con
   SpecWs w = carve_spec(p, B, ws, ws_bytes, &ok);
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   float* hat = xhat_save ? xhat_save : w.hat_in;
-  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, B, Cin, x, w.x1));
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, Cin, x, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, Cin, w.x1, w.tmp, hat));
   LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
   LAUNCHCHK(mode_gemm(st, hat, w.wp, w.hat_out, B, g.Ktot, Cin, Cout, 0));
   LAUNCHCHK(lead_inverse(st, g, p->t, B, Cout, w.hat_out, w.tmp, w.z));
-  LAUNCHCHK(row_inverse(st, g, p->t.tinv_f, B, Cout, w.z, bias, y));
+  LAUNCHCHK(row_inverse(st, g, p->t.tinv_f, p->t.tT[2], p->t.K2P, B, Cout, w.z, bias, y));
   return FNO_OK;
 }
 
@@ -541,7 +586,7 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
     LAUNCHCHK(reduce_slabs(st, w.dbpart, dbias, 64, 1, Cout, Cout, Cout));
   }
   if (!dx && !dwc) return FNO_OK;
-  LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, B, Cout, dy, w.x1));
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, Cout, dy, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, true, B, Cout, w.x1, w.tmp, w.hat_out));   // G
   if (dwc) {
     LAUNCHCHK(mode_gemm_dw(st, xhat, w.hat_out, w.dwp, B, g.Ktot, Cin, Cout));
@@ -551,7 +596,7 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
     LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
     LAUNCHCHK(mode_gemm(st, w.hat_out, w.wpt, w.hat_in, B, g.Ktot, Cout, Cin, 1));   // GX
     LAUNCHCHK(lead_inverse(st, g, p->t, B, Cin, w.hat_in, w.tmp, w.z));
-    LAUNCHCHK(row_inverse(st, g, p->t.tinv_b, B, Cin, w.z, nullptr, dx));
+    LAUNCHCHK(row_inverse(st, g, p->t.tinv_b, p->t.tT[3], p->t.K2P, B, Cin, w.z, nullptr, dx));
   }
   return FNO_OK;
 }
@@ -868,7 +913,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
   } else {
-    LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, B, C, x, w.x1));     // block stack: x is u_0
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));     // block stack: x is u_0
   }
 
   for (int l = 0; l < L; ++l) {
@@ -942,7 +987,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   if (l_hi < L - 1) {
     // a later part: the running gradient and its row spectrum were left in the workspace by the previous call
   } else if (!has_proj) {
-    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, B, C, dy, w.x1));     // dy is dL/du_L
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
   if (g_gemm_x3) {
     const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;

@@ -515,6 +515,110 @@ __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// lanes <-> channels variants of the generic last-dim passes (K2 <= 32 kept bins).  One item = (row r, channel c) keeps all
+// its bins in registers; the table row of the current w is wave-uniform and comes through the scalar cache
+// (tT = [W][2*K2P], zero-padded bins), so the LDS only carries the activation tile: one 4-byte access per 2*K2P FMAs
+// instead of one broadcast read per FMA pair.  Tile [C][RB*W + 1]: odd pitch, conflict-free along c.
+// Persistent workgroups: while the current tile is transformed out of the LDS, the whole next tile (<= 16 channels x
+// 320 floats per wave = 80 registers per lane) is already in flight from HBM, so the load latency overlaps the FMA loop.
+template <int K2P>
+__global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x, float2* __restrict__ x1,
+                                                     const float* __restrict__ tT, int C, int P, int W, int K2, int RB,
+                                                     int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                 // [c][RB*W + 1]
+  const int nblk = (P + RB - 1) / RB;
+  const int pitch = RB * W + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // 4 waves
+  const size_t cstride = (size_t)P * W;
+  float v[16][5];                                   // channel wave + 4k, floats lane + 64 j of the tile's nr*W run
+  auto fetch = [&](int tile) {
+    const int b = tile / nblk, p0 = (tile % nblk) * RB;
+    const int seg = min(RB, P - p0) * W;
+    const float* xb = x + ((size_t)b * C * P + p0) * W;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        v[k][j] = xb[(size_t)min(wave + 4 * k, C - 1) * cstride + min(lane + 64 * j, seg - 1)];   // clamped: no branches
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / nblk, p0 = (tile % nblk) * RB;
+    const int nr = min(RB, P - p0), seg = nr * W;
+    __syncthreads();                                // previous tile's readers are done
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (wave + 4 * k < C && lane + 64 * j < seg) xs[(wave + 4 * k) * pitch + lane + 64 * j] = v[k][j];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    for (int it = threadIdx.x; it < nr * C; it += blockDim.x) {
+      const int r = it / C, c = it - r * C;
+      const float* xr = xs + c * pitch + r * W;
+      float acc[2 * K2P];
+#pragma unroll
+      for (int j = 0; j < 2 * K2P; ++j) acc[j] = 0.f;
+#pragma unroll 4
+      for (int w = 0; w < W; ++w) {
+        const float xv = xr[w];
+        const float* t = tT + (size_t)w * 2 * K2P;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int j = 0; j < 2 * K2P; ++j) acc[j] = fmaf(xv, t[j], acc[j]);
+      }
+      const size_t row = (size_t)b * P + p0 + r;
+#pragma unroll
+      for (int k2 = 0; k2 < K2P; ++k2)
+        if (k2 < K2) x1[(row * K2 + k2) * C + c] = make_float2(acc[2 * k2], acc[2 * k2 + 1]);
+    }
+  }
+}
+
+template <int K2P>
+__global__ void __launch_bounds__(256) k_rowidft_chan(const float2* __restrict__ z, float* __restrict__ y,
+                                                      const float* __restrict__ tT, const float* __restrict__ bias, int C,
+                                                      int P, int W, int K2, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ys = smem;                                 // [c][RB*W + 1]
+  const int nblk = (P + RB - 1) / RB;
+  const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
+  const int nr = min(RB, P - p0);
+  const int pitch = RB * W + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  for (int it = threadIdx.x; it < nr * C; it += blockDim.x) {
+    const int r = it / C, c = it - r * C;
+    const float2* zr = z + ((size_t)b * P + p0 + r) * K2 * C + c;
+    float zz[2 * K2P];
+#pragma unroll
+    for (int k2 = 0; k2 < K2P; ++k2) {
+      const float2 v = k2 < K2 ? zr[(size_t)k2 * C] : make_float2(0.f, 0.f);
+      zz[2 * k2] = v.x; zz[2 * k2 + 1] = v.y;
+    }
+    const float b0 = bias ? bias[c] : 0.f;
+    float* yr = ys + c * pitch + r * W;
+#pragma unroll 4
+    for (int w = 0; w < W; ++w) {
+      const float* t = tT + (size_t)w * 2 * K2P;    // wave-uniform: scalar loads
+      float s0 = b0, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2 * K2P; j += 4) {
+        s0 = fmaf(zz[j], t[j], s0); s1 = fmaf(zz[j + 1], t[j + 1], s1);
+        s2 = fmaf(zz[j + 2], t[j + 2], s2); s3 = fmaf(zz[j + 3], t[j + 3], s3);
+      }
+      yr[w] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  __syncthreads();
+  const int seg = nr * W;
+  const size_t cstride = (size_t)P * W;
+  float* yb = y + ((size_t)b * C * P + p0) * W;
+  for (int c = wave; c < C; c += nwave)
+    for (int o = lane; o < seg; o += 64) yb[(size_t)c * cstride + o] = ys[c * pitch + o];
+}
+
 // dbias[c] partials: sum over (b, pixels) of dy (B, C, PW) -> part[blk][c]
 __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ dy, float* __restrict__ part, int B,
                                                       int C, int PW) {
