@@ -56,7 +56,7 @@ def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device):
 
 class _SpectralConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, modes, norm, weight_last_extent, *weights):
+    def forward(ctx, x, bias, modes, norm, weight_last_extent, direct, *weights):
         _require_cuda(x, "x")
         x = x.contiguous()
         ws_list = [w.contiguous() for w in weights]          # real views (.., 2)
@@ -79,6 +79,7 @@ class _SpectralConvFn(torch.autograd.Function):
                                           _stream()), "spec_forward")
         ctx.plan, ctx.B, ctx.has_bias = plan, B, bias is not None
         ctx.x_shape = x.shape
+        ctx.direct = direct
         ctx.save_for_backward(xhat, *ws_list)
         return y
 
@@ -89,9 +90,10 @@ class _SpectralConvFn(torch.autograd.Function):
         L = _lib.lib()
         need_dx = ctx.needs_input_grad[0]
         need_db = ctx.has_bias and ctx.needs_input_grad[1]
-        need_dw = any(ctx.needs_input_grad[5:])
+        need_dw = any(ctx.needs_input_grad[6:])
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy.device) if need_dx else None
-        dws = [torch.empty_like(w) for w in ws_list] if need_dw else None
+        direct = ctx.direct if need_dw else None
+        dws = (direct if direct is not None else [torch.empty_like(w) for w in ws_list]) if need_dw else None
         db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device) if need_db else None
         nws = L.fno_spec_workspace_bytes(ctx.plan, ctx.B)
         ws = _bytes(nws, dy.device)
@@ -100,19 +102,27 @@ class _SpectralConvFn(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(L.fno_spec_backward(ctx.plan, ctx.B, _ptr(dy), _ptr(xhat), wp, _ptr(dx),
                                            dwp, _ptr(db), _ptr(ws), nws, _stream()), "spec_backward")
-        return (dx, db, None, None, None) + (tuple(dws) if need_dw else (None,) * len(ws_list))
+        if direct is not None:                     # written in place into the caller's gradient storage
+            return (dx, db, None, None, None, None) + (None,) * len(ws_list)
+        return (dx, db, None, None, None, None) + (tuple(dws) if need_dw else (None,) * len(ws_list))
 
 
-def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=None):
+def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=None, direct_grads=False):
     """y = irfftn(pad(W_c . rfftn(x)[corner_c]), s=x.shape[2:]) (+ bias[None, :, None..]).
 
     weights: corner tensors in canonical order, real (Cin, Cout, m.., 2) or complex.
     modes:   kept extent per corner along each dim.
+    direct_grads: the backward WRITES dL/dW into the weights' existing contiguous `.grad` storage (e.g. views of a
+    trainer.FlatGradBucket) instead of returning it to autograd: no accumulation kernel, no zeroing needed.  Only valid when
+    each weight feeds exactly one spectral_conv call per step.
     """
     ws = [torch.view_as_real(w) if w.is_complex() else w for w in weights]
     wle = int(weight_last_extent) if weight_last_extent is not None else int(ws[0].shape[-2])
     b = bias.reshape(-1) if bias is not None else None
-    return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, *ws)
+    direct = None
+    if direct_grads and torch.is_grad_enabled() and all(w.grad is not None and w.grad.is_contiguous() for w in weights):
+        direct = [torch.view_as_real(w.grad) if w.grad.is_complex() else w.grad for w in weights]
+    return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, direct, *ws)
 
 
 # ----------------------------------------------------------------------------

@@ -20,8 +20,13 @@ class SpectralConv2d(nn.Module):
         self.weights1 = _cweight(in_channels, out_channels, modes1, modes2)
         self.weights2 = _cweight(in_channels, out_channels, modes1, modes2)
 
+    def direct_grad_params(self):
+        """parameters whose gradient the engine may write straight into a trainer.FlatGradBucket (one use per step)"""
+        return [self.weights1, self.weights2]
+
     def forward(self, x):
-        return F.spectral_conv(x, [self.weights1, self.weights2], None, (self.modes1, self.modes2), "backward")
+        return F.spectral_conv(x, [self.weights1, self.weights2], None, (self.modes1, self.modes2), "backward",
+                               direct_grads=getattr(self, "_direct_grads", False))
 
 
 class SpectralConv3d(nn.Module):
@@ -33,10 +38,14 @@ class SpectralConv3d(nn.Module):
         for i in range(1, 5):
             setattr(self, f"weights{i}", _cweight(in_channels, out_channels, modes1, modes2, modes3))
 
+    def direct_grad_params(self):
+        return [self.weights1, self.weights2, self.weights3, self.weights4]
+
     def forward(self, x):
         # reference corner order: weights1 (lo,lo), weights2 (hi,lo), weights3 (lo,hi), weights4 (hi,hi)
         # (basics.py:125-139); the engine takes (lo,lo), (lo,hi), (hi,lo), (hi,hi).  Only
         # min(Nz/2+1, modes3) last-dim modes are live (:119,:125-126); the rest get zero gradient.
         k3 = min(x.shape[-1] // 2 + 1, self.modes3)
         return F.spectral_conv(x, [self.weights1, self.weights3, self.weights2, self.weights4], None,
-                               (self.modes1, self.modes2, k3), "backward", weight_last_extent=self.modes3)
+                               (self.modes1, self.modes2, k3), "backward", weight_last_extent=self.modes3,
+                               direct_grads=getattr(self, "_direct_grads", False))

@@ -105,6 +105,11 @@ class FNO(nn.Module):
             return F.fno_model(x, direct_grads=getattr(self, "_direct_grads", False),
                                overlap=getattr(self, "_grad_overlap", None), **self.engine_args())
         # other widths / grids: spectral convolutions on the engine, pointwise glue in torch
+        if getattr(self, "_direct_grads", False) and torch.is_grad_enabled():
+            # a direct-write bucket does not clear this model's gradients; autograd accumulates on this path, so clear them here
+            for p in self.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
         x = self.lifting(x)
         for l in range(self.n_layers):
             x = self.fno_blocks(x, l)

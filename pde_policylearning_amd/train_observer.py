@@ -136,7 +136,7 @@ def run_full_field(args, idx, dev, rank, world, log):
                                  fc_dim=128, layers=[args.width] * (L + 1), in_dim=1, out_dim=1, act="gelu",
                                  pad_ratio=[0.0, 0.0625]).to(dev)                   # run_pde_observers.py:117-131
     broadcast_parameters(model)
-    bucket = FlatGradBucket(model.parameters())
+    bucket = FlatGradBucket(model.parameters(), direct_module=model)      # spectral-weight gradients written in place
     opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)
     env = None
     if args.pde_loss_weight > 0:

@@ -110,7 +110,7 @@ def run(config, args, log=print):
     u_loader = DataLoader(u_set, batch_size=t['batchsize'] * world, shuffle=True, drop_last=world > 1)
     val_loader = DataLoader(valset, batch_size=t['batchsize'])
     broadcast_parameters(model)
-    optimizer = FusedAdam(FlatGradBucket(model.parameters()), lr=t['base_lr'])
+    optimizer = FusedAdam(FlatGradBucket(model.parameters(), direct_module=model), lr=t['base_lr'])
     scheduler = MultiStepLR(optimizer, milestones=t['milestones'], gamma=t['scheduler_gamma'])
     if ckpt and ckpt.get('optim') is not None:
         optimizer.load_state_dict(ckpt['optim'])

@@ -167,21 +167,31 @@ class FlatGradBucket(object):
     for FNO2d(12,12,64) instead of ~30 small ones."""
 
     def __init__(self, params, process_group=None, direct_module=None):
-        """direct_module: an engine FNO whose backward may WRITE its gradients into the bucket
-        (no autograd accumulation kernels, no zeroing); valid when every parameter is used by
-        exactly one engine call per step, as in the reference training step."""
+        """direct_module: a model whose engine calls may WRITE their gradients into the bucket (no autograd
+        accumulation kernels, no zeroing); valid when every such parameter is used by exactly one engine call per
+        step, as in the reference training steps.  A fused engine FNO covers all of its parameters; modules exposing
+        `direct_grad_params()` (the PINO observers' spectral convolutions: > 99 % of their parameter bytes) cover those,
+        and the remaining parameters are laid out at the tail of the bucket, which is the only part zero() clears."""
         self.direct_module = direct_module
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
-        n = sum(self._nfloat(p) for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        for p, v in zip(self.params, self.views(self.flat)):
-            p.grad = v
+        direct_ids = set()
         if direct_module is not None:
             for m in direct_module.modules():
                 if hasattr(m, "fused_supported"):
                     m._direct_grads = True
+                    direct_ids.update(id(p) for p in m.parameters())
+                elif hasattr(m, "direct_grad_params"):
+                    m._direct_grads = True
+                    direct_ids.update(id(p) for p in m.direct_grad_params())
+            if any(id(p) not in direct_ids for p in self.params):
+                self.params = [p for p in self.params if id(p) in direct_ids] + [p for p in self.params if id(p) not in direct_ids]
+        n = sum(self._nfloat(p) for p in self.params)
+        self._zero_from = sum(self._nfloat(p) for p in self.params if id(p) in direct_ids) if direct_module is not None else 0
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, v in zip(self.params, self.views(self.flat)):
+            p.grad = v
 
     @staticmethod
     def _nfloat(p):
@@ -200,8 +210,8 @@ class FlatGradBucket(object):
         return out
 
     def zero(self):
-        if self.direct_module is None:
-            self.flat.zero_()
+        if self._zero_from < self.flat.numel():
+            self.flat[self._zero_from:].zero_()
 
     def check_views(self):
         """autograd accumulates in place into an existing .grad; re-attach if something replaced it."""
