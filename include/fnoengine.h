@@ -65,8 +65,9 @@ int fno_spec_plan_create(const FnoSpecDesc* desc, FnoSpecPlan** out);
 void fno_spec_plan_destroy(FnoSpecPlan* plan);
 size_t fno_spec_workspace_bytes(const FnoSpecPlan* plan, int batch);
 size_t fno_spec_xhat_bytes(const FnoSpecPlan* plan, int batch);
-/* y = specconv(x) + bias.  xhat_save (fno_spec_xhat_bytes) receives the truncated
- * spectrum of x, the only thing backward needs besides dy; may be NULL. */
+/* y = specconv(x) + bias.  xhat_save (fno_spec_xhat_bytes) receives what backward needs besides dy: the truncated
+ * spectrum of x (for dW) and the mode-major transposed weights (for dx, so that backward does not re-pack them);
+ * may be NULL.  fno_spec_backward with xhat = that buffer may pass w_corners = NULL. */
 int fno_spec_forward(const FnoSpecPlan* plan, int batch, const float* x, const float* const* w_corners,
                      const float* bias /*nullable (Cout)*/, float* y, float* xhat_save, void* ws, size_t ws_bytes,
                      void* stream);

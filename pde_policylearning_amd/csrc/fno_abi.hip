@@ -366,9 +366,12 @@ static int unpack_dw(hipStream_t st, const Geom& g, int Cin, int Cout, const flo
   const ModeMap mm = make_modemap(g, Cin, Cout);
   size_t per = (size_t)g.modes[0] * g.wl_stride;
   if (g.nlead == 2) per *= g.modes[1];
-  const size_t n = (size_t)(1 << g.nlead) * Cin * Cout * per;
-  return launch("k_unpack_dw", k_unpack_dw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float2*)dwp,
-                cp, mm);
+  if (per > 0x7fffffffull / 2) return fail(FNO_EUNSUPPORTED, "corner weight of %zu entries per channel pair", per);
+  int bx = 256;
+  while (bx > 16 && (size_t)bx / 2 >= per) bx >>= 1;
+  const int by = 256 / bx, rows = (1 << g.nlead) * Cin * Cout;
+  return launch("k_unpack_dw", k_unpack_dw, dim3((unsigned)((rows + by - 1) / by), (unsigned)((per + bx - 1) / bx)), dim3(bx, by),
+                0, st, (const float2*)dwp, cp, mm, (int)per);
 }
 static int reduce_slabs(hipStream_t st, const float* part, float* out, int nslab, int rows, int ncols, int ld_in,
                         int ld_out) {
@@ -450,8 +453,10 @@ static SpecWs carve_spec(const FnoSpecPlan* p, int B, void* ws, size_t cap, bool
 extern "C" size_t fno_spec_workspace_bytes(const FnoSpecPlan* p, int B) {
   return carve_spec(p, B, nullptr, 0, nullptr).total;
 }
+// saved for the backward: the truncated input spectrum [B][Ktot][Cin] and the transposed packed weights [Ktot][Cout][Cin]
+static size_t spec_xhat_floats(const FnoSpecPlan* p, int B) { return (size_t)B * p->g.Ktot * p->d.Cin * 2; }
 extern "C" size_t fno_spec_xhat_bytes(const FnoSpecPlan* p, int B) {
-  return (size_t)B * p->g.Ktot * p->d.Cin * 2 * sizeof(float);
+  return (spec_xhat_floats(p, B) + (size_t)p->g.Ktot * p->d.Cin * p->d.Cout * 2) * sizeof(float);
 }
 
 // Last-dim passes of the standalone path: MFMA tile kernels when the shape allows it
@@ -563,7 +568,7 @@ extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, con
   float* hat = xhat_save ? xhat_save : w.hat_in;
   LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, Cin, x, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, Cin, w.x1, w.tmp, hat));
-  LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
+  LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, xhat_save ? xhat_save + spec_xhat_floats(p, B) : w.wpt));
   LAUNCHCHK(mode_gemm(st, hat, w.wp, w.hat_out, B, g.Ktot, Cin, Cout, 0));
   LAUNCHCHK(lead_inverse(st, g, p->t, B, Cout, w.hat_out, w.tmp, w.z));
   LAUNCHCHK(row_inverse(st, g, p->t.tinv_f, p->t.tT[2], p->t.K2P, B, Cout, w.z, bias, y));
@@ -574,7 +579,7 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
                                  float* dx, float* const* dwc, float* dbias, void* ws, size_t ws_bytes, void* stream) {
   if (!p || !dy || B < 1) return fail(FNO_EINVAL, "fno_spec_backward: bad argument");
   if (dwc && !xhat) return fail(FNO_EINVAL, "weight gradients need the saved spectrum");
-  if (dx && !wc) return fail(FNO_EINVAL, "input gradient needs the weights");
+  if (dx && !wc && !xhat) return fail(FNO_EINVAL, "input gradient needs the weights (or the buffer saved by the forward)");
   hipStream_t st = (hipStream_t)stream;
   const Geom& g = p->g;
   const int Cin = p->d.Cin, Cout = p->d.Cout;
@@ -593,8 +598,9 @@ extern "C" int fno_spec_backward(const FnoSpecPlan* p, int B, const float* dy, c
     LAUNCHCHK(unpack_dw(st, g, Cin, Cout, w.dwp, dwc));
   }
   if (dx) {
-    LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
-    LAUNCHCHK(mode_gemm(st, w.hat_out, w.wpt, w.hat_in, B, g.Ktot, Cout, Cin, 1));   // GX
+    const float* wpt = xhat ? xhat + spec_xhat_floats(p, B) : w.wpt;                 // packed by the forward when it saved
+    if (!xhat) LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, w.wpt));
+    LAUNCHCHK(mode_gemm(st, w.hat_out, wpt, w.hat_in, B, g.Ktot, Cout, Cin, 1));     // GX
     LAUNCHCHK(lead_inverse(st, g, p->t, B, Cin, w.hat_in, w.tmp, w.z));
     LAUNCHCHK(row_inverse(st, g, p->t.tinv_b, p->t.tT[3], p->t.K2P, B, Cin, w.z, nullptr, dx));
   }

@@ -164,35 +164,29 @@ __global__ void k_pack_w(CornerPtrs cw, float2* __restrict__ wp, float2* __restr
 }
 
 // corner-layout gradients from mode-major dWp[k][i][o]; entries of the stored
-// weight outside the kept last-dim range get zero gradient
-__global__ void k_unpack_dw(const float2* __restrict__ dwp, CornerPtrsMut gw, ModeMap mm) {
-  size_t per_c = (size_t)mm.m[0] * mm.wl_stride;
-  if (mm.nlead == 2) per_c *= mm.m[1];
-  const int ncorner = 1 << mm.nlead;
-  const size_t n = (size_t)ncorner * mm.Cin * mm.Cout * per_c;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const size_t loc = e % per_c;
-  const int o = (e / per_c) % mm.Cout;
-  const int i = (e / (per_c * mm.Cout)) % mm.Cin;
-  const int corner = e / (per_c * mm.Cout * mm.Cin);
-  const int kl = loc % mm.wl_stride;
+// weight outside the kept last-dim range get zero gradient.
+//   block (bx, 256 / bx): x runs along one (corner, i, o) row of per_c contiguous float2 (coalesced stores, 32-bit index
+//   arithmetic), y picks the row;  grid (ceil(rows / by), ceil(per_c / bx))
+__global__ void __launch_bounds__(256) k_unpack_dw(const float2* __restrict__ dwp, CornerPtrsMut gw, ModeMap mm, int per_c) {
+  const int row = blockIdx.x * blockDim.y + threadIdx.y;          // (corner * Cin + i) * Cout + o
+  const int loc = blockIdx.y * blockDim.x + threadIdx.x;
+  const int nrow = (1 << mm.nlead) * mm.Cin * mm.Cout;
+  if (row >= nrow || loc >= per_c) return;
+  const int io = row % (mm.Cin * mm.Cout), corner = row / (mm.Cin * mm.Cout);
+  const int rest = loc / mm.wl_stride, kl = loc - rest * mm.wl_stride;
   float2 v = make_float2(0.f, 0.f);
-  const int klast_kept = mm.K[mm.nlead];
-  if (kl < klast_kept) {
+  if (kl < mm.K[mm.nlead]) {
     int k;
     if (mm.nlead == 2) {
-      const int l2 = (loc / mm.wl_stride) % mm.m[1];
-      const int l1 = loc / ((size_t)mm.wl_stride * mm.m[1]);
+      const int l1 = rest / mm.m[1], l2 = rest - l1 * mm.m[1];
       const int k1 = l1 + (corner >> 1) * mm.m[0], k2 = l2 + (corner & 1) * mm.m[1];
       k = (k1 * mm.K[1] + k2) * mm.K[2] + kl;
     } else {
-      const int l1 = loc / mm.wl_stride;
-      k = (l1 + corner * mm.m[0]) * mm.K[1] + kl;
+      k = (rest + corner * mm.m[0]) * mm.K[1] + kl;
     }
-    v = dwp[((size_t)k * mm.Cin + i) * mm.Cout + o];
+    v = dwp[(size_t)k * mm.Cin * mm.Cout + io];
   }
-  gw.p[corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
+  gw.p[corner][(size_t)io * per_c + loc] = v;
 }
 
 // all layers in one launch (blockIdx.y = layer); per-layer outputs are `stride` float2 apart
