@@ -58,6 +58,9 @@ typedef struct FnoSpecDesc {
   int modes[3];            /* kept extent per corner along each dim */
   int weight_last_extent;  /* last-dim extent of the stored weights (>= modes[ndim-1]) */
   int norm;                /* FNO_NORM_* */
+  int input_gelu;          /* 1: the input is a PRE-activation tensor u and the convolution acts on gelu(u) (applied while
+                              the rows are staged; <= 64 channels, rows <= 320 floats, <= 32 kept last-dim bins).  backward
+                              then returns dL/d gelu(u); the caller (fno_pointwise_backward) applies gelu'(u). */
 } FnoSpecDesc;
 
 typedef struct FnoSpecPlan FnoSpecPlan;
@@ -221,14 +224,19 @@ int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const
  * the Conv1d(k=1) beside every spectral convolution of the observer models
  * (libs/models/pino_models/pinobserver.py:221-226 `sp_convs[i](x) + ws[i](x)`; neuralop/models/rno.py:224-228),
  * for grids the fused block stacks do not cover (odd last dimension).  x, y, addend, dy, dx: (B, C, PW) fp32,
- * C in {32, 64}, PW % 128 == 0; w (C, C) row-major [o][i]; bias / addend / dx / dbias nullable.
+ * C in {32, 64}, PW % 128 == 0; w (C, C) row-major [o][i]; bias / addend / dx_addend / dx / dbias nullable.
  * The gradient w.r.t. `addend` is dy itself.
+ * input_gelu = 1: x is a PRE-activation tensor and the mix acts on gelu(x) (the previous layer's activation applied on
+ * load, as in the fused block stack); backward then returns dx = (W^T dy + dx_addend) * gelu'(x), where dx_addend is
+ * the gradient arriving at gelu(x) from its other consumer (the spectral convolution beside the mix): one layer of
+ * `act(sp_conv(x) + w(x))` chains (pinobserver.py:221-226) costs no separate activation or accumulation pass.
  * ---------------------------------------------------------------------- */
 size_t fno_pointwise_workspace_bytes(int channels);
 int fno_pointwise_forward(int batch, int channels, size_t plane, const float* x, const float* w, const float* bias,
-                          const float* addend, float* y, void* stream);
+                          const float* addend, int input_gelu, float* y, void* stream);
 int fno_pointwise_backward(int batch, int channels, size_t plane, const float* x, const float* w, const float* dy,
-                           float* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream);
+                           const float* dx_addend, int input_gelu, float* dx, float* dw, float* dbias, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Projection head on its own:  y = W2 gelu(W1 x + b1) + b2, x (B, C, PW), C in {32, 64}, hidden 128 or 256,

@@ -19,7 +19,7 @@ c_float_p = C.POINTER(C.c_float)
 class FnoSpecDesc(C.Structure):
     _fields_ = [("ndim", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("dims", C.c_int * 3), ("modes", C.c_int * 3),
-                ("weight_last_extent", C.c_int), ("norm", C.c_int)]
+                ("weight_last_extent", C.c_int), ("norm", C.c_int), ("input_gelu", C.c_int)]
 
 
 class FnoModelDesc(C.Structure):
@@ -91,8 +91,8 @@ def lib():
     L.fno_adam_step_dev.argtypes = [sz, vp, vp, vp, vp, fl, fl, fl, fl, fl, vp, vp, vp]
     L.fno_pointwise_workspace_bytes.argtypes = [ci]
     L.fno_pointwise_workspace_bytes.restype = sz
-    L.fno_pointwise_forward.argtypes = [ci, ci, sz, vp, vp, vp, vp, vp, vp]
-    L.fno_pointwise_backward.argtypes = [ci, ci, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.fno_pointwise_forward.argtypes = [ci, ci, sz, vp, vp, vp, vp, ci, vp, vp]
+    L.fno_pointwise_backward.argtypes = [ci, ci, sz, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, vp]
     L.fno_projection_workspace_bytes.argtypes = [ci, ci]
     L.fno_projection_workspace_bytes.restype = sz
     L.fno_projection_forward.argtypes = [ci, ci, ci, ci, sz] + [vp] * 7

@@ -402,6 +402,7 @@ struct FnoSpecPlan {
   Tables t;
 };
 
+static bool row_chan_ok(const Geom& g, int K2P, int C) { return K2P && C <= 64 && g.W <= 320; }
 extern "C" int fno_spec_plan_create(const FnoSpecDesc* d, FnoSpecPlan** out) {
   if (!d || !out) return fail(FNO_EINVAL, "null argument");
   FnoSpecPlan* p = new FnoSpecPlan();
@@ -414,6 +415,8 @@ extern "C" int fno_spec_plan_create(const FnoSpecDesc* d, FnoSpecPlan** out) {
     if (lds1 > 160 * 1024) rc = fail(FNO_EUNSUPPORTED, "row tile C*(W+1)*4=%zu exceeds LDS", lds1);
   }
   if (rc == FNO_OK) rc = make_tables(p->g, p->t);
+  if (rc == FNO_OK && d->input_gelu && !row_chan_ok(p->g, p->t.K2P, d->Cin))
+    rc = fail(FNO_EUNSUPPORTED, "input_gelu needs <= 64 input channels, rows of <= 320 floats and <= 32 kept last-dim bins");
   if (rc != FNO_OK) { p->t.release(); delete p; return rc; }
   *out = p;
   return FNO_OK;
@@ -474,8 +477,9 @@ static int dev_ncu() {
   return ncu;
 }
 static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const float* tT, int K2P, int B, int C,
-                       const float* x, float* x1) {
-  if (row_fast_ok(g, C)) {
+                       const float* x, float* x1, int act_in = 0) {
+  if (act_in && !row_chan_ok(g, K2P, C)) return fail(FNO_EUNSUPPORTED, "input_gelu needs <= 64 channels, rows <= 320, <= 32 kept bins");
+  if (!act_in && row_fast_ok(g, C)) {
     RowDftArgs a;
     a.x = x; a.x1 = x1; a.tfwd = tfwd; a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2out = g.Klast; a.NJ = g.NJ;
     a.tiles_per_plane = g.PW / 128; a.ntiles = B * a.tiles_per_plane;
@@ -486,7 +490,7 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const f
   }
   static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
   static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 320;
-  if (chan && K2P) {
+  if ((chan || act_in) && K2P) {
     // lanes <-> channels, persistent workgroups with a register-prefetched tile: <= 64 channels, <= 320 floats per channel run
     int rb = std::max(1, std::min(chan_rb, 320 / g.W));
     while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
@@ -495,9 +499,9 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const f
       const int ntiles = B * ((g.P + rb - 1) / rb);
       const int per_cu = std::max(1, (int)std::min<size_t>(4, (160 * 1024) / lds));
       const dim3 grid(std::min(ntiles, per_cu * dev_ncu())), blk(256);
-      if (K2P == 8) return launch("k_rowdft_chan", k_rowdft_chan<8>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
-      if (K2P == 16) return launch("k_rowdft_chan", k_rowdft_chan<16>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
-      return launch("k_rowdft_chan", k_rowdft_chan<32>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles);
+      if (K2P == 8) return launch("k_rowdft_chan", k_rowdft_chan<8>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
+      if (K2P == 16) return launch("k_rowdft_chan", k_rowdft_chan<16>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
+      return launch("k_rowdft_chan", k_rowdft_chan<32>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
     }
   }
   // rows per workgroup: as many as keep the tile + table under 64 KB (several workgroups per CU), at most 8
@@ -566,7 +570,7 @@ extern "C" int fno_spec_forward(const FnoSpecPlan* p, int B, const float* x, con
   SpecWs w = carve_spec(p, B, ws, ws_bytes, &ok);
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   float* hat = xhat_save ? xhat_save : w.hat_in;
-  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, Cin, x, w.x1));
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, Cin, x, w.x1, p->d.input_gelu));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, Cin, w.x1, w.tmp, hat));
   LAUNCHCHK(pack_w(st, g, Cin, Cout, wc, w.wp, xhat_save ? xhat_save + spec_xhat_floats(p, B) : w.wpt));
   LAUNCHCHK(mode_gemm(st, hat, w.wp, w.hat_out, B, g.Ktot, Cin, Cout, 0));
@@ -1403,19 +1407,20 @@ extern "C" size_t fno_pointwise_workspace_bytes(int C) {
   return ((size_t)grid * 2 * C * C + (size_t)grid * C) * sizeof(float) + 1024;
 }
 extern "C" int fno_pointwise_forward(int B, int C, size_t PW, const float* x, const float* w, const float* bias,
-                                     const float* addend, float* y, void* stream) {
+                                     const float* addend, int input_gelu, float* y, void* stream) {
   LAUNCHCHK(pw_check(B, C, PW));
   if (!x || !w || !y) return fail(FNO_EINVAL, "fno_pointwise_forward: null argument");
   FnoModelPlan p = pw_shell(C);
   PwFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.w = w; a.bias = bias; a.add = addend; a.u = y;
+  a.x = x; a.w = w; a.bias = bias; a.add = addend; a.u = y; a.act_in = input_gelu ? 1 : 0;
   a.PW = (int)PW; a.W = 128; a.P = (int)(PW / 128);
   a.tiles_per_plane = (int)(PW / 128); a.ntiles = B * a.tiles_per_plane;
   return launch_block(&p, (hipStream_t)stream, std::min(a.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p.ncu), a);
 }
-extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, const float* w, const float* dy, float* dx,
-                                      float* dw, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, const float* w, const float* dy,
+                                      const float* dx_addend, int input_gelu, float* dx, float* dw, float* dbias, void* ws,
+                                      size_t ws_bytes, void* stream) {
   LAUNCHCHK(pw_check(B, C, PW));
   if (!x || !w || !dy || !dw || !ws) return fail(FNO_EINVAL, "fno_pointwise_backward: null argument");
   if (ws_bytes < fno_pointwise_workspace_bytes(C)) return fail(FNO_ENOMEM, "workspace too small");
@@ -1430,7 +1435,9 @@ extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, c
   if (!c.ok) return fail(FNO_ENOMEM, "workspace too small");
   BlkBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = dy; a.uin = x; a.w = w; a.gout = dx; a.dw_part = dw_part; a.db_part = db_part;
+  if (dx_addend && !dx) return fail(FNO_EINVAL, "fno_pointwise_backward: dx_addend without dx");
+  a.g = dy; a.uin = x; a.w = w; a.gout = dx; a.gadd = dx_addend; a.act_in = input_gelu ? 1 : 0;
+  a.dw_part = dw_part; a.db_part = db_part;
   a.PW = (int)PW; a.W = 128; a.P = tiles; a.tiles_per_plane = tiles; a.ntiles = ntiles;
   LAUNCHCHK(launch_bbwd(&p, st, grid, a));
   JobList jobs;

@@ -27,6 +27,7 @@ struct BlkBwdArgs {
   const float* uin;    // (B, C, PW)
   const float* w;      // (C, C) [o][i]
   const float* zg;     // (B, P, K2in, C, 2) or null
+  const float* gadd;   // (B, C, PW) added to dx before the activation derivative, or null
   const float* tinv;   // (2*K2in, W)
   float* gout;         // (B, C, PW) or null
   float* x1g;          // (B, P, K2out, C, 2) or null
@@ -147,6 +148,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
 #pragma unroll 2
       for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
+    }
+    if (a.gadd) {
+      const float* ap = a.gadd + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
     }
     FNO_STAMP(tslot + 4);
     // ---- activation derivative; us becomes a_l = act(u_l) in place --------
@@ -445,6 +451,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
 #pragma unroll 2
       for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
+    }
+    if (a.gadd) {
+      const float* ap = a.gadd + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
     }
     FNO_STAMP(tslot + 8);
     {

@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restric
 template <int K2P>
 __global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x, float2* __restrict__ x1,
                                                      const float* __restrict__ tT, int C, int P, int W, int K2, int RB,
-                                                     int ntiles) {
+                                                     int ntiles, int act_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                                 // [c][RB*W + 1]
   const int nblk = (P + RB - 1) / RB;
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x
     for (int k = 0; k < 16; ++k)
 #pragma unroll
       for (int j = 0; j < 5; ++j)
-        if (wave + 4 * k < C && lane + 64 * j < seg) xs[(wave + 4 * k) * pitch + lane + 64 * j] = v[k][j];
+        if (wave + 4 * k < C && lane + 64 * j < seg) xs[(wave + 4 * k) * pitch + lane + 64 * j] = act_in ? gelu_f(v[k][j]) : v[k][j];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
     for (int it = threadIdx.x; it < nr * C; it += blockDim.x) {

@@ -36,8 +36,8 @@ def _bytes(n, device):
 # ----------------------------------------------------------------------------
 # standalone spectral convolution
 # ----------------------------------------------------------------------------
-def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device):
-    key = (ndim, cin, cout, tuple(dims), tuple(modes), weight_last_extent, norm, device.index)
+def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, input_gelu=False):
+    key = (ndim, cin, cout, tuple(dims), tuple(modes), weight_last_extent, norm, device.index, bool(input_gelu))
     plan = _spec_plans.get(key)
     if plan is None:
         d = _lib.FnoSpecDesc()
@@ -46,6 +46,7 @@ def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device):
             d.dims[i], d.modes[i] = int(dims[i]), int(modes[i])
         d.weight_last_extent = int(weight_last_extent)
         d.norm = _lib.NORM_CODES[norm]
+        d.input_gelu = 1 if input_gelu else 0
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().fno_spec_plan_create(C.byref(d), C.byref(h)), "spec_plan_create")
@@ -711,7 +712,7 @@ class _PointwiseAddFn(torch.autograd.Function):
         b_c = bias.contiguous() if bias is not None else None
         y = torch.empty_like(x)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().fno_pointwise_forward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(b_c), _ptr(add_c), _ptr(y),
+            _lib.check(_lib.lib().fno_pointwise_forward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(b_c), _ptr(add_c), 0, _ptr(y),
                                                         _stream()), "pointwise_forward")
         ctx.save_for_backward(x, w2)
         ctx.meta = (B, Cc, pw, w.shape, bias is not None, addend is not None)
@@ -729,8 +730,8 @@ class _PointwiseAddFn(torch.autograd.Function):
         nws = L.fno_pointwise_workspace_bytes(Cc)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.fno_pointwise_backward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
-                                                nws, _stream()), "pointwise_backward")
+            _lib.check(L.fno_pointwise_backward(B, Cc, pw, _ptr(x), _ptr(w2), _ptr(dy), None, 0, _ptr(dx), _ptr(dw), _ptr(db),
+                                                _ptr(ws), nws, _stream()), "pointwise_backward")
         return dx, dw.view(wshape), db, (dy if has_add else None)
 
 
@@ -738,6 +739,97 @@ def pointwise_conv_add(x, w, bias=None, addend=None):
     """y = conv1x1(x; w) + bias + addend  (x, addend (B, C, ...), w (C, C[, 1..]), C in {32, 64}) in one engine
     kernel each way; the gradient of `addend` is the incoming gradient itself."""
     return _PointwiseAddFn.apply(x, w, bias, addend)
+
+
+# ----------------------------------------------------------------------------
+# one layer of the observer stacks:  y = SpectralConv(a) + Conv1d_{k=1}(a) + bias,  a = gelu(u) or u
+# ----------------------------------------------------------------------------
+def spectral_layer_supported(u, n_spec_weights, modes, norm, weight_last_extent, input_gelu):
+    """True when spectral_pointwise_layer can run this shape (result cached per shape)."""
+    if not pointwise_supported(u) or n_spec_weights != 2 ** (u.dim() - 3):
+        return False
+    key = ("layer", u.dim() - 2, u.shape[1], tuple(u.shape[2:]), tuple(modes), weight_last_extent, norm, u.device.index, bool(input_gelu))
+    ok = _spec_plans.get(key)
+    if ok is None:
+        try:
+            spec_plan(u.dim() - 2, u.shape[1], u.shape[1], tuple(u.shape[2:]), modes, weight_last_extent, norm, u.device, input_gelu)
+            ok = True
+        except RuntimeError:
+            ok = False
+        _spec_plans[key] = ok
+    return ok
+
+
+class _SpectralLayerFn(torch.autograd.Function):
+    """forward: sp = fno_spec_forward(u) [gelu on load], y = fno_pointwise_forward(u, addend = sp) [gelu on load].
+    backward: (d_a from the spectral branch, dW_spec) = fno_spec_backward(dy); fno_pointwise_backward adds it to W^T dy,
+    applies gelu'(u) and writes du: no separate activation, activation-derivative or gradient-accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, u, w, bias, modes, norm, wle, input_gelu, direct, *spec_ws):
+        _require_cuda(u, "u")
+        u = u.contiguous()
+        B, Cc = u.shape[0], u.shape[1]
+        dims = tuple(u.shape[2:])
+        pw = u.numel() // (B * Cc)
+        ws_list = [t.contiguous() for t in spec_ws]
+        L = _lib.lib()
+        plan = spec_plan(len(dims), Cc, Cc, dims, modes, wle, norm, u.device, input_gelu)
+        sp = torch.empty_like(u)
+        xhat = _bytes(L.fno_spec_xhat_bytes(plan, B), u.device)
+        nws = L.fno_spec_workspace_bytes(plan, B)
+        ws = _bytes(nws, u.device)
+        wp = (C.c_void_p * 4)(*[t.data_ptr() for t in ws_list] + [0] * (4 - len(ws_list)))
+        w2 = w.reshape(Cc, Cc).contiguous()
+        b_c = bias.contiguous() if bias is not None else None
+        y = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            _lib.check(L.fno_spec_forward(plan, B, _ptr(u), wp, None, _ptr(sp), _ptr(xhat), _ptr(ws), nws, _stream()), "spec_forward")
+            _lib.check(L.fno_pointwise_forward(B, Cc, pw, _ptr(u), _ptr(w2), _ptr(b_c), _ptr(sp), 1 if input_gelu else 0, _ptr(y),
+                                               _stream()), "pointwise_forward")
+        ctx.plan, ctx.meta, ctx.direct = plan, (B, Cc, pw, w.shape, bias is not None, bool(input_gelu)), direct
+        ctx.save_for_backward(u, w2, xhat, *ws_list)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, w2, xhat, *ws_list = ctx.saved_tensors
+        B, Cc, pw, wshape, has_b, input_gelu = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        need_du = ctx.needs_input_grad[0]
+        need_dws = any(ctx.needs_input_grad[8:])
+        direct = ctx.direct if need_dws else None
+        dws = (direct if direct is not None else [torch.empty_like(t) for t in ws_list]) if need_dws else None
+        da = torch.empty_like(u) if need_du else None           # gradient reaching gelu(u) through the spectral branch
+        du = torch.empty_like(u) if need_du else None
+        dw = torch.empty_like(w2)
+        db = torch.empty(Cc, dtype=torch.float32, device=u.device) if has_b else None
+        nws = L.fno_spec_workspace_bytes(ctx.plan, B)
+        ws = _bytes(nws, u.device)
+        nws2 = L.fno_pointwise_workspace_bytes(Cc)
+        ws2 = _bytes(nws2, u.device)
+        dwp = (C.c_void_p * 4)(*[t.data_ptr() for t in dws] + [0] * (4 - len(dws))) if need_dws else None
+        with torch.cuda.device(u.device):
+            _lib.check(L.fno_spec_backward(ctx.plan, B, _ptr(dy), _ptr(xhat), None, _ptr(da), dwp, None, _ptr(ws), nws, _stream()),
+                       "spec_backward")
+            _lib.check(L.fno_pointwise_backward(B, Cc, pw, _ptr(u), _ptr(w2), _ptr(dy), _ptr(da), 1 if input_gelu else 0, _ptr(du),
+                                                _ptr(dw), _ptr(db), _ptr(ws2), nws2, _stream()), "pointwise_backward")
+        gw = (None,) * len(ws_list) if (direct is not None or not need_dws) else tuple(dws)
+        return (du, dw.view(wshape), db, None, None, None, None, None) + gw
+
+
+def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=False, weight_last_extent=None,
+                             direct_grads=False):
+    """y = SpectralConv(a) + Conv1d_{k=1}(a; w) + bias with a = gelu(u) if input_gelu else u: one layer of the observer
+    stacks (libs/models/pino_models/pinobserver.py:221-226) with the PREVIOUS layer's activation applied while u is
+    loaded, so a stack is chained on pre-activation tensors.  Check spectral_layer_supported() first."""
+    sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_weights]
+    wle = int(weight_last_extent) if weight_last_extent is not None else int(sw[0].shape[-2])
+    direct = None
+    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_weights):
+        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_weights]
+    return _SpectralLayerFn.apply(u, w, bias, tuple(int(m) for m in modes), norm, wle, bool(input_gelu), direct, *sw)
 
 
 # ----------------------------------------------------------------------------

@@ -41,6 +41,11 @@ class SpectralConv3d(nn.Module):
     def direct_grad_params(self):
         return [self.weights1, self.weights2, self.weights3, self.weights4]
 
+    def engine_call(self, x):
+        """(corner weights in the engine's order, kept modes, stored last-dim extent) for an input of x's shape"""
+        k3 = min(x.shape[-1] // 2 + 1, self.modes3)
+        return [self.weights1, self.weights3, self.weights2, self.weights4], (self.modes1, self.modes2, k3), self.modes3
+
     def forward(self, x):
         # reference corner order: weights1 (lo,lo), weights2 (hi,lo), weights3 (lo,hi), weights4 (hi,hi)
         # (basics.py:125-139); the engine takes (lo,lo), (lo,hi), (hi,lo), (hi,hi).  Only

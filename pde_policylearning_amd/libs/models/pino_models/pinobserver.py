@@ -73,7 +73,24 @@ class _SpectralStack(nn.Module):
                                        for i, o, m1, m2, m3 in zip(layers, layers[1:], modes1, modes2, modes3)])
         self.ws = nn.ModuleList([nn.Conv1d(i, o, 1) for i, o in zip(layers, layers[1:])])
 
+    def _chain_supported(self, x):
+        if self.act is not TF.gelu or len(set(self.layers)) != 1:
+            return False
+        for i, conv in enumerate(self.sp_convs):
+            ws, modes, wle = conv.engine_call(x)
+            if not F.spectral_layer_supported(x, len(ws), modes, "backward", wle, i > 0):
+                return False
+        return True
+
     def _run_stack(self, x):
+        if self._chain_supported(x):
+            # the stack chained on PRE-activation tensors: each layer applies the previous layer's GELU while it loads its
+            # input (spectral rows and channel mix alike) and its backward folds gelu' and the two-branch gradient sum in
+            for i, (conv, w) in enumerate(zip(self.sp_convs, self.ws)):
+                ws, modes, wle = conv.engine_call(x)
+                x = F.spectral_pointwise_layer(x, ws, modes, "backward", w.weight, w.bias, input_gelu=i > 0,
+                                               weight_last_extent=wle, direct_grads=getattr(conv, "_direct_grads", False))
+            return x
         b = x.shape[0]
         sx, sy, sz = x.shape[-3:]
         last = len(self.ws) - 1

@@ -33,8 +33,8 @@ def test_header_symbols_exported(lib):
 
 def test_struct_layout_matches_header(lib):
     from pde_policylearning_amd import _lib
-    # FnoSpecDesc: 3 + 3 + 3 + 2 ints ; FnoModelDesc: 6 + 3 + 3 + 2 ints
-    assert ctypes.sizeof(_lib.FnoSpecDesc) == 11 * 4
+    # FnoSpecDesc: 3 + 3 + 3 + 3 ints ; FnoModelDesc: 6 + 3 + 3 + 2 ints
+    assert ctypes.sizeof(_lib.FnoSpecDesc) == 12 * 4
     assert ctypes.sizeof(_lib.FnoModelDesc) == 14 * 4
     assert ctypes.sizeof(_lib.FnoModelParams) == 8 * (2 + 16 + 64 + 1 + 4)
 

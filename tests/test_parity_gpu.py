@@ -1114,3 +1114,35 @@ def test_pino_direct_gradient_write_matches_autograd(dev):
     for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
         a, b = (torch.view_as_real(t.data) if t.is_complex() else t.data for t in (p, q))
         assert float((a - b).norm()) <= 1e-4 * float(b.norm()), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,width,modes", [((16, 16, 9), 32, (4, 4, 3)), ((8, 16, 73), 64, (4, 8, 8)), ((32, 32, 1), 64, (12, 12, 12))])
+def test_pino_stack_chained_on_preactivations(dev, dims, width, modes):
+    """The observer stack chained on pre-activation tensors (F.spectral_pointwise_layer: GELU on load in fno_spec_forward and
+    fno_pointwise_forward, gelu' and the two-branch gradient sum inside fno_pointwise_backward) against the layer-by-layer
+    composition with torch GELU: output, input gradient and every parameter gradient."""
+    from pde_policylearning_amd.libs.models.pino_models.pinobserver import PlanePredHead
+    torch.manual_seed(5)
+    head = PlanePredHead([width] * 5, [modes[0]] * 4, [modes[1]] * 4, [modes[2]] * 4, 32, 2, "gelu").to(dev)
+    with torch.no_grad():
+        for conv in head.sp_convs:
+            for p in conv.parameters():
+                p.mul_(40.0)                       # make the spectral branch comparable to the pointwise one
+    x = torch.randn((2, width) + dims, device=dev, requires_grad=True)
+    dy = torch.randn((2, width) + dims, device=dev)
+    assert head._chain_supported(x)
+    y1 = head._run_stack(x)
+    y1.backward(dy)
+    g1 = [x.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
+    x.grad = None
+    head.zero_grad(set_to_none=True)
+    head._chain_supported = lambda t: False
+    y2 = head._run_stack(x)
+    y2.backward(dy)
+    g2 = [x.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
+    assert rel_l2(_cpu(y1), _cpu(y2)) < 1e-5
+    assert len(g1) == len(g2) == 1 + 4 * 4 + 4 * 2
+    for a, b in zip(g1, g2):
+        a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+        assert float((a - b).norm()) <= 2e-5 * float(b.norm()), tuple(a.shape)
