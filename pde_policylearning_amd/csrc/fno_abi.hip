@@ -491,17 +491,40 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const f
   static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
   static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 320;
   if ((chan || act_in) && K2P) {
-    // lanes <-> channels, persistent workgroups with a register-prefetched tile: <= 64 channels, <= 320 floats per channel run
-    int rb = std::max(1, std::min(chan_rb, 320 / g.W));
-    while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
-    const size_t lds = (size_t)C * (rb * g.W + 1) * 4;
-    if (C <= 64 && g.W <= 320 && lds <= 160 * 1024) {
+    // long 16-byte-aligned runs when the rows allow it: 8 channels x rb rows, rb * W % 4 == 0, P % rb == 0
+    static const int run4 = getenv("FNO_ROW_RUN4") ? atoi(getenv("FNO_ROW_RUN4")) : 1;
+    if (run4 && C % 8 == 0) {
+      const int q = (g.W % 4 == 0) ? 1 : (g.W % 2 == 0 ? 2 : 4);            // rows per 16-byte period
+      int rb = std::min(2560 / g.W, (int)((80 * 1024 / 4 / 8 - 1) / g.W)) / q * q;
+      while (rb >= q && (g.P % rb != 0 || (long)B * (C / 8) * (g.P / rb) < 4L * dev_ncu())) rb -= q;
+      if (rb >= q && rb * g.W >= 256) {
+        const size_t lds = (size_t)8 * (rb * g.W + 1) * 4;
+        const int ntiles = B * (C / 8) * (g.P / rb);
+        const int per_cu = std::max(1, (int)std::min<size_t>(4, (160 * 1024) / lds));
+        const dim3 grid(std::min(ntiles, per_cu * dev_ncu())), blk(256);
+#define ROWDFT_CHAN4(K) launch("k_rowdft_chan4", k_rowdft_chan4<K>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in)
+        if (K2P == 8) return ROWDFT_CHAN4(8);
+        if (K2P == 16) return ROWDFT_CHAN4(16);
+        return ROWDFT_CHAN4(32);
+#undef ROWDFT_CHAN4
+      }
+    }
+    // lanes <-> channels, persistent workgroups with a register-prefetched tile of CG channels x rb rows
+    const int cg = 64, sl = 5;                      // one group of <= 64 channels, runs of <= 320 floats
+    if (C <= 64 && g.W <= sl * 64) {
+      int rb = std::max(1, std::min(std::min(chan_rb, g.P), sl * 64 / g.W));
+      rb = std::max(1, std::min(rb, (int)((80 * 1024 / 4 / C - 1) / g.W)));
+      while (rb > 1 && (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu()) rb >>= 1;
+      const size_t lds = (size_t)C * (rb * g.W + 1) * 4;
       const int ntiles = B * ((g.P + rb - 1) / rb);
       const int per_cu = std::max(1, (int)std::min<size_t>(4, (160 * 1024) / lds));
       const dim3 grid(std::min(ntiles, per_cu * dev_ncu())), blk(256);
-      if (K2P == 8) return launch("k_rowdft_chan", k_rowdft_chan<8>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
-      if (K2P == 16) return launch("k_rowdft_chan", k_rowdft_chan<16>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
-      return launch("k_rowdft_chan", k_rowdft_chan<32>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in);
+      (void)cg;
+#define ROWDFT_CHAN(K) launch("k_rowdft_chan", k_rowdft_chan<K, 16>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in)
+      if (K2P == 8) return ROWDFT_CHAN(8);
+      if (K2P == 16) return ROWDFT_CHAN(16);
+      return ROWDFT_CHAN(32);
+#undef ROWDFT_CHAN
     }
   }
   // rows per workgroup: as many as keep the tile + table under 64 KB (several workgroups per CU), at most 8

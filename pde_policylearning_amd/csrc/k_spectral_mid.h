@@ -514,45 +514,49 @@ __global__ void __launch_bounds__(256) k_rowidft_generic(const float2* __restric
 // its bins in registers; the table row of the current w is wave-uniform and comes through the scalar cache
 // (tT = [W][2*K2P], zero-padded bins), so the LDS only carries the activation tile: one 4-byte access per 2*K2P FMAs
 // instead of one broadcast read per FMA pair.  Tile [C][RB*W + 1]: odd pitch, conflict-free along c.
-// Persistent workgroups: while the current tile is transformed out of the LDS, the whole next tile (<= 16 channels x
-// 320 floats per wave = 80 registers per lane) is already in flight from HBM, so the load latency overlaps the FMA loop.
-template <int K2P>
+// Persistent workgroups: while the current tile is transformed out of the LDS, the whole next tile (80 registers per lane) is
+// already in flight from HBM, so the load latency overlaps the FMA loop.  A tile is CG = 4 * CPW channels x RB rows: a wave
+// owns CPW channels and 80 / CPW 64-float slots of each channel's contiguous RB*W run (CPW = 16: all of <= 64 channels, runs
+// of <= 320 floats; used when the rows do not allow the 16-byte variant below).
+template <int K2P, int CPW>
 __global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x, float2* __restrict__ x1,
                                                      const float* __restrict__ tT, int C, int P, int W, int K2, int RB,
                                                      int ntiles, int act_in) {
+  constexpr int SL = 80 / CPW, CG = 4 * CPW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                                 // [c][RB*W + 1]
-  const int nblk = (P + RB - 1) / RB;
+  float* xs = smem;                                 // [CG][RB*W + 1]
+  const int nblk = (P + RB - 1) / RB, ncg = (C + CG - 1) / CG;
   const int pitch = RB * W + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // 4 waves
   const size_t cstride = (size_t)P * W;
-  float v[16][5];                                   // channel wave + 4k, floats lane + 64 j of the tile's nr*W run
+  float v[CPW][SL];                                 // channel wave + 4k of the group, floats lane + 64 j of the nr*W run
   auto fetch = [&](int tile) {
-    const int b = tile / nblk, p0 = (tile % nblk) * RB;
-    const int seg = min(RB, P - p0) * W;
+    const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
+    const int p0 = pb * RB, seg = min(RB, P - p0) * W;
     const float* xb = x + ((size_t)b * C * P + p0) * W;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < CPW; ++k)
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        v[k][j] = xb[(size_t)min(wave + 4 * k, C - 1) * cstride + min(lane + 64 * j, seg - 1)];   // clamped: no branches
+      for (int j = 0; j < SL; ++j)
+        v[k][j] = xb[(size_t)min(cg * CG + wave + 4 * k, C - 1) * cstride + min(lane + 64 * j, seg - 1)];   // clamped: no branches
   };
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += gridDim.x) {
-    const int b = tile / nblk, p0 = (tile % nblk) * RB;
-    const int nr = min(RB, P - p0), seg = nr * W;
+    const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
+    const int p0 = pb * RB, nr = min(RB, P - p0), seg = nr * W;
+    const int ncl = min(CG, C - cg * CG);           // channels of this group
     __syncthreads();                                // previous tile's readers are done
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < CPW; ++k)
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (wave + 4 * k < C && lane + 64 * j < seg) xs[(wave + 4 * k) * pitch + lane + 64 * j] = act_in ? gelu_f(v[k][j]) : v[k][j];
+      for (int j = 0; j < SL; ++j)
+        if (wave + 4 * k < ncl && lane + 64 * j < seg) xs[(wave + 4 * k) * pitch + lane + 64 * j] = act_in ? gelu_f(v[k][j]) : v[k][j];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-    for (int it = threadIdx.x; it < nr * C; it += blockDim.x) {
-      const int r = it / C, c = it - r * C;
-      const float* xr = xs + c * pitch + r * W;
+    for (int it = threadIdx.x; it < nr * ncl; it += blockDim.x) {
+      const int r = it / ncl, lc = it - r * ncl;
+      const float* xr = xs + lc * pitch + r * W;
       float acc[2 * K2P];
 #pragma unroll
       for (int j = 0; j < 2 * K2P; ++j) acc[j] = 0.f;
@@ -566,7 +570,71 @@ __global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x
       const size_t row = (size_t)b * P + p0 + r;
 #pragma unroll
       for (int k2 = 0; k2 < K2P; ++k2)
-        if (k2 < K2) x1[(row * K2 + k2) * C + c] = make_float2(acc[2 * k2], acc[2 * k2 + 1]);
+        if (k2 < K2) x1[(row * K2 + k2) * C + cg * CG + lc] = make_float2(acc[2 * k2], acc[2 * k2 + 1]);
+    }
+  }
+}
+
+// Long-run variant: tile = 8 channels x RB rows with RB*W % 4 == 0 and P % RB == 0, so every channel run starts 16-byte
+// aligned and is a whole number of float4: a wave owns 2 channels x 10 slots of 64 float4 (runs of <= 2560 floats).
+// 16-byte requests: four times fewer outstanding misses per byte in flight than the dword staging above.
+template <int K2P>
+__global__ void __launch_bounds__(256) k_rowdft_chan4(const float* __restrict__ x, float2* __restrict__ x1,
+                                                      const float* __restrict__ tT, int C, int P, int W, int K2, int RB,
+                                                      int ntiles, int act_in) {
+  constexpr int CPW = 2, SL = 10, CG = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                                 // [CG][RB*W + 1]
+  const int nblk = P / RB, ncg = (C + CG - 1) / CG;
+  const int seg = RB * W, seg4 = seg / 4, pitch = seg + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t cstride = (size_t)P * W;
+  float4 v[CPW][SL];
+  auto fetch = [&](int tile) {
+    const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
+    const float* xb = x + ((size_t)b * C * P + (size_t)pb * RB) * W;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+#pragma unroll
+      for (int j = 0; j < SL; ++j)
+        v[k][j] = ld4(xb + (size_t)min(cg * CG + wave + 4 * k, C - 1) * cstride + 4 * min(lane + 64 * j, seg4 - 1));
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
+    const int p0 = pb * RB;
+    const int ncl = min(CG, C - cg * CG);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+#pragma unroll
+      for (int j = 0; j < SL; ++j)
+        if (wave + 4 * k < ncl && lane + 64 * j < seg4) {
+          float* d = xs + (wave + 4 * k) * pitch + 4 * (lane + 64 * j);
+          float4 q = v[k][j];
+          if (act_in) { q.x = gelu_f(q.x); q.y = gelu_f(q.y); q.z = gelu_f(q.z); q.w = gelu_f(q.w); }
+          d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    for (int it = threadIdx.x; it < RB * ncl; it += blockDim.x) {
+      const int r = it / ncl, lc = it - r * ncl;
+      const float* xr = xs + lc * pitch + r * W;
+      float acc[2 * K2P];
+#pragma unroll
+      for (int j = 0; j < 2 * K2P; ++j) acc[j] = 0.f;
+#pragma unroll 4
+      for (int w = 0; w < W; ++w) {
+        const float xv = xr[w];
+        const float* t = tT + (size_t)w * 2 * K2P;
+#pragma unroll
+        for (int j = 0; j < 2 * K2P; ++j) acc[j] = fmaf(xv, t[j], acc[j]);
+      }
+      const size_t row = (size_t)b * P + p0 + r;
+#pragma unroll
+      for (int k2 = 0; k2 < K2P; ++k2)
+        if (k2 < K2) x1[(row * K2 + k2) * C + cg * CG + lc] = make_float2(acc[2 * k2], acc[2 * k2 + 1]);
     }
   }
 }
