@@ -495,14 +495,15 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const f
     static const int run4 = getenv("FNO_ROW_RUN4") ? atoi(getenv("FNO_ROW_RUN4")) : 1;
     if (run4 && C % 8 == 0) {
       const int q = (g.W % 4 == 0) ? 1 : (g.W % 2 == 0 ? 2 : 4);            // rows per 16-byte period
-      int rb = std::min(2560 / g.W, (int)((80 * 1024 / 4 / 8 - 1) / g.W)) / q * q;
+      const int tabf = 2 * K2P * rowdft4_pitch((g.W + 3) & ~3) + 4;         // table + slack floats in the same LDS
+      int rb = std::min(2560 / g.W, (int)(((80 * 1024 / 4 - tabf) / 8 - 36) / g.W)) / q * q;
       while (rb >= q && (g.P % rb != 0 || (long)B * (C / 8) * (g.P / rb) < 4L * dev_ncu())) rb -= q;
       if (rb >= q && rb * g.W >= 256) {
-        const size_t lds = (size_t)8 * (rb * g.W + 1) * 4;
+        const size_t lds = ((size_t)8 * rowdft4_pitch(rb * g.W) + 4 + (size_t)2 * K2P * rowdft4_pitch((g.W + 3) & ~3)) * 4;
         const int ntiles = B * (C / 8) * (g.P / rb);
         const int per_cu = std::max(1, (int)std::min<size_t>(4, (160 * 1024) / lds));
         const dim3 grid(std::min(ntiles, per_cu * dev_ncu())), blk(256);
-#define ROWDFT_CHAN4(K) launch("k_rowdft_chan4", k_rowdft_chan4<K>, grid, blk, lds, st, x, (float2*)x1, tT, C, g.P, g.W, g.Klast, rb, ntiles, act_in)
+#define ROWDFT_CHAN4(K) launch("k_rowdft_chan4", k_rowdft_chan4<K>, grid, blk, lds, st, x, (float2*)x1, tfwd, C, g.P, g.W, g.Klast, rb, ntiles, act_in, 16 * g.NJ)
         if (K2P == 8) return ROWDFT_CHAN4(8);
         if (K2P == 16) return ROWDFT_CHAN4(16);
         return ROWDFT_CHAN4(32);

@@ -578,17 +578,30 @@ __global__ void __launch_bounds__(256) k_rowdft_chan(const float* __restrict__ x
 // Long-run variant: tile = 8 channels x RB rows with RB*W % 4 == 0 and P % RB == 0, so every channel run starts 16-byte
 // aligned and is a whole number of float4: a wave owns 2 channels x 10 slots of 64 float4 (runs of <= 2560 floats).
 // 16-byte requests: four times fewer outstanding misses per byte in flight than the dword staging above.
+// smallest pitch > n that is 4 mod 32
+static __host__ __device__ inline int rowdft4_pitch(int n) { return n + 1 + ((4 - (n + 1) % 32) + 32) % 32; }
+
 template <int K2P>
 __global__ void __launch_bounds__(256) k_rowdft_chan4(const float* __restrict__ x, float2* __restrict__ x1,
-                                                      const float* __restrict__ tT, int C, int P, int W, int K2, int RB,
-                                                      int ntiles, int act_in) {
-  constexpr int CPW = 2, SL = 10, CG = 8;
+                                                      const float* __restrict__ tfwd, int C, int P, int W, int K2, int RB,
+                                                      int ntiles, int act_in, int trows) {
+  constexpr int CPW = 2, SL = 10, CG = 8, NJT = K2P / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                                 // [CG][RB*W + 1]
+  const int seg = RB * W, seg4 = seg / 4;
+  const int pitch = rowdft4_pitch(seg), TP = rowdft4_pitch((W + 3) & ~3);   // both = 4 mod 32: 2-way (minimal) conflicts on the MFMA operand reads
+  float* xs = smem;                                 // [CG][pitch] + 4 floats of slack (k-padding reads)
+  float* tab = smem + CG * pitch + 4;               // [16 * NJT][TP]   rows (2 k2, 2 k2 + 1) = (cos, -sin) of bin k2
   const int nblk = P / RB, ncg = (C + CG - 1) / CG;
-  const int seg = RB * W, seg4 = seg / 4, pitch = seg + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
   const size_t cstride = (size_t)P * W;
+  for (int i = threadIdx.x; i < 16 * NJT * TP; i += blockDim.x) {
+    const int j = i / TP, w = i - j * TP;
+    tab[i] = (j < trows && w < W) ? tfwd[(size_t)j * W + w] : 0.f;
+  }
+  if (threadIdx.x < 4) xs[CG * pitch + threadIdx.x] = 0.f;
+  for (int i = threadIdx.x; i < CG * (pitch - seg); i += blockDim.x)   // the pad of every channel run is read (times a zero table entry)
+    xs[(i / (pitch - seg)) * pitch + seg + i % (pitch - seg)] = 0.f;
   float4 v[CPW][SL];
   auto fetch = [&](int tile) {
     const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
@@ -601,6 +614,7 @@ __global__ void __launch_bounds__(256) k_rowdft_chan4(const float* __restrict__ 
   };
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
+  const int nsteps = (W + 3) / 4;
   for (; tile < ntiles; tile += gridDim.x) {
     const int pb = tile % nblk, cg = (tile / nblk) % ncg, b = tile / (nblk * ncg);
     const int p0 = pb * RB;
@@ -610,7 +624,7 @@ __global__ void __launch_bounds__(256) k_rowdft_chan4(const float* __restrict__ 
     for (int k = 0; k < CPW; ++k)
 #pragma unroll
       for (int j = 0; j < SL; ++j)
-        if (wave + 4 * k < ncl && lane + 64 * j < seg4) {
+        if (lane + 64 * j < seg4) {                 // channels past ncl hold a clamped copy: finite filler, never stored
           float* d = xs + (wave + 4 * k) * pitch + 4 * (lane + 64 * j);
           float4 q = v[k][j];
           if (act_in) { q.x = gelu_f(q.x); q.y = gelu_f(q.y); q.z = gelu_f(q.z); q.w = gelu_f(q.w); }
@@ -618,23 +632,32 @@ __global__ void __launch_bounds__(256) k_rowdft_chan4(const float* __restrict__ 
         }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-    for (int it = threadIdx.x; it < RB * ncl; it += blockDim.x) {
+    // X1^T[j][item] = sum_w T[j][w] x_item[w] on the fp32 matrix pipe: 16 table rows x 16 (row, channel) items per MFMA,
+    // k = 4 consecutive... (quad <-> w = 4 s + quad); both operands are 4-byte LDS reads, no per-w scalar traffic
+    const int nitems = RB * ncl;
+    for (int g = wave; g * 16 < nitems; g += 4) {
+      const int it = min(g * 16 + l15, nitems - 1);
       const int r = it / ncl, lc = it - r * ncl;
-      const float* xr = xs + lc * pitch + r * W;
-      float acc[2 * K2P];
+      const float* xr = xs + lc * pitch + r * W + quad;
 #pragma unroll
-      for (int j = 0; j < 2 * K2P; ++j) acc[j] = 0.f;
-#pragma unroll 4
-      for (int w = 0; w < W; ++w) {
-        const float xv = xr[w];
-        const float* t = tT + (size_t)w * 2 * K2P;
+      for (int jt = 0; jt < NJT; ++jt) {
+        const float* tr = tab + (jt * 16 + l15) * TP + quad;
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        int sidx = 0;
+        for (; sidx + 1 < nsteps; sidx += 2) {
+          d0 = mfma16(tr[4 * sidx], xr[4 * sidx], d0);
+          d1 = mfma16(tr[4 * sidx + 4], xr[4 * sidx + 4], d1);
+        }
+        if (sidx < nsteps) d0 = mfma16(tr[4 * sidx], xr[4 * sidx], d0);
+        if (g * 16 + l15 < nitems) {
+          const size_t row = (size_t)b * P + p0 + r;
 #pragma unroll
-        for (int j = 0; j < 2 * K2P; ++j) acc[j] = fmaf(xv, t[j], acc[j]);
+          for (int pr = 0; pr < 2; ++pr) {
+            const int k2 = jt * 8 + quad * 2 + pr;
+            if (k2 < K2) x1[(row * K2 + k2) * C + cg * CG + lc] = make_float2(d0[2 * pr] + d1[2 * pr], d0[2 * pr + 1] + d1[2 * pr + 1]);
+          }
+        }
       }
-      const size_t row = (size_t)b * P + p0 + r;
-#pragma unroll
-      for (int k2 = 0; k2 < K2P; ++k2)
-        if (k2 < K2) x1[(row * K2 + k2) * C + cg * CG + lc] = make_float2(acc[2 * k2], acc[2 * k2 + 1]);
     }
   }
 }

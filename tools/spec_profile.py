@@ -17,9 +17,13 @@ def run(name, shape, modes, norm, wle=None, live=None):
     print(name)
     for n, ms, k in _lib.profile_summary(): print(f"   {n:24s} {ms/k*1e3:9.1f} us x{k}")
     L.fno_profile_reset()
-run("RNO 32x64x128x128 m12", (32, 64, 128, 128), (12, 12), "ortho")
-run("PINO2d 1x64x128x128x73 m8", (1, 64, 128, 128, 73), (8, 8, 8), "backward", 8, (8, 8, 8))
-run("PINO fullfield 32x64x32x32x1 m12", (32, 64, 32, 32, 1), (12, 12, 12), "backward", 12, (12, 12, 1))
+only = os.environ.get("SPEC_ONLY", "")
+if only in ("", "rno"):
+    run("RNO 32x64x128x128 m12", (32, 64, 128, 128), (12, 12), "ortho")
+if only in ("", "pino2d"):
+    run("PINO2d 1x64x128x128x73 m8", (1, 64, 128, 128, 73), (8, 8, 8), "backward", 8, (8, 8, 8))
+if only in ("", "pinoff"):
+    run("PINO fullfield 32x64x32x32x1 m12", (32, 64, 32, 32, 1), (12, 12, 12), "backward", 12, (12, 12, 1))
 if os.environ.get("ROW_ALIGN_PROBE"):
     run("probe W=80 (row 320 B, 128 B-aligned tiles)", (1, 64, 128, 128, 80), (8, 8, 8), "backward", 8, (8, 8, 8))
     run("probe W=72 (row 288 B)", (1, 64, 128, 128, 72), (8, 8, 8), "backward", 8, (8, 8, 8))
