@@ -251,6 +251,18 @@ int fno_projection_forward(int batch, int channels, int hidden, int cout, size_t
 int fno_projection_backward(int batch, int channels, int hidden, int cout, size_t plane, const float* x,
                             const float* w1, const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
                             float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream);
+/* The same head with the hidden activation chosen by the caller: FNO_ACT_GELU (the two calls above) or FNO_ACT_RELU,
+ * the `Linear(freq_dim, 4 freq_dim) -> ReLU -> Linear(4 freq_dim, 1)` regressor that ends RNO2d
+ * (neuralop/models/rno.py:171-175, built with activation='relu' at :319-320; hidden width 256 only). */
+#define FNO_ACT_GELU 0
+#define FNO_ACT_RELU 1
+int fno_projection_forward_act(int batch, int channels, int hidden, int cout, size_t plane, const float* x,
+                               const float* w1, const float* b1, const float* w2, const float* b2, int hidden_act,
+                               float* y, void* stream);
+int fno_projection_backward_act(int batch, int channels, int hidden, int cout, size_t plane, const float* x,
+                                const float* w1, const float* b1, const float* w2, const float* dy, int hidden_act,
+                                float* dx, float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
+                                void* stream);
 
 /* ------------------------------------------------------------------------
  * Lifting layer on its own:  y = W x + b,  x (B, Cin <= 4, PW) -> y (B, C, PW), C in {32, 64}, PW % 128 == 0

@@ -97,6 +97,8 @@ def lib():
     L.fno_projection_workspace_bytes.restype = sz
     L.fno_projection_forward.argtypes = [ci, ci, ci, ci, sz] + [vp] * 7
     L.fno_projection_backward.argtypes = [ci, ci, ci, ci, sz] + [vp] * 11 + [sz, vp]
+    L.fno_projection_forward_act.argtypes = [ci, ci, ci, ci, sz] + [vp] * 5 + [ci, vp, vp]
+    L.fno_projection_backward_act.argtypes = [ci, ci, ci, ci, sz] + [vp] * 5 + [ci] + [vp] * 6 + [sz, vp]
     L.fno_lifting_workspace_bytes.argtypes = [ci]
     L.fno_lifting_workspace_bytes.restype = sz
     L.fno_lifting_forward.argtypes = [ci, ci, ci, sz, vp, vp, vp, vp, vp]
@@ -145,6 +147,7 @@ EXPORTED_SYMBOLS = [
     "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
     "fno_pointwise_workspace_bytes", "fno_pointwise_forward", "fno_pointwise_backward",
     "fno_projection_workspace_bytes", "fno_projection_forward", "fno_projection_backward",
+    "fno_projection_forward_act", "fno_projection_backward_act",
     "fno_lifting_workspace_bytes", "fno_lifting_forward", "fno_lifting_backward",
     "fno_rno_gate_partials", "fno_rno_reset_gate_forward", "fno_rno_reset_gate_backward",
     "fno_rno_output_gate_forward", "fno_rno_output_gate_backward",

@@ -1502,19 +1502,26 @@ extern "C" size_t fno_projection_workspace_bytes(int C, int hidden) {
   if ((C != 32 && C != 64) || (hidden != 128 && hidden != 256)) return 0;
   return carve_proj(C, hidden, nullptr, 0).total;
 }
-template <int C, int HID>
+template <int C, int HID, bool RELU>
 static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
   const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(HID / 32) * (C / 16) * 3 * 64 * 16 + (size_t)(HID + HID + 128) * 4;
-  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, 1>, dim3(grid), dim3(512), lds, st, a);
+  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
-template <int C, int HID>
+template <int C, int HID, bool RELU>
 static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
   const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
-  return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1>, dim3(grid), dim3(512), lds, st, a);
+  return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
-extern "C" int fno_projection_forward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
-                                      const float* b1, const float* w2, const float* b2, float* y, void* stream) {
+static int proj_act_check(int hidden, int act) {
+  if (act != FNO_ACT_GELU && act != FNO_ACT_RELU) return fail(FNO_EINVAL, "projection: hidden_act %d (FNO_ACT_GELU or FNO_ACT_RELU)", act);
+  if (act == FNO_ACT_RELU && hidden != 256) return fail(FNO_EUNSUPPORTED, "projection: the ReLU head is built for hidden width 256 (got %d)", hidden);
+  return FNO_OK;
+}
+extern "C" int fno_projection_forward_act(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                          const float* b1, const float* w2, const float* b2, int hidden_act, float* y,
+                                          void* stream) {
   LAUNCHCHK(proj_check(B, C, hidden, Cout, PW));
+  LAUNCHCHK(proj_act_check(hidden, hidden_act));
   if (!x || !w1 || !b1 || !w2 || !b2 || !y) return fail(FNO_EINVAL, "fno_projection_forward: null argument");
   ProjFwdArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -1522,13 +1529,20 @@ extern "C" int fno_projection_forward(int B, int C, int hidden, int Cout, size_t
   pa.tiles_per_plane = (int)(PW / 128); pa.ntiles = B * pa.tiles_per_plane;
   const int grid = std::min(pa.ntiles, FNO_GRID_PF * dev_ncu());
   hipStream_t st = (hipStream_t)stream;
-  if (C == 32) return hidden == 128 ? proj_fwd_launch<32, 128>(st, grid, pa) : proj_fwd_launch<32, 256>(st, grid, pa);
-  return hidden == 128 ? proj_fwd_launch<64, 128>(st, grid, pa) : proj_fwd_launch<64, 256>(st, grid, pa);
+  if (hidden_act == FNO_ACT_RELU) return C == 32 ? proj_fwd_launch<32, 256, true>(st, grid, pa) : proj_fwd_launch<64, 256, true>(st, grid, pa);
+  if (C == 32) return hidden == 128 ? proj_fwd_launch<32, 128, false>(st, grid, pa) : proj_fwd_launch<32, 256, false>(st, grid, pa);
+  return hidden == 128 ? proj_fwd_launch<64, 128, false>(st, grid, pa) : proj_fwd_launch<64, 256, false>(st, grid, pa);
 }
-extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
-                                       const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
-                                       float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int fno_projection_forward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                      const float* b1, const float* w2, const float* b2, float* y, void* stream) {
+  return fno_projection_forward_act(B, C, hidden, Cout, PW, x, w1, b1, w2, b2, FNO_ACT_GELU, y, stream);
+}
+extern "C" int fno_projection_backward_act(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                           const float* b1, const float* w2, const float* dy, int hidden_act, float* dx,
+                                           float* dw1, float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes,
+                                           void* stream) {
   LAUNCHCHK(proj_check(B, C, hidden, Cout, PW));
+  LAUNCHCHK(proj_act_check(hidden, hidden_act));
   if (!x || !w1 || !b1 || !w2 || !dy || !dx || !dw1 || !db1 || !dw2 || !db2 || !ws)
     return fail(FNO_EINVAL, "fno_projection_backward: null argument");
   ProjWs w = carve_proj(C, hidden, ws, ws_bytes);
@@ -1543,8 +1557,9 @@ extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_
   pb.PW = (int)PW; pb.W = 128; pb.P = (int)(PW / 128); pb.CO = 1;
   pb.tiles_per_plane = (int)(PW / 128); pb.ntiles = B * pb.tiles_per_plane;
   const int grid = std::min(pb.ntiles, FNO_GRID_BWD * dev_ncu());
-  if (C == 32) LAUNCHCHK((hidden == 128 ? proj_bwd_launch<32, 128>(st, grid, pb) : proj_bwd_launch<32, 256>(st, grid, pb)));
-  else LAUNCHCHK((hidden == 128 ? proj_bwd_launch<64, 128>(st, grid, pb) : proj_bwd_launch<64, 256>(st, grid, pb)));
+  if (hidden_act == FNO_ACT_RELU) LAUNCHCHK((C == 32 ? proj_bwd_launch<32, 256, true>(st, grid, pb) : proj_bwd_launch<64, 256, true>(st, grid, pb)));
+  else if (C == 32) LAUNCHCHK((hidden == 128 ? proj_bwd_launch<32, 128, false>(st, grid, pb) : proj_bwd_launch<32, 256, false>(st, grid, pb)));
+  else LAUNCHCHK((hidden == 128 ? proj_bwd_launch<64, 128, false>(st, grid, pb) : proj_bwd_launch<64, 256, false>(st, grid, pb)));
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, 1), dim3(256), 0, st, dy, w.db2_part, B, 1, (int)PW));
   JobList jobs;
   jobs.add(w.dw1_part, dw1, grid, hidden, C, C, C);
@@ -1552,6 +1567,12 @@ extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_
   jobs.add(w.dw2_part, dw2, grid * 4, 1, hidden, hidden, hidden);
   jobs.add(w.db2_part, db2, 64, 1, 1, 1, 1);
   return jobs.run(st);
+}
+extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,
+                                       const float* b1, const float* w2, const float* dy, float* dx, float* dw1,
+                                       float* db1, float* dw2, float* db2, void* ws, size_t ws_bytes, void* stream) {
+  return fno_projection_backward_act(B, C, hidden, Cout, PW, x, w1, b1, w2, dy, FNO_ACT_GELU, dx, dw1, db1, dw2, db2, ws,
+                                     ws_bytes, stream);
 }
 
 // ===========================================================================

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
 //   --- barrier ---
 //   B   dW1[chunk] += dP1 . a^T by the wave group that owns the chunk   (48 bf16 MFMAs)
 //   --- barrier --- (dr is single-buffered)
-template <int C, int HID, int NPX, int NCO>
+template <int C, int HID, int NPX, int NCO, bool RELU = false>
 __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs a) {
   using Cfg = ProjBwdCfg<C, HID, NPX>;
   constexpr int NTN = Cfg::NTN, NW = Cfg::NW, MT = Cfg::MT, NCH = Cfg::NCH, TILES = Cfg::TILES, G = Cfg::G,
@@ -534,7 +534,13 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
 #pragma unroll
           for (int co = 0; co < NCO; ++co) t = fmaf(w2p[co * HID + ro], dyl[co], t);
           float gl, dg;
-          gelu_both(acc[r] + b1p[ro], gl, dg);
+          if constexpr (RELU) {          // hidden ReLU (rno.py:136-137 regressor head): relu'(0) = 0 as torch
+            const float p1 = acc[r] + b1p[ro];
+            gl = fmaxf(p1, 0.f);
+            dg = p1 > 0.f ? 1.f : 0.f;
+          } else {
+            gelu_both(acc[r] + b1p[ro], gl, dg);
+          }
           const float dp = dg * t;
           unsigned short ph, pm, pl;
           split3(dp, ph, pm, pl);
@@ -678,7 +684,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
 //   w1b[((mt*KB + kb)*3 + t)*64 + lane][8] = term t of W1[mt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j]
 // The activation tile is pixel-major bf16x3 (SplitTilePrefetch); each wave keeps its 32 pixels'
 // B fragments (KB x 3 x 4 VGPRs) in registers for all hidden chunks.
-template <int C, int HID, int NPX, int NCO>
+template <int C, int HID, int NPX, int NCO, bool RELU = false>
 __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
   constexpr int NTN = NPX / 32;
   constexpr int NW = 2 * NTN;
@@ -755,7 +761,7 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ro = (r & 3) + 8 * (r >> 2);
-        const float gl = gelu_f(acc[r] + b1p[ro]);
+        const float gl = RELU ? fmaxf(acc[r] + b1p[ro], 0.f) : gelu_f(acc[r] + b1p[ro]);
 #pragma unroll
         for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
       }

@@ -835,13 +835,17 @@ def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=F
 # ----------------------------------------------------------------------------
 # projection head  y = W2 gelu(W1 x + b1) + b2  on (B, C, ...) tensors
 # ----------------------------------------------------------------------------
-def projection_supported(x, hidden, cout):
-    return pointwise_supported(x) and hidden in (128, 256) and cout == 1 and _lib.lib().fno_get_gemm_mode() == 1
+def projection_supported(x, hidden, cout, act="gelu"):
+    return (pointwise_supported(x) and hidden in ((128, 256) if act == "gelu" else (256,)) and cout == 1
+            and act in _ACT_CODES and _lib.lib().fno_get_gemm_mode() == 1)
+
+
+_ACT_CODES = {"gelu": 0, "relu": 1}      # FNO_ACT_* (include/fnoengine.h)
 
 
 class _ProjectionHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, act=0):
         _require_cuda(x, "x")
         x = x.contiguous()
         B, Cc = x.shape[0], x.shape[1]
@@ -851,16 +855,16 @@ class _ProjectionHeadFn(torch.autograd.Function):
         w2c, b2c = w2.reshape(1, hid).contiguous(), b2.contiguous()
         y = torch.empty((B, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().fno_projection_forward(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(b2c),
-                                                         _ptr(y), _stream()), "projection_forward")
+            _lib.check(_lib.lib().fno_projection_forward_act(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c),
+                                                             _ptr(b2c), act, _ptr(y), _stream()), "projection_forward")
         ctx.save_for_backward(x, w1c, b1c, w2c)
-        ctx.meta = (B, Cc, hid, pw, w1.shape, w2.shape)
+        ctx.meta = (B, Cc, hid, pw, w1.shape, w2.shape, act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1c, b1c, w2c = ctx.saved_tensors
-        B, Cc, hid, pw, w1shape, w2shape = ctx.meta
+        B, Cc, hid, pw, w1shape, w2shape, act = ctx.meta
         L = _lib.lib()
         dy = dy.contiguous()
         dx = torch.empty_like(x)
@@ -869,15 +873,16 @@ class _ProjectionHeadFn(torch.autograd.Function):
         nws = L.fno_projection_workspace_bytes(Cc, hid)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.fno_projection_backward(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(dy), _ptr(dx),
-                                                 _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nws, _stream()),
-                       "projection_backward")
-        return dx, dw1.view(w1shape), db1, dw2.view(w2shape), db2
+            _lib.check(L.fno_projection_backward_act(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(dy), act,
+                                                     _ptr(dx), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nws,
+                                                     _stream()), "projection_backward")
+        return dx, dw1.view(w1shape), db1, dw2.view(w2shape), db2, None
 
 
-def projection_head(x, w1, b1, w2, b2):
-    """(B, C, ...) -> (B, 1, ...): fc2(gelu(fc1(x))) with fc1.weight (hidden, C), fc2.weight (1, hidden)."""
-    return _ProjectionHeadFn.apply(x, w1, b1, w2, b2)
+def projection_head(x, w1, b1, w2, b2, act="gelu"):
+    """(B, C, ...) -> (B, 1, ...): fc2(act(fc1(x))) with fc1.weight (hidden, C), fc2.weight (1, hidden); act 'gelu'
+    (FNO projection, PINO observer tails) or 'relu' (RNO2d's regressor head, rno.py:171-175; hidden 256)."""
+    return _ProjectionHeadFn.apply(x, w1, b1, w2, b2, _ACT_CODES[act])
 
 
 # ----------------------------------------------------------------------------

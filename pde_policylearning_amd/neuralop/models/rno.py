@@ -3,7 +3,9 @@ SpectralConv2d (:34-77), SpectralConvWithFC (:80-106), SpectralRegressor (:109-2
 FourierLayer2d (:215-228), RNO_cell (:231-260), RNO_layer (:263-290), RNO2d (:293-392).
 
 Every spectral convolution runs in the HIP engine (functional.spectral_conv, norm 'ortho',
-full modes1 x modes2 per corner); the pointwise glue (Linear / Conv1d(k=1) / gates) is torch.
+full modes1 x modes2 per corner); Fourier layers, cell gates, the input projection and the spectral
+regressor (channel mixes + ReLU head) run on the engine's fused / pointwise kernels whenever the shape
+allows (32 / 64 channels), torch ops otherwise.
 Parameter names and shapes match the reference state_dict."""
 import numpy as np
 import torch
@@ -47,9 +49,20 @@ class SpectralConvWithFC(nn.Module):
         self.return_freq = False
 
     def forward(self, x):
+        a = x.permute(0, 3, 1, 2)
+        if F.pointwise_supported(a) and self.in_channels == self.out_channels:
+            return self.forward_channels_first(a).permute(0, 2, 3, 1)
         res = self.linear(x)
         y = self.spec_conv(self.dropout(x).permute(0, 3, 1, 2).contiguous())
         return self.activation(y.permute(0, 2, 3, 1) + res)
+
+    def forward_channels_first(self, a):
+        """The same layer on a (B, C, X, Y) tensor, no layout changes: the Linear is a 1x1 channel mix, so
+        `linear(a) + bias + spec_conv(dropout(a))` is ONE fno_pointwise_* launch with the spectral branch as its
+        addend (the dropout mask is drawn on the channels-first tensor: same distribution, different element order
+        than the reference's channels-last draw)."""
+        s = self.spec_conv(self.dropout(a))
+        return self.activation(F.pointwise_conv_add(a, self.linear.weight, self.linear.bias, addend=s))
 
 
 class SpectralRegressor(nn.Module):
@@ -76,6 +89,18 @@ class SpectralRegressor(nn.Module):
                                        nn.Linear(self.dim_feedforward, out_dim))
 
     def forward(self, x, edge=None, pos=None, grid=None):
+        a = x.permute(0, 3, 1, 2)            # RNO2d hands over a permuted channels-first tensor: this is a view of it
+        fc1, fc2 = self.regressor[0], self.regressor[2]
+        if (x.dim() == 4 and F.pointwise_supported(a)
+                and all(l.in_channels == l.out_channels for l in self.spectral_conv)
+                and isinstance(self.activation, nn.ReLU)
+                and F.projection_supported(a, fc1.out_features, fc2.out_features, "relu")):
+            # whole regressor channels-first on the engine: two pointwise launches + the fused ReLU head
+            # (hidden (B, X, Y, 256) tensor never materialised; backward recomputes it)
+            for layer in self.spectral_conv:
+                a = layer.forward_channels_first(a)
+            y = F.projection_head(a, fc1.weight, fc1.bias, fc2.weight, fc2.bias, act="relu")
+            return y.permute(0, 2, 3, 1)
         for layer in self.spectral_conv:
             x = layer(x)
         return self.regressor(x)
@@ -178,7 +203,14 @@ class RNO2d(nn.Module):
     def forward_one_step(self, x, v_plane=None, init_hidden_states=None):
         if init_hidden_states is None:
             init_hidden_states = [None] * self.layer_num
-        x = self._pad(self.input_projection_layer(x).permute(0, 1, 4, 2, 3))     # (B, T, C, X, Y)
+        b, t, n1, n2, _ = x.shape
+        lin = self.input_projection_layer
+        xc = x.reshape(b * t, 1, n1, n2)     # in_dim = 1: channels-last == channels-first
+        if not x.requires_grad and F.lifting_supported(xc, self.width):
+            x = F.lifting(xc, lin.weight, lin.bias).view(b, t, self.width, n1, n2)       # engine 1 -> C channel mix
+        else:
+            x = lin(x).permute(0, 1, 4, 2, 3)
+        x = self._pad(x)                     # (B, T, C, X, Y)
         finals = []
         for i, layer in enumerate(self.layers):
             out = layer(x, init_hidden_states[i])

@@ -52,7 +52,22 @@ def build_parser():
     ap.add_argument("--learning-rate", type=float, default=1e-3)
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)                  # run_pde_observers.py:25
+    ap.add_argument("--save-path", default=None, help="whole-module checkpoint written whenever the test rel-L2 improves "
+                    "(run_pde_observers.py:307-315: torch.save(observer_model, './outputs/<path>_<exp>.pth'))")
     return ap
+
+
+def save_if_best(model, test_l2, best, path, rank, log):
+    """run_pde_observers.py:307-315: keep the best-so-far model as a whole pickled module (the format run_control.py
+    reads back with torch.load).  Rank 0 writes; every rank tracks the same `best` (test_l2 is evaluated on identical
+    replicas and the full test set by every rank)."""
+    if test_l2 >= best:
+        return best
+    if path and rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(model, path)
+        log(f"Best model saved at {path}!")
+    return test_l2
 
 
 def run(args, log=print):
@@ -90,7 +105,7 @@ def run(args, log=print):
     opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)
     decoder = MeanStdDecoder(train_ds.v_norm.mean.numpy(), train_ds.v_norm.std.numpy(), eps=train_ds.v_norm.eps, device=dev)
     loss_fn = FusedLpLoss(size_average=False, decoder=decoder)   # myloss = LpLoss(size_average=False), :138
-    history = []
+    history, best = [], float("inf")            # best_loss = 1e10 in the reference (:64)
     for ep in range(args.epochs):
         model.train()
         t0 = time.perf_counter()
@@ -115,6 +130,7 @@ def run(args, log=print):
         rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
                    seconds=time.perf_counter() - t0)
         history.append(rec)
+        best = save_if_best(model, rec["test_l2"], best, getattr(args, "save_path", None), rank, log)
         if rank == 0:
             log(f"epoch {ep}: train rel-L2 {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
     return history
@@ -149,7 +165,7 @@ def run_full_field(args, idx, dev, rank, world, log):
     decoder = MeanStdDecoder(norm.mean.numpy(), norm.std.numpy(), eps=norm.eps, device=dev)
     objective = FullFieldObjective(decoder, args.plane_indexs, env, args.pde_loss_weight)
     forward = lambda plane, re: model(plane.permute(0, 2, 3, 1).unsqueeze(-1), re)     # 'btxy -> bxyt', + channel  (:204)
-    history = []
+    history, best = [], float("inf")
     for ep in range(args.epochs):
         model.train()
         t0 = time.perf_counter()
@@ -174,6 +190,7 @@ def run_full_field(args, idx, dev, rank, world, log):
         rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
                    seconds=time.perf_counter() - t0)
         history.append(rec)
+        best = save_if_best(model, rec["test_l2"], best, getattr(args, "save_path", None), rank, log)
         if rank == 0:
             log(f"epoch {ep}: train loss {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
     return history

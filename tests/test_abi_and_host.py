@@ -72,6 +72,33 @@ def test_fno2d_surface_matches_reference():
     assert torch.equal(m2.lifting.fc.weight, m.lifting.fc.weight)
 
 
+def test_whole_module_checkpoint_round_trip(tmp_path):
+    """run_pde_observers.py:313-314 saves the best observer with torch.save(model) and run_control.py loads it back with
+    torch.load: every observer class of the path must survive that (state, class identity, engine hooks), and
+    train_observer.save_if_best must write only on improvement."""
+    from pde_policylearning_amd.libs.models.fno_models import FNO2dObserver
+    from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    from pde_policylearning_amd.train_observer import save_if_best
+    models = [FNO2dObserver(8, 8, 32), RNO2dObserver(4, 4, 32, 0, layer_num=1),
+              PINObserver2d(modes1=[4] * 4, modes2=[4] * 4, modes3=[4] * 4, fc_dim=16, layers=[8] * 5, in_dim=4, out_dim=1,
+                            act="gelu", pad_ratio=0.0625),
+              PINObserverFullField(plane_num=3, modes1=[4] * 4, modes2=[4] * 4, modes3=[4] * 4, fc_dim=16, layers=[8] * 5,
+                                   in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625])]
+    logs = []
+    for i, m in enumerate(models):
+        path = str(tmp_path / "outputs" / f"m{i}.pth")
+        assert save_if_best(m, 0.5, 1e10, path, 0, logs.append) == 0.5
+        m2 = torch.load(path, weights_only=False)
+        assert type(m2) is type(m)
+        sd, sd2 = m.state_dict(), m2.state_dict()
+        assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
+        os.remove(path)
+        assert save_if_best(m, 0.7, 0.5, path, 0, logs.append) == 0.5 and not os.path.exists(path)      # no improvement
+        assert save_if_best(m, 0.3, 0.5, path, 1, logs.append) == 0.3 and not os.path.exists(path)      # rank != 0 tracks only
+    assert len(logs) == len(models)
+
+
 def test_unsupported_configurations_fail_loudly():
     from pde_policylearning_amd.neuralop.models import FNO, SpectralConv
     with pytest.raises(NotImplementedError):

@@ -528,6 +528,66 @@ def test_rno2d_named_config_uses_fused_layers_and_matches_unfused(dev):
         assert rel_l2(_cpu(a), _cpu(p.grad)) < 5e-4
 
 
+def test_rno2d_width64_engine_regressor_vs_oracle(dev):
+    """RNO2d at the width BASELINE config 3 names (64): input projection through fno_lifting_*, Fourier layers and gates fused,
+    the spectral regressor channels-first through fno_pointwise_* and the ReLU head through fno_projection_*_act - against the
+    CPU oracle (pinned by the reference-generated rno2d goldens at widths 8 / 34), output and every parameter gradient.
+    Two time steps: the second one's input is the first prediction (requires grad -> torch input projection)."""
+    from oracle import observers_oracle as OO
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    torch.manual_seed(11)
+    model = RNO2dObserver(6, 6, 64, 1, layer_num=1).eval()
+    x = torch.from_numpy(fill_named("rno64.x", (2, 2, 32, 32, 1), 1.0))
+    tgt = torch.from_numpy(fill_named("rno64.t", (2, 32, 32, 1), 1.0))
+    pc = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    yc = OO.rno2d_forward(pc, x, 6, 6, 64, 1, 1)
+    O.lp_loss_rel_sum(yc, tgt).backward()
+    model = model.to(dev)
+    calls = {"proj": 0, "pw": 0, "lift": 0}
+    orig = (F.projection_head, F.pointwise_conv_add, F.lifting)
+    def spy(name, fn):
+        def w(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return w
+    F.projection_head, F.pointwise_conv_add, F.lifting = spy("proj", orig[0]), spy("pw", orig[1]), spy("lift", orig[2])
+    try:
+        y = model(x.to(dev))
+    finally:
+        F.projection_head, F.pointwise_conv_add, F.lifting = orig
+    assert calls == {"proj": 2, "pw": 4, "lift": 1}, calls
+    assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    for name, prm in model.named_parameters():
+        assert rel_l2(_cpu(prm.grad), pc[name].grad.numpy()) < TOL_G, name
+
+
+def test_rno2d_regressor_train_mode_dropout(dev):
+    """train mode: the regressor's dropout (p = 0.3, rno.py:319-320) acts on the spectral branch only (rno.py:96-99); with the
+    mask drawn channels-first the layer must equal the torch composition under the SAME mask (same generator state)."""
+    from pde_policylearning_amd.neuralop.models.rno import SpectralConvWithFC
+    torch.manual_seed(3)
+    layer = SpectralConvWithFC(64, 64, 6, 6, dropout=0.3, activation='relu').to(dev).train()
+    a = torch.randn(2, 64, 32, 32, device=dev, requires_grad=True)
+    torch.manual_seed(5)
+    y1 = layer.forward_channels_first(a)
+    y1.square().sum().backward()
+    g1 = [a.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    a.grad = None
+    layer.zero_grad()
+    torch.manual_seed(5)
+    s = layer.spec_conv(layer.dropout(a))
+    y2 = torch.relu(s + torch.nn.functional.conv2d(a, layer.linear.weight.view(64, 64, 1, 1), layer.linear.bias))
+    y2.square().sum().backward()
+    assert rel_l2(_cpu(y1), _cpu(y2)) < TOL_COMP
+    for u, v in zip(g1, [a.grad] + [p.grad for p in layer.parameters()]):
+        assert rel_l2(_cpu(u), _cpu(v)) < 2e-5
+    assert float((y1 == 0).float().mean()) > 0.05          # ReLU active; and the mask really dropped inputs:
+    layer.eval()
+    assert rel_l2(_cpu(layer.forward_channels_first(a)), _cpu(y1)) > 5e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # PINO residual loss (SURVEY.md 8f rank 1) vs vectors generated by the reference's own code
 # ---------------------------------------------------------------------------------------------
@@ -710,9 +770,11 @@ def test_pointwise_conv_add_vs_torch(dev, C, shape):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_COMP, tuple(a.shape)
 
 
-@pytest.mark.parametrize("C,hid,shape", [(64, 128, (2, 64, 8, 16, 65)), (32, 256, (1, 32, 16, 24))])
-def test_projection_head_vs_torch(dev, C, hid, shape):
-    """fno_projection_* (fc1 -> gelu -> fc2, pinobserver.py:231-233) vs the torch ops in fp64-free fp32 on CPU."""
+@pytest.mark.parametrize("C,hid,shape,act", [(64, 128, (2, 64, 8, 16, 65), "gelu"), (32, 256, (1, 32, 16, 24), "gelu"),
+                                             (64, 256, (2, 64, 32, 32), "relu"), (32, 256, (1, 32, 16, 24), "relu")])
+def test_projection_head_vs_torch(dev, C, hid, shape, act):
+    """fno_projection_*_act (fc1 -> gelu -> fc2, pinobserver.py:231-233; fc1 -> relu -> fc2, the RNO2d regressor head
+    rno.py:171-175) vs the torch ops in fp32 on CPU."""
     from pde_policylearning_amd import functional as F
     x = torch.from_numpy(fill_named("phx", shape, 1.0))
     w1 = torch.from_numpy(fill_named("phw1", (hid, C), 0.15))
@@ -722,10 +784,11 @@ def test_projection_head_vs_torch(dev, C, hid, shape):
     dy = torch.from_numpy(fill_named("phd", (shape[0], 1) + shape[2:], 1.0))
     ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
     xr = ref[0].movedim(1, -1)                                                   # channels-last as the reference applies it
-    yr = (torch.nn.functional.gelu(xr @ ref[1].t() + ref[2]) @ ref[3].t() + ref[4]).movedim(-1, 1)
+    actf = torch.nn.functional.gelu if act == "gelu" else torch.relu
+    yr = (actf(xr @ ref[1].t() + ref[2]) @ ref[3].t() + ref[4]).movedim(-1, 1)
     yr.backward(dy)
     eng = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-    ye = F.projection_head(*eng)
+    ye = F.projection_head(*eng, act=act)
     assert rel_l2(_cpu(ye), yr.detach().numpy()) < TOL_Y
     ye.backward(dy.to(dev))
     for a, b in zip(eng, ref):
