@@ -41,6 +41,9 @@ CONFIGS = {
     "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
     # the fine-tuning step of that YAML as train_pino.py runs it: batch 4, loss = 5 * IC + 1 * PDE residual (xy_loss 0)
     "pino_finetune_128x128x65_w64_m8_b4": dict(kind="pino2d_train", batch=4, size=(128, 128, 65)),
+    # BASELINE config 5 AS NAMED (256 x 256, width 64, modes 20, PDE-residual loss): one sample per GPU; the residual loss runs
+    # through the row / column / row slab kernels (k_pino_loss2.h), the spectral weights are 4 layers x 4 corners x 262 MB
+    "pino_finetune_256x256x65_w64_m20_b1": dict(kind="pino2d_train", batch=1, size=(256, 256, 65), modes=20),
 }
 
 
@@ -135,7 +138,8 @@ def main():
         if cfg["kind"] == "pino2d_train":   # train_pino.py:79-106; a = (x, y, t, u0) grid as libs/pino_utils/datasets.py:612-617 builds it
             from pde_policylearning_amd.libs.pino_utils.utils import get_grid3d
             S, T = cfg["size"][0], cfg["size"][2]
-            model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+            m = cfg.get("modes", 8)
+            model = PINObserver2d(modes1=[m] * 4, modes2=[m] * 4, modes3=[m] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
                                   out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)
             u0 = torch.randn((B, S, S, 1, 1), generator=gen)
             grid = torch.cat([g[0] for g in get_grid3d(S, T)], dim=-1)

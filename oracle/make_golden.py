@@ -367,7 +367,7 @@ def gen_pino_loss(outdir):
     spec = importlib.util.spec_from_file_location("ref_pino_losses", os.path.join(sys.path[0], "libs", "pino_utils", "losses.py"))
     L = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(L)
-    for tag, (B, n, nt) in {"n32": (2, 32, 6), "n64": (2, 64, 5), "n128": (1, 128, 4)}.items():
+    for tag, (B, n, nt) in {"n32": (2, 32, 6), "n64": (2, 64, 5), "n128": (1, 128, 4), "n256": (1, 256, 3)}.items():
         u = input_fill("pinoloss.u." + tag, (B, n, n, nt)).requires_grad_(True)
         u0 = input_fill("pinoloss.u0." + tag, (B, n, n))
         re = torch.from_numpy(np.array([180.0, 395.0][:B], dtype=np.float32))

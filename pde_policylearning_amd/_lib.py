@@ -93,6 +93,8 @@ def lib():
     L.fno_pointwise_workspace_bytes.restype = sz
     L.fno_pointwise_forward.argtypes = [ci, ci, sz, vp, vp, vp, vp, ci, vp, vp]
     L.fno_pointwise_backward.argtypes = [ci, ci, sz, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, vp]
+    L.fno_debug_pino_twopass.argtypes = [ci]
+    L.fno_debug_pino_twopass.restype = None
     L.fno_projection_workspace_bytes.argtypes = [ci, ci]
     L.fno_projection_workspace_bytes.restype = sz
     L.fno_projection_forward.argtypes = [ci, ci, ci, ci, sz] + [vp] * 7

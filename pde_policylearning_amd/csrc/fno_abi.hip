@@ -19,6 +19,7 @@
 #include "k_projection.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
+#include "k_pino_loss2.h"
 #include "k_rno_gates.h"
 #include "k_train.h"
 
@@ -281,11 +282,13 @@ static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
 template <int NS>
 static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2* out, const float2* tw, int outer,
                        int n_in, int n_out, int inner) {
+  constexpr int SEGS = NS > 24 ? 4 : 8;      // partial sums [SEGS][NS][64] complex: 80 KB at NS = 40
   if (truncating)
-    return launch("k_axis_fwd", k_axis_fwd<NS>, dim3((inner + 63) / 64, outer), dim3(64, 8), (size_t)8 * NS * 64 * 8,
-                  st, in, out, tw, n_in, inner);
-  return launch("k_axis_inv", k_axis_inv<NS>, dim3((inner + 63) / 64, outer), dim3(64, 16), 0, st, in, out, tw, n_out,
-                inner);
+    return launch("k_axis_fwd", k_axis_fwd<NS, SEGS>, dim3((inner + 63) / 64, outer), dim3(64, SEGS),
+                  (size_t)SEGS * NS * 64 * 8, st, in, out, tw, n_in, inner);
+  constexpr int ISEGS = NS > 24 ? 8 : 16;
+  return launch("k_axis_inv", k_axis_inv<NS, ISEGS>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), 0, st, in, out, tw,
+                n_out, inner);
 }
 static int axis_pass(hipStream_t st, bool truncating, const float* in_, float* out_, const float2* tw, int outer,
                      int n_in, int n_out, int inner) {
@@ -302,6 +305,8 @@ static int axis_pass(hipStream_t st, bool truncating, const float* in_, float* o
     case 16: return axis_pass_t<16>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
     case 20: return axis_pass_t<20>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
     case 24: return axis_pass_t<24>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 32: return axis_pass_t<32>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
+    case 40: return axis_pass_t<40>(st, truncating, in, out, tw, outer, n_in, n_out, inner);   // modes 20: BASELINE config 5
     default: break;
   }
   if (n_out > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d)", n_out);
@@ -1177,25 +1182,36 @@ extern "C" int fno_adam_step_dev(size_t n, float* param, const float* grad, floa
 // PINO residual loss (spectral Navier-Stokes vorticity residual + initial-condition term)
 // ===========================================================================
 static const int kIcSplit = 16;
-struct PinoWs { float *fields, *dws, *part_f, *part_ic, *coef_f, *coef_ic; size_t total; bool ok; };
+static const int kPinoChunk = 64;        // planes per pass of the slab kernels (bounds S1 / S2)
+static int g_pino_twopass = 0;           // debug: route 128 x 128 planes through the slab kernels too (self-check vs the in-LDS path)
+extern "C" void fno_debug_pino_twopass(int on) { g_pino_twopass = on ? 1 : 0; }
+static bool pino_slabs(int n) { return n == 256 || (n == 128 && g_pino_twopass); }
+struct PinoWs { float *fields, *dws, *part_f, *part_ic, *coef_f, *coef_ic; float2 *s1, *s2; int pp, chunk; size_t total; bool ok; };
 static PinoWs carve_pino(int B, int n, int T, void* ws, size_t ws_bytes) {
   Carver c(ws, ws_bytes);
   const size_t np = (size_t)B * (T - 2) * n * n;
   PinoWs w;
+  w.pp = pino_slabs(n) ? n / PINO2_RB : 1;
+  w.chunk = std::min(B * (T - 2), kPinoChunk);
   w.fields = c.take<float>(5 * np);
   w.dws = c.take<float>(np);
-  w.part_f = c.take<float>((size_t)B * (T - 2));
+  w.part_f = c.take<float>((size_t)B * (T - 2) * w.pp);
   w.part_ic = c.take<float>((size_t)B * kIcSplit * 2);
   w.coef_f = c.take<float>(B);
   w.coef_ic = c.take<float>(B);
+  w.s1 = w.s2 = nullptr;
+  if (pino_slabs(n)) {
+    w.s1 = c.take<float2>((size_t)w.chunk * n * n);
+    w.s2 = c.take<float2>((size_t)5 * w.chunk * n * n);
+  }
   w.total = c.off;
   w.ok = c.ok;
   return w;
 }
 static int pino_check(int B, int n, int T) {
   if (B < 1 || T < 3) return fail(FNO_EINVAL, "pino loss: batch %d, %d time levels (need >= 3)", B, T);
-  if (n != 32 && n != 64 && n != 128)
-    return fail(FNO_EUNSUPPORTED, "pino loss: square grids of 32, 64 or 128 points per side (got %d)", n);
+  if (n != 32 && n != 64 && n != 128 && n != 256)
+    return fail(FNO_EUNSUPPORTED, "pino loss: square grids of 32, 64, 128 or 256 points per side (got %d)", n);
   return FNO_OK;
 }
 extern "C" size_t fno_pino_loss_workspace_bytes(int batch, int n, int nt) {
@@ -1208,9 +1224,33 @@ static int pino_launch_planes(bool backward, int planes, hipStream_t st, const P
   if (backward) return launch("k_pino_plane_bwd", k_pino_plane_bwd<N>, dim3(planes), dim3(PinoCfg<N>::NT), lds, st, a);
   return launch("k_pino_plane_fwd", k_pino_plane_fwd<N>, dim3(planes), dim3(PinoCfg<N>::NT), lds, st, a);
 }
-static int pino_planes(bool backward, int n, int planes, hipStream_t st, const PinoArgs& a) {
+// planes too large for one CU's LDS: row / column / row slab passes through HBM (k_pino_loss2.h), `chunk` planes at a time
+template <int N>
+static int pino_launch_slabs(bool backward, int planes, hipStream_t st, const PinoArgs& a, const PinoWs& w) {
+  const size_t lds_r = ((size_t)PINO2_RB * (N + 1) + N / 2) * 8 + 64;
+  const size_t lds_c = ((size_t)N * (PINO2_RB + 1) + N / 2) * 8;
+  for (int p0 = 0; p0 < planes; p0 += w.chunk) {
+    const int pc = std::min(w.chunk, planes - p0);
+    Pino2Args b;
+    b.p = a; b.s1 = w.s1; b.s2 = w.s2; b.plane0 = p0;
+    const dim3 grid(N / PINO2_RB, pc), blk(PINO2_NT);
+    if (!backward) {
+      LAUNCHCHK(launch("k_pino2_rows_fwd", k_pino2_rows_fwd<N>, grid, blk, lds_r, st, b));
+      LAUNCHCHK(launch("k_pino2_cols_fwd", k_pino2_cols_fwd<N>, grid, blk, lds_c, st, b));
+      LAUNCHCHK(launch("k_pino2_rows_inv", k_pino2_rows_inv<N>, grid, blk, lds_r, st, b));
+    } else {
+      LAUNCHCHK(launch("k_pino2_rows_bwd", k_pino2_rows_bwd<N>, grid, blk, lds_r, st, b));
+      LAUNCHCHK(launch("k_pino2_cols_bwd", k_pino2_cols_bwd<N>, grid, blk, lds_c, st, b));
+      LAUNCHCHK(launch("k_pino2_rows_out", k_pino2_rows_out<N>, grid, blk, lds_r, st, b));
+    }
+  }
+  return FNO_OK;
+}
+static int pino_planes(bool backward, int n, int planes, hipStream_t st, const PinoArgs& a, const PinoWs& w) {
   if (n == 32) return pino_launch_planes<32>(backward, planes, st, a);
   if (n == 64) return pino_launch_planes<64>(backward, planes, st, a);
+  if (n == 256) return pino_launch_slabs<256>(backward, planes, st, a, w);
+  if (pino_slabs(n)) return pino_launch_slabs<128>(backward, planes, st, a, w);
   return pino_launch_planes<128>(backward, planes, st, a);
 }
 extern "C" int fno_pino_loss_forward(int B, int n, int T, const float* u, const float* u0, const float* forcing,
@@ -1225,10 +1265,10 @@ extern "C" int fno_pino_loss_forward(int B, int n, int T, const float* u, const 
   memset(&a, 0, sizeof(a));
   a.u = u; a.forcing = forcing; a.visc = visc; a.fields = w.fields; a.partial = w.part_f;
   a.B = B; a.T = T; a.inv2dt = (float)((double)(T - 1) / (2.0 * (double)t_interval));
-  LAUNCHCHK(pino_planes(false, n, B * (T - 2), st, a));
+  LAUNCHCHK(pino_planes(false, n, B * (T - 2), st, a, w));
   LAUNCHCHK(launch("k_pino_ic_partial", k_pino_ic_partial, dim3(kIcSplit, B), dim3(256), 0, st, u, u0, n * n, T, w.part_ic));
   LAUNCHCHK(launch("k_pino_finish", k_pino_finish, dim3(1), dim3(256), 0, st, (const float*)w.part_f, (const float*)w.part_ic,
-                   forcing, B, T, n * n, kIcSplit, loss_ic, loss_f, w.coef_ic, w.coef_f));
+                   forcing, B, T, n * n, kIcSplit, w.pp, loss_ic, loss_f, w.coef_ic, w.coef_f));
   return FNO_OK;
 }
 extern "C" int fno_pino_loss_backward(int B, int n, int T, const float* u, const float* u0, const float* forcing,
@@ -1244,7 +1284,7 @@ extern "C" int fno_pino_loss_backward(int B, int n, int T, const float* u, const
   memset(&a, 0, sizeof(a));
   a.u = u; a.forcing = forcing; a.visc = visc; a.fields = w.fields; a.dws = w.dws; a.coef_f = w.coef_f; a.g_f = g_f;
   a.B = B; a.T = T; a.inv2dt = (float)((double)(T - 1) / (2.0 * (double)t_interval));
-  LAUNCHCHK(pino_planes(true, n, B * (T - 2), st, a));
+  LAUNCHCHK(pino_planes(true, n, B * (T - 2), st, a, w));
   const size_t npix = (size_t)B * n * n;
   LAUNCHCHK(launch("k_pino_assemble", k_pino_assemble, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, u, u0,
                    (const float*)w.dws, (const float*)(w.fields + 4 * np), (const float*)w.coef_f, (const float*)w.coef_ic,

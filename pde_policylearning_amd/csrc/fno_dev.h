@@ -18,6 +18,21 @@ FNO_DEV f32x16 mfma32(float a, float b, f32x16 c) {
 FNO_DEV f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// 8-wave workgroups place waves w and w + 4 on the same SIMD.  Both run the same phase sequence between the same
+// barriers, so without help they reach their MFMA bursts and their VALU bursts together and the two pipes take turns
+// instead of overlapping (phase trace: A1 + E + A3 of the projection backward = MFMA time + VALU time).  Raising the
+// issue priority of one partner lets it run ahead: its VALU phase then overlaps the other's matrix phase.
+// FNO_PRIO: 0 = off, 1 = waves [0, n/2) high, 2 = waves [n/2, n) high.
+#ifndef FNO_PRIO
+#define FNO_PRIO 0
+#endif
+#if FNO_PRIO == 1
+#define FNO_SIMD_PARTNER_PRIO(wave, nwaves) do { if ((nwaves) == 8 && (wave) < 4) __builtin_amdgcn_s_setprio(2); } while (0)
+#elif FNO_PRIO == 2
+#define FNO_SIMD_PARTNER_PRIO(wave, nwaves) do { if ((nwaves) == 8 && (wave) >= 4) __builtin_amdgcn_s_setprio(2); } while (0)
+#else
+#define FNO_SIMD_PARTNER_PRIO(wave, nwaves) do { } while (0)
+#endif
 #ifdef FNO_TRACE
 // Debug build only (-DFNO_TRACE): per-phase shader-clock stamps of workgroup 0, read back with
 // fno_debug_trace_dump (tools/trace_phases.py).  g_trace[wave][slot]

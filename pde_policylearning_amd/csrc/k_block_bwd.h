@@ -351,6 +351,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 
   int tslot = 0;
   FNO_TRACE_IF(false);
+  FNO_SIMD_PARTNER_PRIO(wave, (C / 32) * (NPX / 32));
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;

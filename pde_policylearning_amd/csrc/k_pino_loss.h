@@ -88,7 +88,7 @@ FNO_DEV float2 pino_mult(int f, int ix, int iy) {
 }
 template <int N>
 FNO_DEV int brev_n(int v) {
-  constexpr int LOG = N == 128 ? 7 : N == 64 ? 6 : 5;
+  constexpr int LOG = N == 256 ? 8 : N == 128 ? 7 : N == 64 ? 6 : 5;
   return (int)(__brev((unsigned)v) >> (32 - LOG));
 }
 
@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(256) k_pino_ic_partial(const float* __restrict
 //   loss_f = mean_b ||Du_b - f|| / ||f repeated over T-2||,  loss_ic = mean_b ||u_b(t=0) - u0_b|| / ||u0_b||
 __global__ void __launch_bounds__(256) k_pino_finish(const float* __restrict__ part_f, const float* __restrict__ part_ic,
                                                      const float* __restrict__ forcing, int B, int T, int nn, int S,
+                                                     int PP /* partial sums per plane in part_f */,
                                                      float* __restrict__ loss_ic, float* __restrict__ loss_f,
                                                      float* __restrict__ coef_ic, float* __restrict__ coef_f) {
   __shared__ float sh[256];
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) k_pino_finish(const float* __restrict__ p
     float lf = 0.f, lic = 0.f;
     for (int b = 0; b < B; ++b) {
       float sf = 0.f;
-      for (int k = 0; k < T - 2; ++k) sf += part_f[(size_t)b * (T - 2) + k];
+      for (int k = 0; k < (T - 2) * PP; ++k) sf += part_f[(size_t)b * (T - 2) * PP + k];
       float sd = 0.f, sy = 0.f;
       for (int k = 0; k < S; ++k) { sd += part_ic[((size_t)b * S + k) * 2]; sy += part_ic[((size_t)b * S + k) * 2 + 1]; }
       const float rn = sqrtf(sf), dn = sqrtf(sd), yn = sqrtf(sy);

@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
 
   int tslot = 0;
   FNO_TRACE_IF(true);
+  FNO_SIMD_PARTNER_PRIO(wave, NW);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;

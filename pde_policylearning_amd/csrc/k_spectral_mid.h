@@ -15,14 +15,15 @@
 // ---------------------------------------------------------------------------
 // Truncating pass (many -> few):  out[o][r][q] = sum_n twT[n][r] * in[o][n][q],  n_out = NR small.
 // Each thread keeps all NR complex outputs of one column q in registers; the n range is split over
-// 8 waves (each wave's loads are all in flight together) and combined through LDS.  twT rows are
+// SEGS waves (8; 4 for the widest kept extents, whose partial sums would not fit LDS otherwise; each wave's loads
+// are all in flight together) and combined through LDS.  twT rows are
 // wave-uniform and NR is a compile-time constant -> wide scalar loads, no per-element guards.
-//   block (64, 8), grid (ceil(inner/64), outer)
-template <int NR>
-__global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
-                                                  const float2* __restrict__ twT, int n_in, int inner) {
+//   block (64, SEGS), grid (ceil(inner/64), outer)
+template <int NR, int SEGS = 8>
+__global__ void __launch_bounds__(64 * SEGS) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
+                                                        const float2* __restrict__ twT, int n_in, int inner) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float2* sh = reinterpret_cast<float2*>(smem);     // [8][NR][64]
+  float2* sh = reinterpret_cast<float2*>(smem);     // [SEGS][NR][64]
   const int ql = threadIdx.x;
   const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int q = blockIdx.x * 64 + ql;
@@ -32,16 +33,16 @@ __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in,
   for (int r = 0; r < NR; ++r) acc[r] = make_float2(0.f, 0.f);
   if (q < inner) {
     const float2* src = in + (size_t)o * n_in * inner + q;
-    for (int nb = seg; nb < n_in; nb += 64) {
+    for (int nb = seg; nb < n_in; nb += 8 * SEGS) {
       float2 v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int n = nb + 8 * j;
+        const int n = nb + SEGS * j;
         v[j] = (n < n_in) ? src[(size_t)n * inner] : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int n = nb + 8 * j;
+        const int n = nb + SEGS * j;
         if (n < n_in) {
           const float2* t = twT + (size_t)n * NR;
 #pragma unroll
@@ -58,10 +59,10 @@ __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in,
   for (int r = 0; r < NR; ++r) sh[(seg * NR + r) * 64 + ql] = acc[r];
   __syncthreads();
   if (q < inner) {
-    for (int r = seg; r < NR; r += 8) {
+    for (int r = seg; r < NR; r += SEGS) {
       float sx = 0.f, sy = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { sx += sh[(k * NR + r) * 64 + ql].x; sy += sh[(k * NR + r) * 64 + ql].y; }
+      for (int k = 0; k < SEGS; ++k) { sx += sh[(k * NR + r) * 64 + ql].x; sy += sh[(k * NR + r) * 64 + ql].y; }
       out[((size_t)o * NR + r) * inner + q] = make_float2(sx, sy);
     }
   }
@@ -70,9 +71,9 @@ __global__ void __launch_bounds__(512) k_axis_fwd(const float2* __restrict__ in,
 // Expanding pass (few -> many):  out[o][r][q] = sum_k tw[r][k] * in[o][k][q],  n_in = NK small.
 // Each thread holds its column's NK inputs in registers and sweeps its share of r (16 waves per
 // block share the sweep); tw rows are wave-uniform, NK compile-time -> wide scalar loads.
-//   block (64, 16), grid (ceil(inner/64), outer)
-template <int NK>
-__global__ void __launch_bounds__(1024) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
+//   block (64, SEGS), grid (ceil(inner/64), outer); SEGS = 16, or 8 when NK > 24 (register budget of the NK inputs)
+template <int NK, int SEGS = 16>
+__global__ void __launch_bounds__(64 * SEGS) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
                                                    const float2* __restrict__ tw, int n_out, int inner) {
   const int ql = threadIdx.x;
   const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(1024) k_axis_inv(const float2* __restrict__ in
 #pragma unroll
   for (int k = 0; k < NK; ++k) v[k] = in[((size_t)o * NK + k) * inner + q];
 #pragma unroll 2
-  for (int r = seg; r < n_out; r += 16) {
+  for (int r = seg; r < n_out; r += SEGS) {
     const float2* t = tw + (size_t)r * NK;
     float sr = 0.f, si = 0.f;
 #pragma unroll

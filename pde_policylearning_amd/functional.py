@@ -498,7 +498,8 @@ class _PinoLossFn(torch.autograd.Function):
 def pino_loss(u, u0, forcing, visc, t_interval=1.0):
     """(loss_ic, loss_f) of Channelflow_PINO_loss / PINO_loss3d (libs/envs/diff_control_env.py:44-60):
     u (B, n, n, nt) model output, u0 (B, n, n), forcing (n, n) or (1, n, n, 1), visc (B,) = 1 / Re.
-    Differentiable w.r.t. u.  n in {32, 64, 128}."""
+    Differentiable w.r.t. u.  n in {32, 64, 128} (one workgroup per plane, in-LDS FFTs) or 256 (row / column / row
+    slab passes through HBM)."""
     return _PinoLossFn.apply(u, u0, forcing, visc, t_interval)
 
 

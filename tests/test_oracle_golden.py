@@ -209,7 +209,7 @@ def test_pinobserver2d():
     _check_model_grads(g, p, O.lp_loss_rel_sum(y, _t(g["target"])))
 
 
-@pytest.mark.parametrize("tag", ["n32", "n64", "n128"])
+@pytest.mark.parametrize("tag", ["n32", "n64", "n128", "n256"])
 def test_pino_residual_loss_golden(tag):
     """oracle/pino_loss_oracle.py vs vectors produced by the reference's own FDM_NS_vorticity / PINO_loss3d
     (libs/pino_utils/losses.py:68-104, 246-262 == libs/envs/diff_control_env.py:5-60)."""

@@ -424,6 +424,8 @@ def test_fno2d_observer_train_trajectory_fused_tail(dev):
     ("C", (2, 32, 64, 32), (5, 7)),            # rows of 32 floats: 4 rows per tile
     ("C", (1, 64, 16, 32, 64), (4, 6, 9)),     # 3-D, last dim 64
     ("A", (2, 64, 64, 128), (6, 6)),           # unfused FNO block convolution with bias
+    ("C", (1, 32, 48, 44, 41), (20, 20, 20)),  # BASELINE config 5 as named: modes 20 -> kept extent 40 on both leading axes
+    ("B", (2, 32, 64, 64), (16, 12)),          # kept extent 32 (k_axis_fwd<32, 4> / k_axis_inv<32, 8>)
 ])
 def test_specconv_tile_rows_vs_oracle(dev, dialect, shape, modes):
     from pde_policylearning_amd import functional as F
@@ -591,7 +593,7 @@ def test_rno2d_regressor_train_mode_dropout(dev):
 # ---------------------------------------------------------------------------------------------
 # PINO residual loss vs vectors generated by the reference's own code
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["n32", "n64", "n128"])
+@pytest.mark.parametrize("tag", ["n32", "n64", "n128", "n256"])
 def test_pino_residual_loss_golden(dev, tag):
     from pde_policylearning_amd import functional as F
     g = load_golden("pino_loss_" + tag)
@@ -624,6 +626,35 @@ def test_pino_residual_fields_vs_oracle(dev):
     assert abs(float(eic) - float(lic)) < 1e-5 * float(lic) and abs(float(ef) - float(lf)) < 1e-5 * float(lf)
     (eic + 2.0 * ef).backward()
     assert rel_l2(_cpu(ue.grad), uo.grad.numpy()) < 1e-5
+
+
+def test_pino_residual_slab_passes_equal_plane_kernels(dev):
+    """The row / column / row slab kernels that serve 256 x 256 planes (k_pino_loss2.h), forced onto 128 x 128 planes, must
+    reproduce the single-workgroup plane kernels: both losses and dL/du, with more planes (2 x 38 = 76) than one chunk
+    of the slab passes (64) and samples of different viscosity."""
+    from pde_policylearning_amd import _lib
+    from pde_policylearning_amd import functional as F
+    from oracle import pino_loss_oracle as P
+    B, n, nt = 2, 128, 40
+    u = torch.from_numpy(fill_named("pl2.u", (B, n, n, nt), 1.0)).to(dev)
+    u0 = torch.from_numpy(fill_named("pl2.u0", (B, n, n), 1.0)).to(dev)
+    visc = torch.tensor([1 / 180.0, 1 / 395.0], device=dev)
+    f = P.forcing(n).to(dev)
+    L = _lib.lib()
+    res = []
+    for mode in (0, 1):
+        L.fno_debug_pino_twopass(mode)
+        try:
+            ue = u.clone().requires_grad_(True)
+            lic, lf = F.pino_loss(ue, u0, f, visc, 0.5)
+            (5.0 * lic + lf).backward()
+            torch.cuda.synchronize()
+            res.append((float(lic), float(lf), _cpu(ue.grad)))
+        finally:
+            L.fno_debug_pino_twopass(0)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    assert abs(res[0][1] - res[1][1]) <= 2e-6 * abs(res[0][1])
+    assert rel_l2(res[1][2], res[0][2]) < 2e-6
 
 
 def test_pino_loss_reference_surface(dev):
