@@ -151,6 +151,21 @@ int fno_model_backward_part(const FnoModelPlan* plan, int batch, const FnoModelP
                             const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
                             size_t ws_bytes, void* stream, int l_hi, int l_lo);
 
+/* Fan-out of Fourier layers over ONE input: y_j = SpecConv_j(x) + W_j x + b_j, j < n_out.  The GRU-style cell of the
+ * recurrent neural operator evaluates eight Fourier layers on three distinct inputs (neuralop/models/rno.py:254-260:
+ * f1, f3, f5, f7 on x; f2, f4, f8 on h; f6 on r * h); the reference transforms each input once per layer.  Here the
+ * forward transforms of the shared input run once for all members, and backward produces dx = sum_j dL/dx|_j by chaining
+ * the members through the block kernel's gradient-addend input (no accumulation pass, no n_out separate dx tensors).
+ * `plan` is a block-stack plan (Cin = Cout = 0, gelu_mask = 0) created with n_layers >= n_out; members occupy layer slots
+ * 0..n_out-1 of FnoModelParams / FnoModelGrads (skip_w, spec_w only), biases are separate (C) arrays (entries / the
+ * array itself nullable).  Workspace: fno_model_workspace_bytes(plan, batch); stash: fno_fanout_saved_bytes. */
+size_t fno_fanout_saved_bytes(const FnoModelPlan* plan, int batch, int n_out);
+int fno_fanout_forward(const FnoModelPlan* plan, int batch, int n_out, const FnoModelParams* p, const float* const* bias,
+                       const float* x, float* const* y, void* saved, void* ws, size_t ws_bytes, void* stream);
+int fno_fanout_backward(const FnoModelPlan* plan, int batch, int n_out, const FnoModelParams* p, const float* x,
+                        const float* const* dy, const void* saved, const FnoModelGrads* g, float* const* dbias, float* dx,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Training-step tail (run_pde_observers.py:185-193), SURVEY.md section 8(f) rank 2.
  * Loss: pd = pred*(std+eps)+mean, td = target*(std+eps)+mean  (NormalizerGivenMeanStd.cuda_decode,

@@ -1106,6 +1106,119 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
 }
 
 // ===========================================================================
+// Fan-out of Fourier layers over ONE input (neuralop/models/rno.py:254-260: f1, f3, f5, f7 act on x, f2, f4, f8 on h):
+//   y_j = SpecConv_j(x) + W_j x + b_j,  j < n_out,
+// on a block-stack plan (Cin = Cout = 0, no GELU) created with n_layers >= n_out (sizes the workspace).  The forward row
+// transform and leading-axis passes of x run once for all members; backward chains the members' input gradients through
+// the block kernel's gradient-addend input (dx is read and rewritten in place), so no accumulation pass exists.
+// Members use layer slots 0..n_out-1 of FnoModelParams / FnoModelGrads (skip_w, spec_w); biases come as separate (C) arrays.
+// ===========================================================================
+static int fanout_check(const FnoModelPlan* p, int B, int n_out) {
+  if (!p || B < 1) return fail(FNO_EINVAL, "fno_fanout: bad argument");
+  if (p->d.Cin != 0 || p->d.Cout != 0 || p->d.gelu_mask != 0)
+    return fail(FNO_EINVAL, "fno_fanout: needs a block-stack plan (Cin = Cout = 0) without activations");
+  if (n_out < 1 || n_out > p->d.n_layers) return fail(FNO_EINVAL, "fno_fanout: %d members on a plan sized for %d", n_out, p->d.n_layers);
+  return FNO_OK;
+}
+extern "C" size_t fno_fanout_saved_bytes(const FnoModelPlan* p, int B, int n_out) {
+  if (!p || B < 1 || n_out < 1) return 0;
+  const ModelSizes s = model_sizes(p, B);
+  return (s.n_hat + (size_t)2 * n_out * s.n_wp) * sizeof(float) + 256;
+}
+extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const FnoModelParams* prm,
+                                  const float* const* bias, const float* x, float* const* y, void* saved, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  LAUNCHCHK(fanout_check(p, B, n_out));
+  if (!prm || !x || !y || !saved) return fail(FNO_EINVAL, "fno_fanout_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const int C = p->d.C;
+  const ModelSizes s = model_sizes(p, B);
+  bool ok;
+  ModelWs w = carve_model(p, B, ws, ws_bytes, false, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  float* hat = (float*)saved;
+  float* wps = hat + s.n_hat;
+  float* wpts = wps + (size_t)n_out * s.n_wp;
+  {
+    CornerPtrsL cp;
+    memset(&cp, 0, sizeof(cp));
+    for (int j = 0; j < n_out; ++j)
+      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (const float2*)prm->spec_w[j][c];
+    const ModeMap mm = make_modemap(g, C, C);
+    const size_t n = (size_t)g.Ktot * C * C;
+    LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st, cp,
+                     (float2*)wps, (float2*)wpts, mm, n));
+  }
+  LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));
+  LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));        // the shared truncated spectrum of x
+  for (int j = 0; j < n_out; ++j) {
+    if (!y[j]) return fail(FNO_EINVAL, "fno_fanout_forward: y[%d] is null", j);
+    LAUNCHCHK(mode_gemm(st, hat, wps + (size_t)j * s.n_wp, w.ohat, B, g.Ktot, C, C, 0));
+    LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z));
+    PwFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = prm->skip_w[j]; a.bias = bias ? bias[j] : nullptr;
+    a.z = w.z; a.tinv = p->t.tinv_f; a.u = y[j]; a.tfwd = p->t.tfwd_f;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
+  }
+  return FNO_OK;
+}
+extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, const FnoModelParams* prm, const float* x,
+                                   const float* const* dy, const void* saved, const FnoModelGrads* gr,
+                                   float* const* dbias, float* dx, void* ws, size_t ws_bytes, void* stream) {
+  LAUNCHCHK(fanout_check(p, B, n_out));
+  if (!prm || !x || !dy || !saved || !gr || !dx) return fail(FNO_EINVAL, "fno_fanout_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const Geom& g = p->g;
+  const int C = p->d.C;
+  const ModelSizes s = model_sizes(p, B);
+  bool ok;
+  ModelWs w = carve_model(p, B, ws, ws_bytes, true, &ok);
+  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  const float* hat = (const float*)saved;
+  const float* wpts = hat + s.n_hat + (size_t)n_out * s.n_wp;
+  const int ks = bbwd_ksplit(p);
+  JobList jobs;
+  for (int j = 0; j < n_out; ++j) {
+    if (!dy[j]) return fail(FNO_EINVAL, "fno_fanout_backward: dy[%d] is null", j);
+    float* dwp_j = w.dwp + (size_t)j * s.n_wp;
+    float* dw_part_j = w.dw_part + (size_t)j * s.grid * ks * C * C;
+    float* db_part_j = w.db_part + (size_t)j * s.grid * C;
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], w.x1));
+    LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
+    LAUNCHCHK(mode_gemm_dw(st, hat, w.ohat, dwp_j, B, g.Ktot, C, C));
+    LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
+    LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
+    BlkBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = dy[j]; a.uin = x; a.w = prm->skip_w[j];
+    a.zg = w.z; a.tinv = p->t.tinv_b;
+    a.gout = dx; a.gadd = j > 0 ? dx : nullptr;          // every lane re-reads exactly the elements it then rewrites
+    a.tfwd = p->t.tfwd_b;
+    a.dw_part = dw_part_j; a.db_part = db_part_j;
+    a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
+    a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
+    jobs.add(dw_part_j, gr->skip_w[j], s.grid * ks, C, C, C, C);
+    if (dbias && dbias[j]) jobs.add(db_part_j, dbias[j], s.grid, 1, C, C, C);
+  }
+  LAUNCHCHK(jobs.run(st));
+  CornerPtrsMutL cp;
+  memset(&cp, 0, sizeof(cp));
+  for (int j = 0; j < n_out; ++j)
+    for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (float2*)gr->spec_w[j][c];
+  const ModeMap mm = make_modemap(g, C, C);
+  size_t per = (size_t)g.modes[0] * g.wl_stride;
+  if (g.nlead == 2) per *= g.modes[1];
+  const size_t n = (size_t)(1 << g.nlead) * C * C * per;
+  return launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st,
+                (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C);
+}
+
+// ===========================================================================
 // Training-step tail: fused decode + LpLoss.rel (+ gradient) and Adam on a flat bucket
 // ===========================================================================
 static const int kLossSplit = 16;

@@ -455,6 +455,95 @@ def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0):
 
 
 # ----------------------------------------------------------------------------
+# fan-out of Fourier layers over one input (RNO cell: f1, f3, f5, f7 on x; f2, f4, f8 on h)
+# ----------------------------------------------------------------------------
+FANOUT_MAX = 4
+
+
+class _FourierFanoutFn(torch.autograd.Function):
+    """Tensor arguments: x, then skip_w[n], bias[n], spec_w[n * ncorner] (member-major).  Returns n tensors."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *rest):
+        n, modes, norm = cfg
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        dims = tuple(x.shape[2:])
+        ndim = len(dims)
+        nc = 2 ** (ndim - 1)
+        skip_ws = [t.contiguous() for t in rest[:n]]
+        biases = [t.contiguous() for t in rest[n:2 * n]]
+        spec_ws = [t.contiguous() for t in rest[2 * n:]]
+        assert len(spec_ws) == n * nc and n <= FANOUT_MAX
+        for t in skip_ws + biases + spec_ws:
+            _require_cuda(t, "parameter")
+        B, c = x.shape[0], x.shape[1]
+        L = _lib.lib()
+        plan = model_plan(ndim, 0, c, 0, 0, FANOUT_MAX, dims, modes, norm, 0, x.device)
+        prm = _lib.FnoModelParams()
+        for j in range(n):
+            prm.skip_w[j] = skip_ws[j].data_ptr()
+            for k in range(nc):
+                prm.spec_w[j][k] = spec_ws[j * nc + k].data_ptr()
+        ys = [torch.empty_like(x) for _ in range(n)]
+        bptr = (C.c_void_p * n)(*[b.data_ptr() for b in biases])
+        yptr = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
+        saved = _bytes(L.fno_fanout_saved_bytes(plan, B, n), x.device)
+        nws = L.fno_model_workspace_bytes(plan, B)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_fanout_forward(plan, B, n, C.byref(prm), bptr, _ptr(x), yptr, _ptr(saved), _ptr(ws), nws,
+                                            _stream()), "fanout_forward")
+        ctx.plan, ctx.B, ctx.n, ctx.nc = plan, B, n, nc
+        ctx.save_for_backward(x, saved, *skip_ws, *spec_ws)
+        ctx.bias_shapes = [b.shape for b in rest[n:2 * n]]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        sv = ctx.saved_tensors
+        x, saved = sv[:2]
+        n, nc = ctx.n, ctx.nc
+        skip_ws, spec_ws = list(sv[2:2 + n]), list(sv[2 + n:])
+        dys = [torch.zeros_like(x) if d is None else d.contiguous() for d in dys]
+        L = _lib.lib()
+        prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
+        g_skip = [torch.empty_like(t) for t in skip_ws]
+        g_spec = [torch.empty_like(t) for t in spec_ws]
+        g_bias = [torch.empty(x.shape[1], dtype=torch.float32, device=x.device) for _ in range(n)]
+        for j in range(n):
+            prm.skip_w[j], grd.skip_w[j] = skip_ws[j].data_ptr(), g_skip[j].data_ptr()
+            for k in range(nc):
+                prm.spec_w[j][k], grd.spec_w[j][k] = spec_ws[j * nc + k].data_ptr(), g_spec[j * nc + k].data_ptr()
+        dyptr = (C.c_void_p * n)(*[d.data_ptr() for d in dys])
+        dbptr = (C.c_void_p * n)(*[b.data_ptr() for b in g_bias])
+        dx = torch.empty_like(x)
+        nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.fno_fanout_backward(ctx.plan, ctx.B, n, C.byref(prm), _ptr(x), dyptr, _ptr(saved), C.byref(grd), dbptr,
+                                             _ptr(dx), _ptr(ws), nws, _stream()), "fanout_backward")
+        g_bias = [g.view(sh) for g, sh in zip(g_bias, ctx.bias_shapes)]
+        return (None, dx if ctx.needs_input_grad[1] else None) + tuple(g_skip) + tuple(g_bias) + tuple(g_spec)
+
+
+def fanout_supported(x, n, modes, norm):
+    if not (1 <= n <= FANOUT_MAX and blocks_supported(x)):
+        return False
+    return model_plan_available(x.dim() - 2, 0, x.shape[1], 0, 0, FANOUT_MAX, tuple(x.shape[2:]), tuple(int(m) for m in modes),
+                                norm, 0, x.device)
+
+
+def fourier_fanout(x, skip_ws, biases, spec_ws, modes, norm):
+    """[SpecConv_j(x) + conv1x1(x; skip_ws[j]) + biases[j] for j < n]: n <= 4 Fourier layers (rno.py:215-228) on ONE input,
+    whose forward transforms run once and whose input gradients are summed inside the backward kernels
+    (include/fnoengine.h, fno_fanout_*).  spec_ws is member-major: member j's corner weights at [j * ncorner, (j+1) * ncorner)."""
+    n = len(skip_ws)
+    cfg = (n, tuple(int(m) for m in modes), norm)
+    return _FourierFanoutFn.apply(cfg, x, *skip_ws, *biases, *spec_ws)
+
+
+# ----------------------------------------------------------------------------
 # PINO residual loss (spectral Navier-Stokes vorticity residual + initial condition)
 # ----------------------------------------------------------------------------
 class _PinoLossFn(torch.autograd.Function):

@@ -134,7 +134,23 @@ class RNO_cell(nn.Module):
         for i in range(1, 5):
             setattr(self, f"b{i}", nn.Parameter(torch.normal(torch.tensor(0.), torch.tensor(1.))))
 
+    def _fan(self, layers, t):
+        """Fourier layers that share the input t as one engine fan-out (fno_fanout_*): t is transformed once, and the
+        layers' input gradients are summed inside the backward kernels."""
+        sc = layers[0].spec_conv
+        return F.fourier_fanout(t, [l.norm_conv1d.weight for l in layers], [l.norm_conv1d.bias for l in layers],
+                                [w for l in layers for w in l.spec_conv.fourier_weight], (sc.modes1, sc.modes2), sc.norm)
+
     def forward(self, x, h):
+        sc = self.f1.spec_conv
+        if (F.gates_supported(x, h) and x.shape == h.shape and x.shape[-1] == x.shape[-2]
+                and F.fanout_supported(x, 4, (sc.modes1, sc.modes2), sc.norm)):
+            # three distinct inputs feed the eight Fourier layers (rno.py:254-260): x -> f1, f3, f5, f7; h -> f2, f4, f8;
+            # r * h -> f6
+            a1, a3, a5, a7 = self._fan((self.f1, self.f3, self.f5, self.f7), x)
+            a2, a4, a8 = self._fan((self.f2, self.f4, self.f8), h)
+            rh = F.rno_reset_gate(a3, a4, self.b2, h)
+            return F.rno_output_gate(a1, a2, self.b1, a7, a8, self.b4, a5, self.f6(rh), self.b3, h)
         if F.gates_supported(x, h):
             # two fused engine kernels for everything between the eight Fourier layers (fno_rno_*_gate_*)
             rh = F.rno_reset_gate(self.f3(x), self.f4(h), self.b2, h)

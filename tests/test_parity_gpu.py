@@ -504,6 +504,45 @@ def test_block_stack_vs_oracle(dev, C, S, modes, B, L, norm):
     assert rel_l2(_cpu(dl[0].grad), leaves[0].grad.numpy()) < TOL_Y
 
 
+@pytest.mark.parametrize("n_out,shape,modes,norm", [(4, (2, 64, 64, 64), (12, 12), "ortho"), (3, (1, 32, 32, 32), (5, 7), "ortho"),
+                                                    (2, (2, 32, 8, 16, 32), (3, 4, 5), "backward")])
+def test_fourier_fanout_equals_separate_layers(dev, n_out, shape, modes, norm):
+    """fno_fanout_* (shared forward transforms, input gradients chained in place) vs n_out separate fused Fourier layers
+    (F.fno_blocks, themselves pinned against the oracle above): outputs, dx (the SUM over members) and every parameter gradient."""
+    from pde_policylearning_amd import functional as F
+    C, nd = shape[1], len(shape) - 2
+    nc = 2 ** (nd - 1)
+    x = torch.from_numpy(fill_named("fan.x", shape, 1.0)).to(dev)
+    skip = [torch.from_numpy(fill_named(f"fan.s{j}", (C, C, 1), 0.1)).to(dev) for j in range(n_out)]
+    bias = [torch.from_numpy(fill_named(f"fan.b{j}", (C,), 0.1)).to(dev) for j in range(n_out)]
+    spec = [torch.from_numpy(fill_named(f"fan.w{i}", (C, C) + tuple(modes) + (2,), 0.02)).to(dev) for i in range(n_out * nc)]
+    dys = [torch.from_numpy(fill_named(f"fan.d{j}", shape, 1.0)).to(dev) for j in range(n_out)]
+    assert F.fanout_supported(x, n_out, modes, norm)
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in [x] + skip + bias + spec]
+    la = leaves()
+    ys = F.fourier_fanout(la[0], la[1:1 + n_out], la[1 + n_out:1 + 2 * n_out], la[1 + 2 * n_out:], modes, norm)
+    torch.autograd.backward(ys, dys)
+    lb = leaves()
+    for j in range(n_out):
+        yj = F.fno_blocks(lb[0], [lb[1 + j]], lb[1 + 2 * n_out + j * nc:1 + 2 * n_out + (j + 1) * nc],
+                          lb[1 + n_out + j].view(1, C), modes, norm)
+        assert rel_l2(_cpu(ys[j]), _cpu(yj)) < 1e-6, j
+        yj.backward(dys[j])
+    for a, b in zip(la, lb):
+        assert rel_l2(_cpu(a.grad), _cpu(b.grad)) < 2e-6, tuple(a.shape)
+    # an unused member (no gradient arrives for it) contributes zero
+    lc = leaves()
+    ys = F.fourier_fanout(lc[0], lc[1:1 + n_out], lc[1 + n_out:1 + 2 * n_out], lc[1 + 2 * n_out:], modes, norm)
+    ys[0].backward(dys[0])
+    ld = leaves()
+    F.fno_blocks(ld[0], [ld[1]], ld[1 + 2 * n_out:1 + 2 * n_out + nc], ld[1 + n_out].view(1, C), modes, norm).backward(dys[0])
+    assert rel_l2(_cpu(lc[0].grad), _cpu(ld[0].grad)) < 2e-6
+    if n_out > 1:
+        assert float(lc[2].grad.abs().max()) == 0.0
+
+
 def test_rno2d_named_config_uses_fused_layers_and_matches_unfused(dev):
     """RNO2d as named in BASELINE config 3 (width 64, 128x128 reduced to 64x64 here): the fused FourierLayer2d path must
     agree with the unfused composition (engine spectral conv + torch Conv1d) it replaces."""
