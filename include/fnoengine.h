@@ -37,6 +37,11 @@ const char* fno_last_error(void);
  * 0 = fp32 MFMA.  Environment FNO_GEMM_F32=1 selects 0 at load time. */
 void fno_set_gemm_mode(int split_bf16x3);
 int fno_get_gemm_mode(void);
+/* The mode contraction 'bixy,ioxy->boxy' (spectral_convolution.py:15-36, rno.py:51-58, basics.py:14-24) and its two
+ * adjoints: 1 (default) = one real GEMM per kept mode on the fp32 matrix cores (32 / 64 channels; other channel counts
+ * always take the VALU kernels); 0 = VALU kernels everywhere.  Environment FNO_MODE_GEMM_VALU=1 selects 0 at load time. */
+void fno_set_mode_gemm(int mfma);
+int fno_get_mode_gemm(void);
 
 /* ------------------------------------------------------------------------
  * Standalone spectral convolution  y = irfftn(pad(W_c . rfftn(x)[corner_c])) (+ bias)

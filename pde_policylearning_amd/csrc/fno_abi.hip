@@ -50,6 +50,11 @@ static int g_gemm_x3 = []() { const char* e = getenv("FNO_GEMM_F32"); return (e 
 extern "C" void fno_set_gemm_mode(int x3) { g_gemm_x3 = x3 ? 1 : 0; }
 extern "C" int fno_get_gemm_mode(void) { return g_gemm_x3; }
 extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
+// mode contraction on the fp32 matrix cores (default) or the VALU kernels (FNO_MODE_GEMM_VALU=1 / fno_set_mode_gemm(0)):
+// an A/B switch for profiling and for the parity tests, which run both
+static int g_mode_mfma = []() { const char* e = getenv("FNO_MODE_GEMM_VALU"); return (e && e[0] == '1') ? 0 : 1; }();
+extern "C" void fno_set_mode_gemm(int mfma) { g_mode_mfma = mfma ? 1 : 0; }
+extern "C" int fno_get_mode_gemm(void) { return g_mode_mfma; }
 
 // --------------------------------------------------------------------------
 // optional per-kernel timing (HIP events on the launch stream)
@@ -333,6 +338,16 @@ static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, i
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
                      int conj_w) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
+    const dim3 grid(Ktot, (B + 63) / 64), blk(2 * (2 * Cout / 32) * 64);
+    const size_t lds = ((size_t)64 * (2 * Cin + 1) + (size_t)2 * Cin * (2 * Cout + 32)) * 4;
+    const float2 *xx = (const float2*)x, *ww = (const float2*)w;
+    float2* oo = (float2*)out;
+    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
+    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
+    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
+    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
+  }
   if (512 % Cout == 0 && Cout >= 32) {
     const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
     const size_t lds = ((size_t)Cin * Cout + (size_t)bt * Cin) * 8;
@@ -347,6 +362,16 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
 }
 static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
+    const dim3 grid(Ktot), blk((Cin / 32) * (2 * Cout / 32) * 64);
+    const size_t lds = ((size_t)64 * 2 * Cin + (size_t)128 * (2 * Cout + 32)) * 4;
+    const float2 *xx = (const float2*)x, *gg = (const float2*)g;
+    float2* dd = (float2*)dw;
+    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
+    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
+    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
+    return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
+  }
   if (512 % Cout == 0 && Cout >= 32) {
     const int it = 2 * (512 / Cout);                   // 2 input channels per thread
     return launch("k_mode_gemm_dw", k_mode_gemm_dw_lds<2>, dim3(Ktot, (Cin + it - 1) / it), dim3(512),

@@ -5,7 +5,8 @@
 //   k_axis_pass        truncated DFT / inverse DFT along one leading axis, as a
 //                      table-driven complex mat-vec: out[o][r][q] = sum_n tw[r][n] in[o][n][q]
 //   k_pack_w / k_unpack_dw   reference corner-weight layout (Cin,Cout,m..) <-> mode-major [K][Cin][Cout]
-//   k_mode_gemm_*      the complex contraction 'bixy,ioxy->boxy' over kept modes and its two adjoints
+//   k_mode_gemm_*      the complex contraction 'bixy,ioxy->boxy' over kept modes and its two adjoints (32 / 64 channels:
+//                      one real GEMM per mode on the fp32 matrix cores, k_mode_gemm_mfma / k_mode_gemm_dw_mfma)
 //                      (neuralop/models/spectral_convolution.py:15-36, rno.py:51-58, basics.py:14-24)
 //   k_rowdft_generic / k_rowidft_generic   last-dim passes for shapes the fused MFMA
 //                      kernels do not cover (W not a multiple of 32, odd channel counts)
@@ -353,6 +354,109 @@ __global__ void __launch_bounds__(512) k_mode_gemm_dw_lds(const float2* __restri
     const int i = i0 + ig + j * ng;
     if (i < Cin) dw[((size_t)k * Cin + i) * Cout + o] = make_float2(sr[j], si[j]);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-core variants of the mode contraction for 32 / 64 channels: per kept mode k the complex product
+// 'bi,io->bo' is ONE real GEMM on the interleaved (re, im) storage,
+//   [.. xr_i xi_i ..] (B x 2Cin)  .  [[ wr  wi ], [ -wi  wr ]]_(i,o) (2Cin x 2Cout)  =  [.. yr_o yi_o ..] (B x 2Cout),
+// run as exact-fp32 v_mfma_f32_32x32x2_f32 tiles (K step 2 = one complex input channel).  A workgroup owns one mode and
+// 64 batch rows; the expanded real weight block and the spectra are staged once in LDS (weight rows padded by 32 floats so
+// that the two lane halves, which read adjacent k rows, fall on disjoint banks; spectrum rows by 1 float for the
+// row-per-lane A reads).  Wave (mt, nt): batch rows [32 mt, +32), real output columns [32 nt, +32).
+//   grid (Ktot, ceil(B / 64)), block 2 * (2 CO / 32) waves, LDS 64 (2 CI + 1) + 2 CI (2 CO + 32) floats
+template <int CI, int CO>
+__global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
+                                                                           const float2* __restrict__ w,
+                                                                           float2* __restrict__ out, int B, int Ktot,
+                                                                           int conj_w) {
+  constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1, PB = 2 * CO + 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                 // [64][PA]
+  float* ws = smem + 64 * PA;       // [2 CI][PB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int k = blockIdx.x, b0 = blockIdx.y * 64;
+  const int nb = min(64, B - b0);
+  const float sg = conj_w ? -1.f : 1.f;
+  const float2* wk = w + (size_t)k * CI * CO;
+  for (int i = tid; i < CI * CO; i += NT) {
+    const int ci = i / CO, o = i % CO;
+    float2 v = wk[i];
+    v.y *= sg;
+    float* r0 = ws + (2 * ci) * PB + 2 * o;
+    r0[0] = v.x; r0[1] = v.y;
+    r0[PB] = -v.y; r0[PB + 1] = v.x;
+  }
+  for (int i = tid; i < 64 * CI; i += NT) {
+    const int bb = i / CI, ci = i % CI;
+    const float2 v = bb < nb ? x[((size_t)(b0 + bb) * Ktot + k) * CI + ci] : make_float2(0.f, 0.f);
+    xs[bb * PA + 2 * ci] = v.x;
+    xs[bb * PA + 2 * ci + 1] = v.y;
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ap = xs + (mt * 32 + l31) * PA + half;
+  const float* bp = ws + half * PB + nt * 32 + l31;
+#pragma unroll 8
+  for (int s = 0; s < CI; ++s) acc = mfma32(ap[2 * s], bp[(2 * s) * PB], acc);
+  float* op = reinterpret_cast<float*>(out);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int bb = mt * 32 + acc_row32(r, half);
+    if (bb < nb) op[((size_t)(b0 + bb) * Ktot + k) * (2 * CO) + nt * 32 + l31] = acc[r];
+  }
+}
+
+// dW[k][i][o] = sum_b conj(X[b][k][i]) G[b][k][o] the same way: rows i, real columns 2o + c, K = 2B with
+//   A[i][2b + h] = (xr, xi)_h,   B[2b][2o + c] = (gr, gi)_c,   B[2b + 1][2o + c] = (gi, -gr)_c.
+// The batch is staged in chunks of 64 samples.  Wave (mt, nt): input channels [32 mt, +32), columns [32 nt, +32).
+//   grid (Ktot), block (CI / 32) * (2 CO / 32) waves, LDS 64 * 2 CI + 128 (2 CO + 32) floats
+template <int CI, int CO>
+__global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw_mfma(const float2* __restrict__ x,
+                                                                                      const float2* __restrict__ g,
+                                                                                      float2* __restrict__ dw, int B,
+                                                                                      int Ktot) {
+  constexpr int NTN = 2 * CO / 32, NT = (CI / 32) * NTN * 64, PA = 2 * CI, PB = 2 * CO + 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                 // [64][PA]   raw interleaved spectra of the chunk
+  float* gs = smem + 64 * PA;       // [128][PB]  rows 2b: (gr, gi), rows 2b + 1: (gi, -gr)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int k = blockIdx.x;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = min(64, B - b0);
+    __syncthreads();
+    for (int i = tid; i < 64 * CI; i += NT) {
+      const int bb = i / CI, ci = i % CI;
+      const float2 v = bb < nb ? x[((size_t)(b0 + bb) * Ktot + k) * CI + ci] : make_float2(0.f, 0.f);
+      xs[bb * PA + 2 * ci] = v.x;
+      xs[bb * PA + 2 * ci + 1] = v.y;
+    }
+    for (int i = tid; i < 64 * CO; i += NT) {
+      const int bb = i / CO, o = i % CO;
+      const float2 v = bb < nb ? g[((size_t)(b0 + bb) * Ktot + k) * CO + o] : make_float2(0.f, 0.f);
+      float* r0 = gs + (2 * bb) * PB + 2 * o;
+      r0[0] = v.x; r0[1] = v.y;
+      r0[PB] = v.y; r0[PB + 1] = -v.x;
+    }
+    __syncthreads();
+    const float* ap = xs + 2 * (mt * 32 + l31) + half;
+    const float* bp = gs + half * PB + nt * 32 + l31;
+#pragma unroll 8
+    for (int s = 0; s < 64; ++s) acc = mfma32(ap[s * PA], bp[(2 * s) * PB], acc);
+  }
+  float* op = reinterpret_cast<float*>(dw);
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    op[((size_t)k * CI + mt * 32 + acc_row32(r, half)) * (2 * CO) + nt * 32 + l31] = acc[r];
 }
 
 // dW[k][i][o] = sum_b conj(X[b][k][i]) * G[b][k][o]

@@ -414,6 +414,36 @@ def test_fno2d_observer_train_trajectory_fused_tail(dev):
         assert abs(float(loss) - float(g["losses"][step])) < 5e-5 * abs(float(g["losses"][step])), step
 
 
+@pytest.mark.parametrize("shape,modes,cout", [((70, 64, 32, 32), (6, 5), 64), ((3, 32, 16, 32), (4, 4), 32), ((33, 64, 8, 8, 16), (2, 3, 4), 64)])
+def test_mode_contraction_matrix_cores_equal_valu_kernels(dev, shape, modes, cout):
+    """'bixy,ioxy->boxy' as one real GEMM per mode on the fp32 matrix cores (k_mode_gemm_mfma / k_mode_gemm_dw_mfma: the
+    default for 32 / 64 channels, so every other parity test runs it) vs the VALU kernels it replaces (fno_set_mode_gemm(0)):
+    y, dx, dW; batches that are not a multiple of the 32-row tile or span two 64-row workgroups."""
+    from pde_policylearning_amd import _lib
+    from pde_policylearning_amd import functional as F
+    nd = len(shape) - 2
+    C = shape[1]
+    x = torch.from_numpy(fill_named("mm.x", shape, 1.0)).to(dev)
+    dy = torch.from_numpy(fill_named("mm.dy", shape, 1.0)).to(dev)
+    ws = [torch.from_numpy(fill_named(f"mm.w{i}", (C, C) + tuple(modes) + (2,), 0.05)).to(dev) for i in range(2 ** (nd - 1))]
+    L = _lib.lib()
+    assert L.fno_get_mode_gemm() == 1
+    res = []
+    for mode in (1, 0):
+        L.fno_set_mode_gemm(mode)
+        try:
+            xe = x.clone().requires_grad_(True)
+            we = [w.clone().requires_grad_(True) for w in ws]
+            y = F.spectral_conv(xe, we, None, modes, "ortho")
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res.append([_cpu(y), _cpu(xe.grad)] + [_cpu(w.grad) for w in we])
+        finally:
+            L.fno_set_mode_gemm(1)
+    for a, b in zip(*res):
+        assert rel_l2(a, b) < 1e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # standalone spectral convolution at the shapes that take the MFMA last-dim tile kernels
 # (k_rowdft_tile / k_rowidft_tile: 32 or 64 channels, rows of 32 / 64 / 128 floats) vs the oracle
