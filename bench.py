@@ -47,7 +47,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r01_v12_pmc_traffic.json"
+PMC_TRAFFIC_JSON = "r01_v22_pmc_traffic.json"
+PMC_SQ_CSV = "r01_v22_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def kernel_model(cfg):
@@ -261,6 +262,21 @@ def main():
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                                   "separate passes, corrected; same command and workload)")
                     roofline["algorithmic_bytes"] = round(km[dom["name"]]["bytes"])
+            except Exception:
+                pass
+            # matrix-pipe occupancy of that kernel from the committed SQ pass: busy cycles summed over the 1024 SIMDs /
+            # (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            try:
+                import csv
+                if args.config == "fno2d_128x128_w64_m12_b64":
+                    base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
+                    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", PMC_SQ_CSV))):
+                        if r["kernel"] in (base + "_x3", base):
+                            roofline["matrix_pipe_busy"] = round(float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0
+                                                                 / (float(r["GRBM_GUI_ACTIVE"]) / 8.0), 3)
+                            roofline["matrix_pipe_busy_source"] = f"profiles/{PMC_SQ_CSV} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, own pass)"
+                            if r["kernel"].endswith("_x3"):
+                                break
             except Exception:
                 pass
             roofline["avg_launch_ms"] = dom["avg_ms"]
