@@ -221,6 +221,78 @@ def test_fno2d_fullsize_properties(dev):
         assert rel_l2(_cpu(pg2[k].grad) + _cpu(pg3[k].grad), gfull) < 2e-5, k
 
 
+def _module_fullsize_properties(model, inputs, tgt, dev, tol_add=5e-5):
+    """(i) batch independence, (ii) parameter gradients additive over the batch under the sum-reduced relative L2
+    (the data-parallel invariant: N ranks == one big batch), (iii) finite, non-zero gradients."""
+    B = inputs[0].shape[0]
+
+    def run(lo, hi):
+        model.zero_grad(set_to_none=True)
+        y = model(*[t[lo:hi] for t in inputs])
+        O.lp_loss_rel_sum(y.reshape(hi - lo, -1), tgt[lo:hi].reshape(hi - lo, -1)).backward()
+        return y.detach(), [p.grad.detach().clone() for p in model.parameters()]
+    y, g = run(0, B)
+    y1, _ = run(0, 1)
+    assert rel_l2(_cpu(y[:1]), _cpu(y1)) < 2e-6
+    _, ga = run(0, B // 2)
+    _, gb = run(B // 2, B)
+    for (name, _), gf, u, v in zip(model.named_parameters(), g, ga, gb):
+        gf = _cpu(torch.view_as_real(gf) if gf.is_complex() else gf)
+        s = _cpu(torch.view_as_real(u + v) if u.is_complex() else u + v)
+        assert np.isfinite(gf).all() and np.abs(gf).max() > 0, name
+        assert rel_l2(s, gf) < tol_add, name
+
+
+def test_rno2d_fullsize_properties(dev):
+    """BASELINE config 3 as named: RNO2d(12, 12, 64), 128 x 128, 32 fields per GPU (256 / 8)."""
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    torch.manual_seed(0)
+    model = RNO2dObserver(12, 12, 64, 0, layer_num=1).to(dev).eval()
+    x = torch.from_numpy(fill_named("rnofull.x", (32, 1, 128, 128, 1), 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("rnofull.t", (32, 128, 128, 1), 1.0)).to(dev)
+    _module_fullsize_properties(model, (x,), tgt, dev)
+
+
+def test_fno3d_fullsize_properties(dev):
+    """BASELINE config 4: FNO3d(8, 8, 8, 32) on 64^3 fields, batch 16."""
+    from pde_policylearning_amd.neuralop.models import FNO3d
+    torch.manual_seed(0)
+    model = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1).to(dev)
+    x = torch.from_numpy(fill_named("f3full.x", (16, 3, 64, 64, 64), 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("f3full.t", (16, 1, 64, 64, 64), 1.0)).to(dev)
+    _module_fullsize_properties(model, (x,), tgt, dev)
+
+
+def test_pino_finetune_fullsize_properties(dev):
+    """BASELINE config 5 as shipped (configs/pino-observer-finetune-1s.yaml): PINObserver2d, 128 x 128 x 65, modes 8, batch 4,
+    and the residual loss at that size: loss_f / loss_ic are batch MEANS of per-sample relative norms, so the batch-4
+    value is the mean of the two half-batch values and dL/du of a sample does not depend on its batch mates up to 1 / B."""
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.libs.models.pino_models import PINObserver2d
+    from oracle import pino_loss_oracle as P
+    torch.manual_seed(0)
+    model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4, out_dim=1,
+                          act="gelu", pad_ratio=0.0625).to(dev)
+    x = torch.from_numpy(fill_named("p5full.x", (4, 128, 128, 65, 4), 1.0)).to(dev)
+    re = torch.tensor([[120.0], [180.0], [250.0], [395.0]], device=dev)
+    tgt = torch.from_numpy(fill_named("p5full.t", (4, 128, 128, 65, 1), 1.0)).to(dev)
+    _module_fullsize_properties(model, (x, re), tgt, dev)
+    u = torch.from_numpy(fill_named("p5full.u", (4, 128, 128, 65), 1.0)).to(dev)
+    u0 = u[..., 0].clone() + 0.1
+    f = P.forcing(128).to(dev)
+    visc = (1.0 / re.reshape(4))
+
+    def run(lo, hi):
+        ue = u[lo:hi].clone().requires_grad_(True)
+        lic, lf = F.pino_loss(ue, u0[lo:hi], f, visc[lo:hi], 0.5)
+        (5.0 * lic + lf).backward()
+        return float(lic), float(lf), ue.grad
+    a, b, c = run(0, 4), run(0, 2), run(2, 4)
+    assert abs(a[0] - 0.5 * (b[0] + c[0])) < 2e-6 * abs(a[0])
+    assert abs(a[1] - 0.5 * (b[1] + c[1])) < 2e-6 * abs(a[1])
+    assert rel_l2(_cpu(torch.cat([b[2], c[2]]) * 0.5), _cpu(a[2])) < 2e-6
+
+
 def test_fails_loudly_on_cpu_tensor(dev):
     from pde_policylearning_amd import functional as F
     with pytest.raises(RuntimeError):
