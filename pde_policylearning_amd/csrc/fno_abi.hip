@@ -588,6 +588,28 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, const f
     int rb = std::max(1, std::min(chan_rb, 320 / g.W));
     while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
     const size_t lds2 = (size_t)C * (rb * g.W + 1) * 4;
+    static const int chan_mfma = getenv("FNO_ROW_INV_VALU") ? 0 : 1;
+    if (chan_mfma && C % 32 == 0 && g.W <= 128) {            // truncated inverse DFT on the fp32 matrix cores
+      const size_t tabb = (size_t)2 * g.Klast * (((g.W + 31) / 32) * 32 + 4) * 4;
+      static const int flat = getenv("FNO_ROW_INV_ROWTILES") ? 0 : 1;
+      const size_t ldsf = (size_t)C * (ROWFLAT_CH + 4) * 4 + tabb;
+      if (flat && g.PW % 4 == 0 && g.W < ROWFLAT_CH && ldsf <= 160 * 1024 && B <= 65535) {     // whole-line tiles of the flattened planes
+        const dim3 gridf((g.PW + ROWFLAT_CH - 1) / ROWFLAT_CH, B);
+        static const int flat_threads = getenv("FNO_ROWFLAT_THREADS") ? atoi(getenv("FNO_ROWFLAT_THREADS")) : 512;
+        if (K2P == 8) return launch("k_rowidft_chan", k_rowidft_flat_mfma<8>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
+        if (K2P == 16) return launch("k_rowidft_chan", k_rowidft_flat_mfma<16>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
+        return launch("k_rowidft_chan", k_rowidft_flat_mfma<32>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
+      }
+      int rbm = rb;
+      while (rbm > 1 && (size_t)C * (rbm * g.W + 1) * 4 + tabb > 80 * 1024) rbm >>= 1;
+      const size_t lds3 = (size_t)C * (rbm * g.W + 1) * 4 + tabb;
+      const dim3 gridm(B * ((g.P + rbm - 1) / rbm));
+      if (lds3 <= 160 * 1024) {
+        if (K2P == 8) return launch("k_rowidft_chan", k_rowidft_chan_mfma<8>, gridm, dim3(256), lds3, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast, rbm);
+        if (K2P == 16) return launch("k_rowidft_chan", k_rowidft_chan_mfma<16>, gridm, dim3(256), lds3, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast, rbm);
+        return launch("k_rowidft_chan", k_rowidft_chan_mfma<32>, gridm, dim3(256), lds3, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast, rbm);
+      }
+    }
     if (lds2 <= 160 * 1024) {
       const dim3 grid(B * ((g.P + rb - 1) / rb));
       const dim3 blk(std::min(256, ((rb * C + 63) / 64) * 64));

@@ -809,6 +809,148 @@ __global__ void __launch_bounds__(256) k_rowidft_chan(const float2* __restrict__
     for (int o = lane; o < seg; o += 64) yb[(size_t)c * cstride + o] = ys[c * pitch + o];
 }
 
+// The same pass with the truncated inverse DFT on the fp32 matrix cores (C a multiple of 32, W <= 128): per workgroup
+// one real GEMM  Y[(r, c)][w] = sum_j Z[(r, c)][j] T[j][w]  (M = RB * C items, N = W, K = 2 * K2; j = 2 * bin + re/im)
+// as v_mfma_f32_32x32x2_f32 tiles.  A operand straight from global memory: lane (l31, half) of M-tile (r, 32-channel
+// block) loads the float2 spectrum value of its channel and keeps the re (half 0) or im (half 1) part - K step s = kept
+// bin s.  B operand from an LDS copy of the (2 K2, W) table, zero-padded to whole 32-column tiles.  The VALU variant
+// above paces its FMA loop by scalar table loads that share the lgkm counter with its LDS writes; here a wave issues
+// K2 * ceil(W / 32) MFMAs per M-tile and the rest of the kernel is the store phase.
+//   LDS: ys [C][RB*W + 1] | tab [2 K2][WP],  WP = 32 * ceil(W / 32) + 4
+template <int K2P>
+__global__ void __launch_bounds__(256) k_rowidft_chan_mfma(const float2* __restrict__ z, float* __restrict__ y,
+                                                           const float* __restrict__ tinv, const float* __restrict__ bias,
+                                                           int C, int P, int W, int K2, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int pitch = RB * W + 1;
+  const int NTN = (W + 31) / 32, WP = NTN * 32 + 4;
+  float* ys = smem;                                 // [c][pitch]
+  float* tab = smem + C * pitch;                    // [2 K2][WP]
+  const int nblk = (P + RB - 1) / RB;
+  const int b = blockIdx.x / nblk, p0 = (blockIdx.x % nblk) * RB;
+  const int nr = min(RB, P - p0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  for (int i = threadIdx.x; i < 2 * K2 * WP; i += blockDim.x) {
+    const int j = i / WP, w = i - j * WP;
+    tab[i] = w < W ? tinv[(size_t)j * W + w] : 0.f;
+  }
+  __syncthreads();
+  const int cb = C / 32;                            // 32-channel blocks per row
+  for (int m = wave; m < nr * cb; m += nwave) {
+    const int r = m / cb, c0 = (m - r * cb) * 32;
+    const float2* zr = z + ((size_t)b * P + p0 + r) * K2 * C + c0 + l31;
+    float av[K2P];
+#pragma unroll
+    for (int s = 0; s < K2P; ++s) {
+      const float2 v = s < K2 ? zr[(size_t)s * C] : make_float2(0.f, 0.f);
+      av[s] = half ? v.y : v.x;
+    }
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bv[q] = bias ? bias[c0 + acc_row32(q, half)] : 0.f;
+    for (int nt = 0; nt < NTN; ++nt) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = bv[q];
+      const float* tp = tab + half * WP + nt * 32 + l31;
+#pragma unroll
+      for (int s = 0; s < K2P; ++s)
+        if (s < K2) acc = mfma32(av[s], tp[(2 * s) * WP], acc);
+      const int w = nt * 32 + l31;
+      if (w < W) {
+        float* yp = ys + (c0 + 4 * half) * pitch + r * W + w;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) yp[((q & 3) + 8 * (q >> 2)) * pitch] = acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  const int seg = nr * W;
+  const size_t cstride = (size_t)P * W;
+  float* yb = y + ((size_t)b * C * P + p0) * W;
+  for (int c = wave; c < C; c += nwave)
+    for (int o = lane; o < seg; o += 64) yb[(size_t)c * cstride + o] = ys[c * pitch + o];
+}
+
+// Same arithmetic, tiled along the FLATTENED plane instead of by rows: a workgroup owns floats [CH * j, CH * (j + 1)) of
+// every channel plane (CH = 256 floats = eight 128-byte lines) and the <= ceil(CH / W) + 1 rows that overlap them.  Row
+// runs of odd length (W = 73: 292 bytes) start at arbitrary byte offsets, so row tiles are written as unaligned dword
+// stores whose first and last lines are shared with the neighbouring workgroups (on other XCDs); flat tiles are whole
+// lines written once, by one 16-byte store per lane and channel.  Needs PW % 4 == 0 (16-byte aligned planes).
+//   grid (ceil(PW / CH), B), LDS: ys [C][CH + 4] | tab [2 K2][WP]
+constexpr int ROWFLAT_CH = 256;
+template <int K2P>
+__global__ void __launch_bounds__(512) k_rowidft_flat_mfma(const float2* __restrict__ z, float* __restrict__ y,
+                                                           const float* __restrict__ tinv, const float* __restrict__ bias,
+                                                           int C, int P, int W, int K2) {
+  constexpr int CH = ROWFLAT_CH, YP = CH + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NTN = (W + 31) / 32, WP = NTN * 32 + 4;
+  float* ys = smem;                                 // [c][YP]
+  float* tab = smem + C * YP;                       // [2 K2][WP]
+  const int b = blockIdx.y;
+  const int PW = P * W;
+  const int f0 = blockIdx.x * CH, f1 = min(f0 + CH, PW);
+  const int r_lo = f0 / W, r_hi = (f1 - 1) / W;     // rows overlapping the tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  for (int i = threadIdx.x; i < 2 * K2 * WP; i += blockDim.x) {
+    const int j = i / WP, w = i - j * WP;
+    tab[i] = w < W ? tinv[(size_t)j * W + w] : 0.f;
+  }
+  __syncthreads();
+  const int cb = C / 32;
+  const int nm = (r_hi - r_lo + 1) * cb;
+  float zn[K2P];                                    // next M-tile's spectrum values (this lane's re or im part), in
+  {                                                 // flight during this tile's MFMAs
+    const int m0 = wave < nm ? wave : 0;
+    const float* zr = reinterpret_cast<const float*>(z + ((size_t)b * P + r_lo + m0 / cb) * K2 * C + (m0 % cb) * 32 + l31) + half;
+#pragma unroll
+    for (int s = 0; s < K2P; ++s) zn[s] = s < K2 ? zr[(size_t)s * C * 2] : 0.f;
+  }
+  for (int m = wave; m < nm; m += nwave) {
+    const int r = r_lo + m / cb, c0 = (m % cb) * 32;
+    float av[K2P];
+#pragma unroll
+    for (int s = 0; s < K2P; ++s) av[s] = zn[s];
+    {
+      const int mn = m + nwave < nm ? m + nwave : m;
+      const float* zr = reinterpret_cast<const float*>(z + ((size_t)b * P + r_lo + mn / cb) * K2 * C + (mn % cb) * 32 + l31) + half;
+#pragma unroll
+      for (int s = 0; s < K2P; ++s) zn[s] = s < K2 ? zr[(size_t)s * C * 2] : 0.f;
+    }
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bv[q] = bias ? bias[c0 + acc_row32(q, half)] : 0.f;
+    for (int nt = 0; nt < NTN; ++nt) {
+      const int w = nt * 32 + l31;
+      const int f = r * W + w - f0;                 // position of (r, w) inside the tile
+      if (r * W + nt * 32 >= f1 || r * W + nt * 32 + 31 < f0) continue;     // whole column block outside (wave-uniform)
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = bv[q];
+      const float* tp = tab + half * WP + nt * 32 + l31;
+#pragma unroll
+      for (int s = 0; s < K2P; ++s)
+        if (s < K2) acc = mfma32(av[s], tp[(2 * s) * WP], acc);
+      if (w < W && f >= 0 && f < f1 - f0) {
+        float* yp = ys + (c0 + 4 * half) * YP + f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) yp[((q & 3) + 8 * (q >> 2)) * YP] = acc[q];
+      }
+    }
+  }
+  __syncthreads();
+  float* yb = y + (size_t)b * C * PW + f0;
+  if (f1 - f0 == CH) {
+    for (int c = wave; c < C; c += nwave) st4(yb + (size_t)c * PW + 4 * lane, ld4(ys + c * YP + 4 * lane));
+  } else {
+    for (int c = wave; c < C; c += nwave)
+      for (int o = lane; o < f1 - f0; o += 64) yb[(size_t)c * PW + o] = ys[c * YP + o];
+  }
+}
+
 // dbias[c] partials: sum over (b, pixels) of dy (B, C, PW) -> part[blk][c]
 __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ dy, float* __restrict__ part, int B,
                                                       int C, int PW) {
