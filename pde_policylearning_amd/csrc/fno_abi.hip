@@ -695,6 +695,7 @@ struct FnoModelPlan {
   Geom g;
   Tables t;
   int NPX;      // pixels per workgroup tile (128 or 256)
+  bool loose;   // rows do not tile the pixel tile (last dim not a multiple of 32): block stacks only, separate row-DFT passes
   int ncu;      // compute units of the device the plan was made on
 };
 
@@ -739,7 +740,15 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
   int rc = make_geom(p->g, d->ndim, d->dims, d->modes, 0, d->norm);
   if (rc == FNO_OK) {
     const int W = p->g.W;
-    if (W % 32 != 0 || W > 256) rc = fail(FNO_EUNSUPPORTED, "fused path needs last dim %% 32 == 0 and <= 256 (got %d)", W);
+    p->loose = false;
+    static const int no_loose = getenv("FNO_NO_LOOSE") ? 1 : 0;      // A/B switch: loose-row stacks fall back to the chained layers
+    if (!no_loose && W % 32 != 0 && W >= 32 && W <= 320 && d->Cin == 0 && d->Cout == 0 && p->g.PW % 128 == 0 && p->g.Klast <= 32) {
+      // "loose rows" (e.g. the PINO observers' padded time axis, 73): 128-pixel tiles of the flattened plane; the block
+      // kernels take the spectral rows that overlap their tile (kext_loose_rows) and the last-dim forward transforms
+      // run as separate lanes-as-channels passes instead of kernel epilogues.  Block stacks only.
+      p->loose = true;
+      p->NPX = 128;
+    } else if (W % 32 != 0 || W > 256) rc = fail(FNO_EUNSUPPORTED, "fused path needs last dim %% 32 == 0 and <= 256 (got %d)", W);
     else {
       p->NPX = W > 128 ? 256 : 128;
       if (p->NPX % W != 0 || p->g.PW % p->NPX != 0)
@@ -751,9 +760,9 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
       // kept last-dim modes do not: such shapes take the unfused composition)
       const Geom& g = p->g;
       const int npx = p->NPX, C = d->C;
-      const size_t tz = ((size_t)2 * g.Klast * g.W + (size_t)(npx / g.W) * g.Klast * C * 2) * 4;   // inverse table + Z rows
+      const size_t tz = ((size_t)2 * g.Klast * g.W + (size_t)(npx / g.W + (p->loose ? 2 : 0)) * g.Klast * C * 2) * 4;   // inverse table + Z rows
       const size_t tf = (size_t)16 * g.NJ * (g.W + 4) * 4;                                          // forward table
-      const bool many = d->n_layers > 1;                   // blocks above 0 also carry the forward table
+      const bool many = d->n_layers > 1 && !p->loose;      // blocks above 0 also carry the forward table
       const size_t xin = d->Cin > 0 ? (size_t)8 * (npx + 4) * 4 : 0;                                // block 0: lifting rows
       const size_t bbwd_f32 = (size_t)2 * C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
       const size_t bbwd_x3 = (size_t)6 * C * (npx + 8) * 2 + (size_t)C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
@@ -872,13 +881,18 @@ static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const Pw
 }
 template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
-  const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
+  const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
+                     (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
+  if (p->loose)
+    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+                  lds, st, a);
   if (p->NPX == 128)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
 }
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  if (p->loose && !g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
   if (g_gemm_x3) return p->d.C == 32 ? launch_block_x3<32>(p, st, grid, a) : launch_block_x3<64>(p, st, grid, a);
   if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a, "k_pw_fwd_block");
   return launch_pw<64, 64>(p, st, grid, a, "k_pw_fwd_block");
@@ -892,6 +906,11 @@ static size_t bbwd_x3_lds(int C, int npx, const BlkBwdArgs& a) {
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   const size_t pitch = p->NPX + 4;
+  if (p->loose) {
+    if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
+    const size_t ldsl = bbwd_x3_lds(C, 128, a) + (a.zg ? (size_t)2 * a.K2in * C * 2 * 4 : 0);
+    return launch("k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, a);
+  }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
     return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
@@ -1003,6 +1022,9 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
   }
 
   for (int l = 0; l < L; ++l) {
+    if (p->loose && l > 0)     // no row-DFT epilogue on loose rows: transform act(u_l) in its own pass
+      LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, u + (size_t)l * s.n_act, w.x1,
+                            (int)((d.gelu_mask >> (l - 1)) & 1u)));
     LAUNCHCHK(spectral_mid_fwd(p, st, B, w, wps + (size_t)l * s.n_wp, hats + (size_t)l * s.n_hat));
     memset(&a, 0, sizeof(a));
     a.x = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act;
@@ -1010,7 +1032,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.bias = prm->spec_bias ? prm->spec_bias + (size_t)l * C : nullptr;
     a.z = w.z; a.tinv = p->t.tinv_f;
     a.u = (l == L - 1 && !has_proj) ? y : u + (size_t)(l + 1) * s.n_act;
-    a.x1 = (l + 1 < L) ? w.x1 : nullptr;
+    a.x1 = (l + 1 < L && !p->loose) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
@@ -1119,7 +1141,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     a.g = gcur; a.uin = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act; a.w = prm->skip_w[l];
     a.zg = w.z; a.tinv = p->t.tinv_b;
     a.gout = (l > 0) ? gnext : (has_lift ? nullptr : dx);
-    a.x1g = (l > 0) ? w.x1 : nullptr;
+    a.x1g = (l > 0 && !p->loose) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_l; a.db_part = db_part_l;
     a.xin = (l == 0 && has_lift) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
@@ -1127,6 +1149,8 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
+    if (p->loose && l > 0)     // the running gradient's row spectrum for the next (lower) block, in its own pass
+      LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, gnext, w.x1));
     jobs.add(dw_part_l, gr->skip_w[l], s.grid * ks, C, C, C, C);
     if (gr->spec_bias) jobs.add(db_part_l, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C);
     if (l == 0 && has_lift) {

@@ -225,6 +225,33 @@ struct SplitTilePrefetch {
   }
 };
 
+// Spectral K-extension for rows that do not tile the workgroup's pixel tile ("loose rows": odd row lengths such as the
+// PINO observers' padded T axis, W >= 32): acc[c][px] += sum_s Z[row(px)][s][c] . T[s][w(px)] for one 32-pixel block that
+// starts at flattened plane index f.  A block overlaps at most two rows; each gets its own pass with the table column
+// masked to the lanes (pixels) that belong to it.  zs = [rows of the tile][K2][C][2] from row r_lo, tinv_s = [2 K2][W].
+template <int C>
+FNO_DEV f32x16 kext_loose_rows(f32x16 acc, const float* zs, const float* tinv_s, int K2, int W, int f, int r_lo, int mt,
+                               int l31, int half) {
+  const int ra = f / W;
+  const int w0 = f - ra * W;                 // wave-uniform: position of the block's first pixel in its row
+  const int wl = w0 + l31;
+  {
+    const float* zr = zs + ((size_t)((ra - r_lo) * K2) * C + mt * 32 + l31) * 2 + half;
+    const bool in = wl < W;
+    const float* tv = tinv_s + half * W + (in ? wl : 0);
+#pragma unroll 2
+    for (int s = 0; s < K2; ++s) acc = mfma32(zr[s * C * 2], in ? tv[2 * s * W] : 0.f, acc);
+  }
+  if (w0 + 31 >= W) {
+    const float* zr = zs + ((size_t)((ra + 1 - r_lo) * K2) * C + mt * 32 + l31) * 2 + half;
+    const bool in = wl >= W;
+    const float* tv = tinv_s + half * W + (in ? wl - W : 0);
+#pragma unroll 2
+    for (int s = 0; s < K2; ++s) acc = mfma32(zr[s * C * 2], in ? tv[2 * s * W] : 0.f, acc);
+  }
+  return acc;
+}
+
 FNO_DEV float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 FNO_DEV void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -39,6 +39,7 @@ struct BlkBwdArgs {
   int CL;
   int PW, W, P, K2in, K2out, NJ;
   int act_in;
+  int loose;           // rows do not tile the pixel tile (see PwFwdArgs.loose); k_block_bwd_x3 only
   int tiles_per_plane, ntiles;
 };
 
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 //   R3   fp32 C x PITCH: g as loaded (for dbias and the pixel-major split pass), later the gout tile
 // Per tile:  commit (GELU, row-major splits) | dW GEMM + dbias | split pass + dg | dx GEMM, x gelu',
 // gout store | row DFT / lifting gradients - five barriers, as in the fp32 kernel.
-template <int C, int NPX>
+template <int C, int NPX, bool LOOSE = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_block_bwd_x3(BlkBwdArgs a) {
   using Cfg = BlkBwdCfg<C, NPX>;
   constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   float* r3 = reinterpret_cast<float*>(gr + 6 * RTERM);              // C x PITCH fp32
   float* xls = r3 + C * PITCH;
   float* tinv_s = xls + (a.xin ? 8 * PITCH : 0);
-  const int R = NPX / a.W;
+  const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
   float* zs = tinv_s + (a.zg ? 2 * a.K2in * a.W : 0);
   float* tfwd_s = zs + (a.zg ? R * a.K2in * C * 2 : 0);
 
@@ -307,7 +308,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1g)
     for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
-  const int zcount4 = a.zg ? R * a.K2in * C / 2 : 0;
+  auto zc4 = [&](int px0) {
+    const int nrows = LOOSE ? (px0 + NPX - 1) / a.W - px0 / a.W + 1 : R;
+    return a.zg ? nrows * a.K2in * C / 2 : 0;
+  };
 
   // A fragments of W^T: A[i][k = o] = W[o][i], split into (h, m, l)
   bf16x8 afrag[KB][3];
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, tid);
     pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
-    if (tid < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+    if (tid < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
   auto put_row4 = [&](unsigned short* img, int c, int q, const float4& t) {   // 4 pixels of row c -> 3 terms
@@ -374,6 +378,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       }
       put_row4(ar, c, q, uv);
     }
+    const int zcount4 = zc4(px0);
     if (tid < zcount4) st4(zs + 4 * tid, zv);
     for (int i = tid + NT; i < zcount4; i += NT)      // more spectral rows than threads (short rows, many modes)
       st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
@@ -447,7 +452,9 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
         acc = mfma_x3(afrag[kb], bf, acc);
       }
     }
-    if (a.zg) {
+    if constexpr (LOOSE) {
+      if (a.zg) acc = kext_loose_rows<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
+    } else if (a.zg) {
       const float* zr = zs + (((n0 / a.W) * a.K2in) * C + mt * 32 + l31) * 2 + half;
       const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
 #pragma unroll 2

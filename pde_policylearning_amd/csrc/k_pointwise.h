@@ -43,6 +43,7 @@ struct PwFwdArgs {
   const float* add;   // (B, COUT, PW) tensor added to the output before it is stored, or null
   int PW, W, P, K2in, K2out, NJ;
   int act_in, act_out;
+  int loose;          // rows do not tile the pixel tile (W >= 32, any remainder): spectral rows per tile vary, no x1 epilogue
   int tiles_per_plane, ntiles;
 };
 
@@ -222,7 +223,7 @@ static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ
 // NTW = 32-pixel column tiles per wave.  NTW = 2 halves the workgroup (4 waves at C = 64, NPX = 128)
 // so that TWO workgroups share a CU at the same 256-VGPR budget per wave: their phases (split /
 // MFMA / epilogue / row DFT) drift apart and the matrix pipe of one overlaps the VALU work of the other.
-template <int C, int NPX, int NTW>
+template <int C, int NPX, int NTW, bool LOOSE = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;
   constexpr int NTG = NTN / NTW;          // wave groups along the pixel dimension
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
   unsigned short* xb = reinterpret_cast<unsigned short*>(smem);     // 3 x NPX x (C+8) halfs ...
   float* xs = smem;                                                  // ... reused as the C x PITCH fp32 output tile
   float* tinv_s = smem + REGION / 4;
-  const int R = NPX / a.W;
+  const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
   float* zs = tinv_s + (a.z ? 2 * a.K2in * a.W : 0);
   float* tfwd_s = zs + (a.z ? R * a.K2in * C * 2 : 0);
 
@@ -262,14 +263,18 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     split3x8(v, afrag[kb][0], afrag[kb][1], afrag[kb][2]);
   }
 
-  const int zcount4 = a.z ? R * a.K2in * C / 2 : 0;
+  // float4s of spectral rows a tile needs: R rows when rows tile it, else the rows that overlap [px0, px0 + NPX)
+  auto zc4 = [&](int px0) {
+    const int nrows = LOOSE ? (px0 + NPX - 1) / a.W - px0 / a.W + 1 : R;
+    return a.z ? nrows * a.K2in * C / 2 : 0;
+  };
   PF pf;
   float4 zpf = make_float4(0.f, 0.f, 0.f, 0.f);
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, tid);
-    if (tid < zcount4) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+    if (tid < zc4(px0)) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
@@ -280,6 +285,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
     pf.commit(xb, a.act_in != 0, tid);
+    const int zcount4 = zc4(px0);
     if (tid < zcount4) st4(zs + 4 * tid, zpf);
     for (int i = tid + NT; i < zcount4; i += NT)   // rare tail (small workgroups): straight from L2
       st4(zs + 4 * i, ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
@@ -301,7 +307,9 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
         for (int t = 0; t < 3; ++t) bf[t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
         acc[q] = mfma_x3(afrag[kb], bf, acc[q]);
       }
-      if (a.z) {
+      if constexpr (LOOSE) {
+        if (a.z) acc[q] = kext_loose_rows<C>(acc[q], zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
+      } else if (a.z) {
         const int rr = n0 / a.W;
         const float* zr = zs + ((rr * a.K2in) * C + mt * 32 + l31) * 2 + half;
         const float* tv = tinv_s + half * a.W + n0 % a.W + l31;

@@ -365,7 +365,8 @@ class _FNOBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, bias, *rest):
-        n_layers, modes, norm, gelu_mask = cfg
+        n_layers, modes, norm, gelu_mask, direct = cfg
+        ctx.direct = direct
         _require_cuda(x, "x")
         x = x.contiguous()
         dims = tuple(x.shape[2:])
@@ -409,7 +410,7 @@ class _FNOBlocksFn(torch.autograd.Function):
         L = _lib.lib()
         prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
         g_skip = [torch.empty_like(t) for t in skip_ws]
-        g_spec = [torch.empty_like(t) for t in spec_ws]
+        g_spec = ctx.direct if ctx.direct is not None else [torch.empty_like(t) for t in spec_ws]   # direct: the weights' own .grad storage
         g_sb = torch.empty_like(sb) if sb is not None else None
         for l in range(nl):
             prm.skip_w[l], grd.skip_w[l] = skip_ws[l].data_ptr(), g_skip[l].data_ptr()
@@ -423,7 +424,7 @@ class _FNOBlocksFn(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
                                                C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "blocks_backward")
-        return (None, dx, g_sb) + tuple(g_skip) + tuple(g_spec)
+        return (None, dx, g_sb) + tuple(g_skip) + ((None,) * len(g_spec) if ctx.direct is not None else tuple(g_spec))
 
 
 def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
@@ -437,7 +438,11 @@ def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
     for s in x.shape[2:]:
         pw *= s
     npx = 256 if w > 128 else 128
-    if not (c in (32, 64) and w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0 and n_layers <= _lib.FNO_MAX_LAYERS):
+    tiled = w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0
+    # "loose rows" (any last dim in 32..320 that is not a multiple of 32, e.g. the PINO observers' padded time axis):
+    # 128-pixel tiles of the flattened plane, spectral rows gathered per tile (split-precision GEMM mode only)
+    loose = w % 32 != 0 and 32 <= w <= 320 and pw % 128 == 0 and _lib.lib().fno_get_gemm_mode() == 1
+    if not (c in (32, 64) and (tiled or loose) and n_layers <= _lib.FNO_MAX_LAYERS):
         return False
     if modes is None:
         return True
@@ -445,13 +450,17 @@ def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
                                 int(gelu_mask), x.device)
 
 
-def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0):
+def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0, direct_grads=False):
     """Stack of fused Fourier layers (include/fnoengine.h, block stacks): per layer one spectral
     convolution (corner weights `spec_ws`, layer-major, real view (C, C, m.., 2)), one 1x1 convolution
     (`skip_ws[l]`, (C, C) or (C, C, 1..)) and one bias row of `bias` (L, C); GELU after layer l iff bit l
     of `gelu_mask`.  Returns (B, C, ...); differentiable w.r.t. x and every parameter."""
-    cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask))
-    return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *spec_ws)
+    sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_ws]
+    direct = None       # direct_grads: backward WRITES dL/dW of the spectral weights into their existing .grad storage
+    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws):
+        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
+    cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
+    return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *sw)
 
 
 # ----------------------------------------------------------------------------

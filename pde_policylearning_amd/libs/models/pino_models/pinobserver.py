@@ -82,7 +82,30 @@ class _SpectralStack(nn.Module):
                 return False
         return True
 
+    def _fused_stack(self, x):
+        """The whole stack as ONE engine block stack (fno_model_* with Cin = Cout = 0: per layer one fused kernel each way that
+        applies the previous GELU on load, mixes the channels, adds the inverse last-dim transform of the spectral branch
+        as a K-extension of the same GEMM and the bias; no `SpectralConv(x)` tensor, no addend / gradient-addend passes)
+        when every layer has the same width and kept modes and the weights store exactly the live last-dim modes."""
+        if self.act is not TF.gelu or len(set(self.layers)) != 1:
+            return None
+        calls = [conv.engine_call(x) for conv in self.sp_convs]
+        modes = calls[0][1]
+        if any(c[1] != modes or c[2] != modes[-1] for c in calls):
+            return None
+        n = len(self.ws)
+        gelu_mask = (1 << (n - 1)) - 1                       # GELU after every layer but the last
+        if not F.blocks_supported(x, n, modes, "backward", gelu_mask):
+            return None
+        bias = torch.stack([w.bias for w in self.ws])
+        direct = all(getattr(conv, "_direct_grads", False) for conv in self.sp_convs)
+        return F.fno_blocks(x, [w.weight for w in self.ws], [t for c in calls for t in c[0]], bias, modes, "backward",
+                            gelu_mask=gelu_mask, direct_grads=direct)
+
     def _run_stack(self, x):
+        y = self._fused_stack(x)
+        if y is not None:
+            return y
         if self._chain_supported(x):
             # the stack chained on PRE-activation tensors: each layer applies the previous layer's GELU while it loads its
             # input (spectral rows and channel mix alike) and its backward folds gelu' and the two-branch gradient sum in

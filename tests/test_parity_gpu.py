@@ -922,6 +922,45 @@ def test_block_stack_3d_vs_oracle(dev):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, (a.shape,)
 
 
+@pytest.mark.parametrize("C,dims,modes,L", [(64, (16, 8, 73), (3, 4, 8), 3), (32, (8, 16, 40), (2, 3, 5), 2), (64, (128, 33), (6, 7), 2)])
+def test_block_stack_loose_rows_vs_oracle(dev, C, dims, modes, L):
+    """Fused block stacks on rows that do not tile the 128-pixel workgroup tile (last dim 73 / 40 / 33: the spectral
+    K-extension gathers the one or two rows every 32-pixel block overlaps, the last-dim forward transforms run as separate
+    passes) against the CPU oracle: dialect C (norm 'backward'), GELU between the layers, output, input gradient and every
+    parameter gradient."""
+    from pde_policylearning_amd import functional as F
+    nd = len(dims)
+    nc = 2 ** (nd - 1)
+    B = 2
+    shape = (B, C) + dims
+    x = torch.from_numpy(fill_named("lr.x", shape, 1.0))
+    dy = torch.from_numpy(fill_named("lr.dy", shape, 1.0))
+    skip = [torch.from_numpy(fill_named(f"lr.s{l}", (C, C, 1), 0.12)) for l in range(L)]
+    bias = torch.from_numpy(fill_named("lr.b", (L, C), 0.1))
+    spec = [torch.from_numpy(fill_named(f"lr.w{i}", (C, C) + tuple(modes) + (2,), 0.03)) for i in range(L * nc)]
+    leaves = [t.clone().requires_grad_(True) for t in [x] + skip + spec + [bias]]
+    xo, so, wo, bo = leaves[0], leaves[1:1 + L], leaves[1 + L:1 + L + L * nc], leaves[-1]
+    h = xo
+    for l in range(L):
+        wc = [torch.view_as_complex(w) for w in wo[l * nc:(l + 1) * nc]]
+        if nd == 3:
+            sp = O.spectral_conv_C3d(h, wc[0], wc[2], wc[1], wc[3], *modes)       # oracle takes the reference's corner order
+        else:
+            sp = O.spectral_conv_C2d(h, *wc, *modes)
+        h = sp + O.conv1x1(h, so[l].view(C, C, *([1] * nd)), bo[l])
+        if l < L - 1:
+            h = torch.nn.functional.gelu(h)
+    h.backward(dy)
+    dl = [t.detach().clone().to(dev).requires_grad_(True) for t in leaves]
+    assert F.blocks_supported(dl[0], L, modes, "backward", (1 << (L - 1)) - 1)
+    ye = F.fno_blocks(dl[0], dl[1:1 + L], dl[1 + L:1 + L + L * nc], dl[-1], modes, "backward", gelu_mask=(1 << (L - 1)) - 1)
+    assert rel_l2(_cpu(ye), h.detach().numpy()) < TOL_Y
+    ye.backward(dy.to(dev))
+    for a, b in zip(dl, leaves):
+        assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, tuple(a.shape)
+    assert rel_l2(_cpu(dl[0].grad), leaves[0].grad.numpy()) < TOL_Y
+
+
 @pytest.mark.parametrize("C,shape", [(64, (2, 64, 8, 16, 73)), (32, (3, 32, 4, 96))])
 def test_pointwise_conv_add_vs_torch(dev, C, shape):
     """fno_pointwise_* (Conv1d(k=1) + bias + residual add, pinobserver.py:221-226) vs the torch ops, odd row lengths."""
@@ -1367,17 +1406,27 @@ def test_pino_stack_chained_on_preactivations(dev, dims, width, modes):
     x = torch.randn((2, width) + dims, device=dev, requires_grad=True)
     dy = torch.randn((2, width) + dims, device=dev)
     assert head._chain_supported(x)
-    y1 = head._run_stack(x)
-    y1.backward(dy)
-    g1 = [x.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
-    x.grad = None
-    head.zero_grad(set_to_none=True)
-    head._chain_supported = lambda t: False
-    y2 = head._run_stack(x)
-    y2.backward(dy)
-    g2 = [x.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
-    assert rel_l2(_cpu(y1), _cpu(y2)) < 1e-5
-    assert len(g1) == len(g2) == 1 + 4 * 4 + 4 * 2
-    for a, b in zip(g1, g2):
-        a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
-        assert float((a - b).norm()) <= 2e-5 * float(b.norm()), tuple(a.shape)
+    # rows of 73 floats (the padded time axis of configs/pino-observer-finetune-1s.yaml) also take the ONE-block-stack path
+    # (fno_model_* on "loose rows": spectral rows gathered per 128-pixel tile); all three routes must agree
+    with torch.no_grad():
+        fused_available = head._fused_stack(x) is not None
+    assert fused_available == (dims[-1] == 73)
+    res = {}
+    for route in ("default", "chain", "unfused"):
+        x.grad = None
+        head.zero_grad(set_to_none=True)
+        if route != "default":
+            head._fused_stack = lambda t: None
+        if route == "unfused":
+            head._chain_supported = lambda t: False
+        y = head._run_stack(x)
+        y.backward(dy)
+        res[route] = (y.detach(), [x.grad.clone()] + [p.grad.clone() for p in head.parameters() if p.grad is not None])
+    y2, g2 = res["unfused"]
+    for route in ("default", "chain"):
+        y1, g1 = res[route]
+        assert rel_l2(_cpu(y1), _cpu(y2)) < 1e-5, route
+        assert len(g1) == len(g2) == 1 + 4 * 4 + 4 * 2
+        for a, b in zip(g1, g2):
+            a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
+            assert float((a - b).norm()) <= 2e-5 * float(b.norm()), (route, tuple(a.shape))
