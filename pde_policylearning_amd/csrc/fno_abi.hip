@@ -768,7 +768,9 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
       const size_t bbwd_x3 = (size_t)6 * C * (npx + 8) * 2 + (size_t)C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
       const size_t bbwd = (npx == 128 && bbwd_x3 <= 160 * 1024) ? bbwd_x3 : bbwd_f32;
       const size_t pwx3 = (size_t)3 * npx * (C + 8) * 2 + tz + (many ? tf : 0), pwf32 = (size_t)C * (npx + 4) * 4 + tz + (many ? tf : 0);
-      if (bbwd > 160 * 1024 || pwx3 > 160 * 1024 || pwf32 > 160 * 1024)
+      if (p->loose && bbwd_x3 > 160 * 1024)      // loose rows exist for the split-precision kernels only
+        rc = fail(FNO_EUNSUPPORTED, "loose-row tile of %d channels with %d kept last-dim modes exceeds LDS", C, g.Klast);
+      else if (bbwd > 160 * 1024 || pwx3 > 160 * 1024 || pwf32 > 160 * 1024)
         rc = fail(FNO_EUNSUPPORTED, "tile of %d pixels x %d channels with %d kept last-dim modes exceeds LDS", npx, C,
                   g.Klast);
     }

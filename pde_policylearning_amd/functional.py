@@ -840,6 +840,129 @@ def pointwise_conv_add(x, w, bias=None, addend=None):
     return _PointwiseAddFn.apply(x, w, bias, addend)
 
 
+class _PointwisePerSampleFn(torch.autograd.Function):
+    """y[b] = conv1x1(x[b]; w) + bias[b]: the channel mix with a PER-SAMPLE bias row (B, C) - the Re-conditioning affine
+    `B x + A re + bias` of the PINO observers (pinobserver.py:41-59), whose per-sample code `A re` would otherwise cost a
+    broadcast-add pass over the whole tensor (and a reduction pass in backward).  One fno_pointwise_* call per sample."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_cuda(x, "x")
+        x = x.contiguous()
+        B, Cc = x.shape[0], x.shape[1]
+        pw = x.numel() // (B * Cc)
+        w2 = w.reshape(Cc, Cc).contiguous()
+        bc = bias.contiguous()
+        y = torch.empty_like(x)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            for b in range(B):
+                _lib.check(L.fno_pointwise_forward(1, Cc, pw, _ptr(x[b]), _ptr(w2), _ptr(bc[b]), None, 0, _ptr(y[b]), _stream()),
+                           "pointwise_forward")
+        ctx.save_for_backward(x, w2)
+        ctx.meta = (B, Cc, pw, w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        B, Cc, pw, wshape = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dws = torch.empty((B, Cc, Cc), dtype=torch.float32, device=x.device)
+        dbs = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        nws = L.fno_pointwise_workspace_bytes(Cc)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            for b in range(B):
+                _lib.check(L.fno_pointwise_backward(1, Cc, pw, _ptr(x[b]), _ptr(w2), _ptr(dy[b]), None, 0,
+                                                    _ptr(dx[b]) if dx is not None else None, _ptr(dws[b]), _ptr(dbs[b]), _ptr(ws), nws,
+                                                    _stream()), "pointwise_backward")
+        return dx, dws.sum(0).view(wshape), dbs
+
+
+def pointwise_conv_per_sample_bias(x, w, bias):
+    """y[b] = conv1x1(x[b]; w) + bias[b] with bias (B, C); x (B, C, ...), C in {32, 64}."""
+    return _PointwisePerSampleFn.apply(x, w, bias)
+
+
+class _LiftingPerSampleFn(torch.autograd.Function):
+    """lifting with a per-sample bias row (B, C): one fno_lifting_* call per sample (see _PointwisePerSampleFn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_cuda(x, "x")
+        if x.requires_grad:
+            raise RuntimeError("fnoengine lifting: the input field is data (no gradient is produced for it)")
+        x = x.contiguous()
+        B, cin = x.shape[0], x.shape[1]
+        cout = w.shape[0]
+        pw = x.numel() // (B * cin)
+        wc = w.reshape(cout, cin).contiguous()
+        bc = bias.contiguous()
+        y = torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            for b in range(B):
+                _lib.check(L.fno_lifting_forward(1, cin, cout, pw, _ptr(x[b]), _ptr(wc), _ptr(bc[b]), _ptr(y[b]), _stream()),
+                           "lifting_forward")
+        ctx.save_for_backward(x)
+        ctx.meta = (B, cin, cout, pw, w.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, cin, cout, pw, wshape = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dws = torch.empty((B, cout, cin), dtype=torch.float32, device=x.device)
+        dbs = torch.empty((B, cout), dtype=torch.float32, device=x.device)
+        nws = L.fno_lifting_workspace_bytes(cout)
+        ws = _bytes(nws, x.device)
+        with torch.cuda.device(x.device):
+            for b in range(B):
+                _lib.check(L.fno_lifting_backward(1, cin, cout, pw, _ptr(x[b]), _ptr(dy[b]), _ptr(dws[b]), _ptr(dbs[b]), _ptr(ws), nws,
+                                                  _stream()), "lifting_backward")
+        return None, dws.sum(0).view(wshape), dbs
+
+
+def lifting_per_sample_bias(x, w, bias):
+    """y[b] = conv1x1(x[b]; w) + bias[b]: x (B, Cin <= 4, ...) data, w (C, Cin), bias (B, C)."""
+    return _LiftingPerSampleFn.apply(x, w, bias)
+
+
+class _ZeroLastPadsFn(torch.autograd.Function):
+    """Zero the first p0 and last p1 entries of the last dimension IN PLACE, forward and backward: makes a tensor that was
+    computed on a zero-padded INPUT equal to the zero-padded tensor the reference builds with F.pad after the fact
+    (pinobserver.py:208-213), without the pad copy (forward) or the slice copy (backward)."""
+
+    @staticmethod
+    def forward(ctx, y, p0, p1):
+        ctx.pads = (p0, p1)
+        ctx.mark_dirty(y)
+        if p0 > 0:
+            y[..., :p0].zero_()
+        if p1 > 0:
+            y[..., y.shape[-1] - p1:].zero_()
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p0, p1 = ctx.pads
+        g = g.contiguous()          # the block stack's input gradient: a fresh tensor with no other consumer
+        if p0 > 0:
+            g[..., :p0].zero_()
+        if p1 > 0:
+            g[..., g.shape[-1] - p1:].zero_()
+        return g, None, None
+
+
+def zero_last_pads_(y, p0, p1):
+    return _ZeroLastPadsFn.apply(y, int(p0), int(p1))
+
+
 # ----------------------------------------------------------------------------
 # one layer of the observer stacks:  y = SpectralConv(a) + Conv1d_{k=1}(a) + bias,  a = gelu(u) or u
 # ----------------------------------------------------------------------------

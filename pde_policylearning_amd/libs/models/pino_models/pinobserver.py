@@ -157,6 +157,9 @@ class PINObserver2d(_SpectralStack):
         re = re.float()
         size_z = x.shape[-2]
         num_pad = [round(size_z * r) for r in self.pad_ratio] if max(self.pad_ratio) > 0 else [0., 0.]
+        y = self._forward_padded(x, re, [int(p) for p in num_pad])
+        if y is not None:
+            return y
         x = _lift_front(self.fc0, self.multiplicative_net1, x, re, self.layers[0])
         x = _unpad_last(self._run_stack(_pad_last(x, num_pad).contiguous()), num_pad)
         if (self.act is TF.gelu and self.layers[-1] in (32, 64)
@@ -169,6 +172,39 @@ class PINObserver2d(_SpectralStack):
             return y.permute(0, 2, 3, 4, 1)
         x = self.multiplicative_net2(x.permute(0, 2, 3, 4, 1), re)
         return self.fc2(self.act(self.fc1(x)))
+
+
+    PER_SAMPLE_MAX = 16      # the per-sample-bias kernels are launched once per sample
+
+    def _forward_padded(self, x, re, num_pad):
+        """The whole forward on the PADDED grid, channels-first, with no layout or padding copies of the 64-channel tensors:
+        the in_dim-channel INPUT is padded (C / in_dim times cheaper), lifted per sample with the Re-conditioning code folded
+        into the bias, and the pad columns are zeroed in place (= F.pad of the lifted tensor, pinobserver.py:208-213); the
+        tail (second Re-conditioning affine with its code as a per-sample bias, fc1 -> GELU -> fc2) runs on the padded tensor
+        too - it is pointwise, the pad columns are dropped from the 1-channel output (:228).  None when the engine's
+        lifting / pointwise / projection kernels do not cover the shape."""
+        B = x.shape[0]
+        if (x.requires_grad or self.act is not TF.gelu or len(set(self.layers)) != 1 or self.layers[0] not in (32, 64)
+                or B > self.PER_SAMPLE_MAX or self.fc2.out_features != 1):
+            return None
+        p0, p1 = num_pad
+        xc = TF.pad(x.permute(0, 4, 1, 2, 3), (p0, p1)) if p0 + p1 > 0 else x.permute(0, 4, 1, 2, 3).contiguous()
+        C = self.layers[0]
+        like = xc[:, :1].expand(-1, C, -1, -1, -1)          # a (B, C, X, Y, T') view for the shape predicates (no memory)
+        if not (F.lifting_supported(xc, C) and F.pointwise_supported(like)
+                and F.projection_supported(like, self.fc1.out_features, self.fc2.out_features)):
+            return None
+        fc0, mn1, mn2 = self.fc0, self.multiplicative_net1, self.multiplicative_net2
+        re2 = re if re.dim() >= 2 else re.unsqueeze(-1)
+        w = mn1.B @ fc0.weight                                             # (C, in_dim): fc0 then the Re-conditioning mix
+        bias = (mn1.B @ fc0.bias + mn1.bias)[None, :] + re2 @ mn1.A.t()    # (B, C): + the per-sample code
+        h = F.zero_last_pads_(F.lifting_per_sample_bias(xc, w, bias), p0, p1)
+        h = self._run_stack(h)
+        h = F.pointwise_conv_per_sample_bias(h, mn2.B, mn2.bias[None, :] + re2 @ mn2.A.t())
+        y = F.projection_head(h, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        if p0 + p1 > 0:
+            y = y[..., p0:y.shape[-1] - p1]
+        return y.permute(0, 2, 3, 4, 1)
 
 
 class PlanePredHead(_SpectralStack):
