@@ -163,8 +163,10 @@ int fno_model_backward_part(const FnoModelPlan* plan, int batch, const FnoModelP
  * the members through the block kernel's gradient-addend input (no accumulation pass, no n_out separate dx tensors).
  * `plan` is a block-stack plan (Cin = Cout = 0, gelu_mask = 0) created with n_layers >= n_out; members occupy layer slots
  * 0..n_out-1 of FnoModelParams / FnoModelGrads (skip_w, spec_w only), biases are separate (C) arrays (entries / the
- * array itself nullable).  Workspace: fno_model_workspace_bytes(plan, batch); stash: fno_fanout_saved_bytes. */
+ * array itself nullable).  The members' mode contractions and leading-axis passes run as ONE launch each (member-major
+ * buffers, member index on the contraction grid).  Workspace: fno_fanout_workspace_bytes; stash: fno_fanout_saved_bytes. */
 size_t fno_fanout_saved_bytes(const FnoModelPlan* plan, int batch, int n_out);
+size_t fno_fanout_workspace_bytes(const FnoModelPlan* plan, int batch, int n_out);
 int fno_fanout_forward(const FnoModelPlan* plan, int batch, int n_out, const FnoModelParams* p, const float* const* bias,
                        const float* x, float* const* y, void* saved, void* ws, size_t ws_bytes, void* stream);
 int fno_fanout_backward(const FnoModelPlan* plan, int batch, int n_out, const FnoModelParams* p, const float* x,

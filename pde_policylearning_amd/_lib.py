@@ -87,6 +87,8 @@ def lib():
                                      C.POINTER(FnoModelGrads), vp, sz, vp]
     L.fno_fanout_saved_bytes.argtypes = [vp, ci, ci]
     L.fno_fanout_saved_bytes.restype = sz
+    L.fno_fanout_workspace_bytes.argtypes = [vp, ci, ci]
+    L.fno_fanout_workspace_bytes.restype = sz
     L.fno_fanout_forward.argtypes = [vp, ci, ci, C.POINTER(FnoModelParams), C.POINTER(vp), vp, C.POINTER(vp), vp, vp, sz, vp]
     L.fno_fanout_backward.argtypes = [vp, ci, ci, C.POINTER(FnoModelParams), vp, C.POINTER(vp), vp,
                                       C.POINTER(FnoModelGrads), C.POINTER(vp), vp, vp, sz, vp]
@@ -154,7 +156,7 @@ EXPORTED_SYMBOLS = [
     "fno_spec_forward", "fno_spec_backward",
     "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",
     "fno_model_forward", "fno_model_backward", "fno_model_backward_dx", "fno_model_backward_part",
-    "fno_fanout_saved_bytes", "fno_fanout_forward", "fno_fanout_backward",
+    "fno_fanout_saved_bytes", "fno_fanout_workspace_bytes", "fno_fanout_forward", "fno_fanout_backward",
     "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
     "fno_pointwise_workspace_bytes", "fno_pointwise_forward", "fno_pointwise_backward",
     "fno_projection_workspace_bytes", "fno_projection_forward", "fno_projection_backward",

@@ -335,18 +335,24 @@ static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, i
   return axis_pass(st, false, tmp, z, t.tw_inv[1], B * g.dims[0], g.Klead[1], g.dims[1], g.Klast * C);
 }
 
+// nm > 1: nm independent contractions in one launch (fan-out members); *_ms = member strides in floats (0 = shared operand).
+// Only the matrix-core kernels take members; callers check mode_gemm_members_ok() first.
+static bool mode_gemm_members_ok(int Cin, int Cout) {
+  return g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64);
+}
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
-                     int conj_w) {
+                     int conj_w, int nm = 1, size_t x_ms = 0, size_t w_ms = 0, size_t o_ms = 0) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
-    const dim3 grid(Ktot, (B + 63) / 64), blk(2 * (2 * Cout / 32) * 64);
+    const dim3 grid(Ktot, (B + 63) / 64, nm), blk(2 * (2 * Cout / 32) * 64);
     const size_t lds = ((size_t)64 * (2 * Cin + 1) + (size_t)2 * Cin * (2 * Cout + 32)) * 4;
     const float2 *xx = (const float2*)x, *ww = (const float2*)w;
     float2* oo = (float2*)out;
-    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
-    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
-    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
-    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w);
+    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
+    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
+    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
+    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
@@ -360,17 +366,19 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
   return launch("k_mode_gemm", k_mode_gemm, grid, dim3(256), 0, st, (const float2*)x, (const float2*)w, (float2*)out, B,
                 Ktot, Cin, Cout, conj_w);
 }
-static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout) {
+static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* dw, int B, int Ktot, int Cin, int Cout,
+                        int nm = 1, size_t x_ms = 0, size_t g_ms = 0, size_t d_ms = 0) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
-    const dim3 grid(Ktot), blk((Cin / 32) * (2 * Cout / 32) * 64);
+    const dim3 grid(Ktot, nm), blk((Cin / 32) * (2 * Cout / 32) * 64);
     const size_t lds = ((size_t)64 * 2 * Cin + (size_t)128 * (2 * Cout + 32)) * 4;
     const float2 *xx = (const float2*)x, *gg = (const float2*)g;
     float2* dd = (float2*)dw;
-    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
-    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
-    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
-    return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot);
+    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
+    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
+    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
+    return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int it = 2 * (512 / Cout);                   // 2 input channels per thread
@@ -1198,6 +1206,27 @@ extern "C" size_t fno_fanout_saved_bytes(const FnoModelPlan* p, int B, int n_out
   const ModelSizes s = model_sizes(p, B);
   return (s.n_hat + (size_t)2 * n_out * s.n_wp) * sizeof(float) + 256;
 }
+// member-major copies of the spectral-middle buffers, so that the leading-axis passes and the mode contractions of all
+// members run as ONE launch each (outer dimension n_out * B; member index on the contraction grid)
+struct FanWs { float *x1, *z, *ohat, *hat2, *tmp; size_t total; bool ok; };
+static FanWs carve_fanout(const FnoModelPlan* p, int B, int n_out, void* ws, size_t cap, size_t base) {
+  const ModelSizes s = model_sizes(p, B);
+  Carver c(ws ? (char*)ws + base : nullptr, cap > base ? cap - base : 0);
+  FanWs f;
+  f.x1 = c.take<float>((size_t)n_out * s.n_x1);
+  f.z = c.take<float>((size_t)n_out * s.n_x1);
+  f.ohat = c.take<float>((size_t)n_out * s.n_hat);
+  f.hat2 = c.take<float>((size_t)n_out * s.n_hat);
+  f.tmp = c.take<float>((size_t)n_out * s.n_tmp);
+  f.total = base + c.off;
+  f.ok = c.ok;
+  return f;
+}
+extern "C" size_t fno_fanout_workspace_bytes(const FnoModelPlan* p, int B, int n_out) {
+  if (!p || B < 1 || n_out < 1) return 0;
+  const size_t base = carve_model(p, B, nullptr, 0, true, nullptr).total;
+  return carve_fanout(p, B, n_out, nullptr, 0, base).total;
+}
 extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const FnoModelParams* prm,
                                   const float* const* bias, const float* x, float* const* y, void* saved, void* ws,
                                   size_t ws_bytes, void* stream) {
@@ -1208,8 +1237,9 @@ extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const
   const int C = p->d.C;
   const ModelSizes s = model_sizes(p, B);
   bool ok;
-  ModelWs w = carve_model(p, B, ws, ws_bytes, false, &ok);
-  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  ModelWs w = carve_model(p, B, ws, ws_bytes, true, &ok);
+  FanWs f = carve_fanout(p, B, n_out, ws, ws_bytes, w.total);
+  if (!ok || !f.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu (fno_fanout_workspace_bytes)", f.total, ws_bytes);
   float* hat = (float*)saved;
   float* wps = hat + s.n_hat;
   float* wpts = wps + (size_t)n_out * s.n_wp;
@@ -1225,14 +1255,23 @@ extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const
   }
   LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));        // the shared truncated spectrum of x
+  const bool batched = n_out > 1 && mode_gemm_members_ok(C, C) && (long)n_out * B * (g.nlead == 2 ? g.dims[0] : 1) <= 65535;
+  if (batched) {      // every member's contraction and leading-axis inverse in one launch each
+    LAUNCHCHK(mode_gemm(st, hat, wps, f.ohat, B, g.Ktot, C, C, 0, n_out, 0, s.n_wp, s.n_hat));
+    LAUNCHCHK(lead_inverse(st, g, p->t, n_out * B, C, f.ohat, f.tmp, f.z));
+  }
   for (int j = 0; j < n_out; ++j) {
     if (!y[j]) return fail(FNO_EINVAL, "fno_fanout_forward: y[%d] is null", j);
-    LAUNCHCHK(mode_gemm(st, hat, wps + (size_t)j * s.n_wp, w.ohat, B, g.Ktot, C, C, 0));
-    LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z));
+    const float* zj = w.z;
+    if (batched) zj = f.z + (size_t)j * s.n_x1;
+    else {
+      LAUNCHCHK(mode_gemm(st, hat, wps + (size_t)j * s.n_wp, w.ohat, B, g.Ktot, C, C, 0));
+      LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z));
+    }
     PwFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = prm->skip_w[j]; a.bias = bias ? bias[j] : nullptr;
-    a.z = w.z; a.tinv = p->t.tinv_f; a.u = y[j]; a.tfwd = p->t.tfwd_f;
+    a.z = zj; a.tinv = p->t.tinv_f; a.u = y[j]; a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
@@ -1250,25 +1289,40 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   const ModelSizes s = model_sizes(p, B);
   bool ok;
   ModelWs w = carve_model(p, B, ws, ws_bytes, true, &ok);
-  if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
+  FanWs f = carve_fanout(p, B, n_out, ws, ws_bytes, w.total);
+  if (!ok || !f.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu (fno_fanout_workspace_bytes)", f.total, ws_bytes);
   const float* hat = (const float*)saved;
   const float* wpts = hat + s.n_hat + (size_t)n_out * s.n_wp;
   const int ks = bbwd_ksplit(p);
+  for (int j = 0; j < n_out; ++j)
+    if (!dy[j]) return fail(FNO_EINVAL, "fno_fanout_backward: dy[%d] is null", j);
+  const bool batched = n_out > 1 && mode_gemm_members_ok(C, C) && (long)n_out * B * (g.nlead == 2 ? g.dims[0] : 1) <= 65535;
+  if (batched) {
+    for (int j = 0; j < n_out; ++j)
+      LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], f.x1 + (size_t)j * s.n_x1));
+    LAUNCHCHK(lead_forward(st, g, p->t, true, n_out * B, C, f.x1, f.tmp, f.ohat));
+    LAUNCHCHK(mode_gemm_dw(st, hat, f.ohat, w.dwp, B, g.Ktot, C, C, n_out, 0, s.n_hat, s.n_wp));
+    LAUNCHCHK(mode_gemm(st, f.ohat, wpts, f.hat2, B, g.Ktot, C, C, 1, n_out, s.n_hat, s.n_wp, s.n_hat));
+    LAUNCHCHK(lead_inverse(st, g, p->t, n_out * B, C, f.hat2, f.tmp, f.z));
+  }
   JobList jobs;
   for (int j = 0; j < n_out; ++j) {
-    if (!dy[j]) return fail(FNO_EINVAL, "fno_fanout_backward: dy[%d] is null", j);
     float* dwp_j = w.dwp + (size_t)j * s.n_wp;
     float* dw_part_j = w.dw_part + (size_t)j * s.grid * ks * C * C;
     float* db_part_j = w.db_part + (size_t)j * s.grid * C;
-    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], w.x1));
-    LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
-    LAUNCHCHK(mode_gemm_dw(st, hat, w.ohat, dwp_j, B, g.Ktot, C, C));
-    LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
-    LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
+    const float* zj = w.z;
+    if (batched) zj = f.z + (size_t)j * s.n_x1;
+    else {
+      LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], w.x1));
+      LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
+      LAUNCHCHK(mode_gemm_dw(st, hat, w.ohat, dwp_j, B, g.Ktot, C, C));
+      LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
+      LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
+    }
     BlkBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.g = dy[j]; a.uin = x; a.w = prm->skip_w[j];
-    a.zg = w.z; a.tinv = p->t.tinv_b;
+    a.zg = zj; a.tinv = p->t.tinv_b;
     a.gout = dx; a.gadd = j > 0 ? dx : nullptr;          // every lane re-reads exactly the elements it then rewrites
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_j; a.db_part = db_part_j;

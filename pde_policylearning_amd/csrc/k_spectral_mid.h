@@ -369,7 +369,9 @@ template <int CI, int CO>
 __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
                                                                            const float2* __restrict__ w,
                                                                            float2* __restrict__ out, int B, int Ktot,
-                                                                           int conj_w) {
+                                                                           int conj_w, size_t x_ms, size_t w_ms, size_t o_ms) {
+  // blockIdx.z = member of a batch of independent contractions (fan-outs); *_ms = member strides in float2 (0: shared)
+  x += blockIdx.z * x_ms; w += blockIdx.z * w_ms; out += blockIdx.z * o_ms;
   constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1, PB = 2 * CO + 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [64][PA]
@@ -419,7 +421,8 @@ template <int CI, int CO>
 __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw_mfma(const float2* __restrict__ x,
                                                                                       const float2* __restrict__ g,
                                                                                       float2* __restrict__ dw, int B,
-                                                                                      int Ktot) {
+                                                                                      int Ktot, size_t x_ms, size_t g_ms, size_t d_ms) {
+  x += blockIdx.y * x_ms; g += blockIdx.y * g_ms; dw += blockIdx.y * d_ms;        // blockIdx.y = member (see k_mode_gemm_mfma)
   constexpr int NTN = 2 * CO / 32, NT = (CI / 32) * NTN * 64, PA = 2 * CI, PB = 2 * CO + 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [64][PA]   raw interleaved spectra of the chunk

@@ -498,7 +498,7 @@ class _FourierFanoutFn(torch.autograd.Function):
         bptr = (C.c_void_p * n)(*[b.data_ptr() for b in biases])
         yptr = (C.c_void_p * n)(*[y.data_ptr() for y in ys])
         saved = _bytes(L.fno_fanout_saved_bytes(plan, B, n), x.device)
-        nws = L.fno_model_workspace_bytes(plan, B)
+        nws = L.fno_fanout_workspace_bytes(plan, B, n)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
             _lib.check(L.fno_fanout_forward(plan, B, n, C.byref(prm), bptr, _ptr(x), yptr, _ptr(saved), _ptr(ws), nws,
@@ -527,7 +527,7 @@ class _FourierFanoutFn(torch.autograd.Function):
         dyptr = (C.c_void_p * n)(*[d.data_ptr() for d in dys])
         dbptr = (C.c_void_p * n)(*[b.data_ptr() for b in g_bias])
         dx = torch.empty_like(x)
-        nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
+        nws = L.fno_fanout_workspace_bytes(ctx.plan, ctx.B, n)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
             _lib.check(L.fno_fanout_backward(ctx.plan, ctx.B, n, C.byref(prm), _ptr(x), dyptr, _ptr(saved), C.byref(grd), dbptr,
