@@ -15,10 +15,13 @@ while done < n:
     C = random.choice([32, 64])
     L = random.randint(1, 4)
     B = random.randint(1, 2)
-    dims = (random.choice([8, 16, 32, 64]), random.choice([32, 64, 128])) if nd == 2 else (random.choice([4, 8]), random.choice([8, 16]), random.choice([32, 64]))
+    # last dims that tile the 128-pixel workgroup tile, and "loose" ones (33..96, not multiples of 32: spectral rows gathered per tile)
+    last2 = random.choice([32, 64, 128, 33, 40, 73, 96 - 1, 50])
+    last3 = random.choice([32, 64, 40, 73, 36])
+    dims = (random.choice([8, 16, 32, 64, 128]), last2) if nd == 2 else (random.choice([4, 8, 16]), random.choice([8, 16]), last3)
     pw = 1
     for d in dims: pw *= d
-    if pw % 128 or 128 % dims[-1]:
+    if pw % 128 or (dims[-1] % 32 == 0 and 128 % dims[-1]):
         continue
     modes = tuple(random.randint(1, min(8, d // 2)) for d in dims[:-1]) + (random.randint(1, min(12, dims[-1] // 2)),)
     norm = random.choice(["backward", "forward", "ortho"])
