@@ -776,8 +776,13 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
       const size_t bbwd_x3 = (size_t)6 * C * (npx + 8) * 2 + (size_t)C * (npx + 4) * 4 + tz + std::max(xin, many ? tf : (size_t)0);
       const size_t bbwd = (npx == 128 && bbwd_x3 <= 160 * 1024) ? bbwd_x3 : bbwd_f32;
       const size_t pwx3 = (size_t)3 * npx * (C + 8) * 2 + tz + (many ? tf : 0), pwf32 = (size_t)C * (npx + 4) * 4 + tz + (many ? tf : 0);
-      if (p->loose && bbwd_x3 > 160 * 1024)      // loose rows exist for the split-precision kernels only
+      // loose rows exist for the split-precision kernels only; their backward kernel can apply the K-extension in chunks
+      // of kept modes, so one mode's rows + table column must fit next to the GEMM images
+      const size_t bbwd_x3_1 = (size_t)6 * C * (npx + 8) * 2 + (size_t)C * (npx + 4) * 4 +
+                               ((size_t)2 * g.W + (size_t)(npx / g.W + 2) * C * 2) * 4;
+      if (p->loose && (bbwd_x3_1 > 160 * 1024 || pwx3 > 160 * 1024))
         rc = fail(FNO_EUNSUPPORTED, "loose-row tile of %d channels with %d kept last-dim modes exceeds LDS", C, g.Klast);
+      else if (p->loose) { /* fits */ }
       else if (bbwd > 160 * 1024 || pwx3 > 160 * 1024 || pwf32 > 160 * 1024)
         rc = fail(FNO_EUNSUPPORTED, "tile of %d pixels x %d channels with %d kept last-dim modes exceeds LDS", npx, C,
                   g.Klast);
@@ -918,8 +923,21 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   const size_t pitch = p->NPX + 4;
   if (p->loose) {
     if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
-    const size_t ldsl = bbwd_x3_lds(C, 128, a) + (a.zg ? (size_t)2 * a.K2in * C * 2 * 4 : 0);
-    return launch("k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, a);
+    BlkBwdArgs al = a;
+    const int rows = 128 / a.W + 2;
+    BlkBwdArgs nz = a;
+    nz.zg = nullptr;
+    const size_t base = bbwd_x3_lds(C, 128, nz);                          // everything but the spectral rows and their table
+    const size_t per_mode = ((size_t)2 * a.W + (size_t)rows * C * 2) * 4;
+    size_t ldsl = base;
+    if (a.zg) {
+      int kch = a.K2in;
+      while (kch > 1 && base + kch * per_mode > 160 * 1024) --kch;         // chunk the K-extension until the tile fits
+      if (base + kch * per_mode > 160 * 1024) return fail(FNO_EUNSUPPORTED, "loose-row backward tile exceeds LDS");
+      al.kch = kch < a.K2in ? kch : 0;
+      ldsl = base + kch * per_mode;
+    }
+    return launch("k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
     return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),

@@ -40,6 +40,8 @@ struct BlkBwdArgs {
   int PW, W, P, K2in, K2out, NJ;
   int act_in;
   int loose;           // rows do not tile the pixel tile (see PwFwdArgs.loose); k_block_bwd_x3 only
+  int kch;             // loose rows: kept last-dim modes per K-extension chunk (0 = all at once); the spectral rows and
+                       // the table of a chunk are staged right before it is applied, so many kept modes still fit LDS
   int tiles_per_plane, ntiles;
 };
 
@@ -293,8 +295,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   float* xls = r3 + C * PITCH;
   float* tinv_s = xls + (a.xin ? 8 * PITCH : 0);
   const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
-  float* zs = tinv_s + (a.zg ? 2 * a.K2in * a.W : 0);
-  float* tfwd_s = zs + (a.zg ? R * a.K2in * C * 2 : 0);
+  const int KC = (LOOSE && a.kch > 0 && a.kch < a.K2in) ? a.kch : a.K2in;     // modes resident in LDS at a time
+  const bool chunked = KC < a.K2in;
+  float* zs = tinv_s + (a.zg ? 2 * KC * a.W : 0);
+  float* tfwd_s = zs + (a.zg ? R * KC * C * 2 : 0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -304,13 +308,13 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   const int dtl = wave % TILES, dkp = wave / TILES;     // dW job
   const int dmt = dtl / MT, dnt = dtl % MT;
 
-  if (a.zg)
+  if (a.zg && !chunked)
     for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
   if (a.x1g)
     for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
   auto zc4 = [&](int px0) {
     const int nrows = LOOSE ? (px0 + NPX - 1) / a.W - px0 / a.W + 1 : R;
-    return a.zg ? nrows * a.K2in * C / 2 : 0;
+    return (a.zg && !chunked) ? nrows * a.K2in * C / 2 : 0;
   };
 
   // A fragments of W^T: A[i][k = o] = W[o][i], split into (h, m, l)
@@ -453,7 +457,22 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       }
     }
     if constexpr (LOOSE) {
-      if (a.zg) acc = kext_loose_rows<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
+      if (a.zg && !chunked) acc = kext_loose_rows<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
+      else if (a.zg) {
+        const int r_lo = px0 / a.W, nrows = (px0 + NPX - 1) / a.W - r_lo + 1;
+        for (int k0 = 0; k0 < a.K2in; k0 += KC) {
+          const int kc = min(KC, a.K2in - k0);
+          __syncthreads();                        // every wave is done with the previous chunk (or the previous tile's last)
+          for (int i = tid; i < 2 * kc * a.W; i += NT) tinv_s[i] = a.tinv[2 * k0 * a.W + i];
+          const int per_row4 = kc * C / 2;        // float4s of one row's chunk: modes k0 .. k0 + kc are contiguous in a row
+          for (int i = tid; i < nrows * per_row4; i += NT) {
+            const int r = i / per_row4, rem = i - r * per_row4;
+            st4(zs + 4 * i, ld4(a.zg + (((size_t)b * a.P + r_lo + r) * a.K2in + k0) * C * 2 + 4 * rem));
+          }
+          __syncthreads();
+          acc = kext_loose_rows<C>(acc, zs, tinv_s, kc, a.W, px0 + n0, r_lo, mt, l31, half);
+        }
+      }
     } else if (a.zg) {
       const float* zr = zs + (((n0 / a.W) * a.K2in) * C + mt * 32 + l31) * 2 + half;
       const float* tv = tinv_s + half * a.W + n0 % a.W + l31;

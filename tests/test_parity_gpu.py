@@ -922,7 +922,8 @@ def test_block_stack_3d_vs_oracle(dev):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_G, (a.shape,)
 
 
-@pytest.mark.parametrize("C,dims,modes,L", [(64, (16, 8, 73), (3, 4, 8), 3), (32, (8, 16, 40), (2, 3, 5), 2), (64, (128, 33), (6, 7), 2)])
+@pytest.mark.parametrize("C,dims,modes,L", [(64, (16, 8, 73), (3, 4, 8), 3), (32, (8, 16, 40), (2, 3, 5), 2), (64, (128, 33), (6, 7), 2),
+                                            (64, (8, 16, 73), (2, 3, 20), 2)])      # 20 kept last-dim modes: the backward K-extension runs in chunks
 def test_block_stack_loose_rows_vs_oracle(dev, C, dims, modes, L):
     """Fused block stacks on rows that do not tile the 128-pixel workgroup tile (last dim 73 / 40 / 33: the spectral
     K-extension gathers the one or two rows every 32-pixel block overlaps, the last-dim forward transforms run as separate
