@@ -30,6 +30,8 @@ CONFIGS = {
     "fno2d_128x128_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(128, 128)),
     "fno2d_64x64_w32_m8_b4": dict(kind="2d", modes=(8, 8), width=32, batch=4, size=(64, 64)),
     "fno3d_64_w32_m8_b16": dict(kind="3d", modes=(8, 8, 8), width=32, batch=16, size=(64, 64, 64)),
+    # a grid whose rows do not tile the kernels' 128-pixel tile ("loose rows": spectral rows gathered per tile)
+    "fno2d_96x96_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(96, 96)),
     # observer models of BASELINE configs 3 / 5.  Secondary workloads: their spectral
     # convolutions run in the engine (fno_spec_*), the channels-last pointwise glue is still torch ops; no
     # roofline / cpu_baseline legs.

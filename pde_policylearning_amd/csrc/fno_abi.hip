@@ -703,7 +703,7 @@ struct FnoModelPlan {
   Geom g;
   Tables t;
   int NPX;      // pixels per workgroup tile (128 or 256)
-  bool loose;   // rows do not tile the pixel tile (last dim not a multiple of 32): block stacks only, separate row-DFT passes
+  bool loose;   // rows do not tile the pixel tile (last dim 96, 160, 73, ...): spectral rows gathered per tile, separate row-DFT passes
   int ncu;      // compute units of the device the plan was made on
 };
 
@@ -750,9 +750,12 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
     const int W = p->g.W;
     p->loose = false;
     static const int no_loose = getenv("FNO_NO_LOOSE") ? 1 : 0;      // A/B switch: loose-row stacks fall back to the chained layers
-    if (!no_loose && W % 32 != 0 && W >= 32 && W <= 320 && d->Cin == 0 && d->Cout == 0 && p->g.PW % 128 == 0 && p->g.Klast <= 32) {
-      // "loose rows" (e.g. the PINO observers' padded time axis, 73): 128-pixel tiles of the flattened plane; the block
-      // kernels take the spectral rows that overlap their tile (kext_loose_rows) and the last-dim forward transforms
+    const int npx_tiled = W > 128 ? 256 : 128;
+    const bool tiles = W % 32 == 0 && W <= 256 && npx_tiled % W == 0 && p->g.PW % npx_tiled == 0;
+    if (!no_loose && !tiles && W >= 32 && W <= 320 && p->g.PW % 128 == 0 && p->g.Klast <= 32) {
+      // "loose rows" (the PINO observers' padded time axis, 73; FNO grids such as 96 x 96 or 160 x 160): 128-pixel tiles of
+      // the flattened plane; the block kernels take the spectral rows that overlap their tile (kext_loose_rows) and the
+      // last-dim forward transforms
       // run as separate lanes-as-channels passes instead of kernel epilogues.  Block stacks only.
       p->loose = true;
       p->NPX = 128;
@@ -1040,11 +1043,12 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     // lifting (tfno.py:19-20) + row DFT of its output
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
-    a.u = u; a.x1 = w.x1; a.tfwd = p->t.tfwd_f;
+    a.u = u; a.x1 = p->loose ? nullptr : w.x1; a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
+    if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, u, w.x1));   // no epilogue on loose rows
   } else {
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));     // block stack: x is u_0
   }
@@ -1132,7 +1136,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
-  pb.w2 = prm->proj_w2; pb.gout = w.ga; pb.x1g = w.x1; pb.tfwd = p->t.tfwd_b;
+  pb.w2 = prm->proj_w2; pb.gout = w.ga; pb.x1g = p->loose ? nullptr : w.x1; pb.tfwd = p->t.tfwd_b;
   pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;
   pb.PW = g.PW; pb.W = g.W; pb.P = g.P; pb.K2out = g.Klast; pb.NJ = g.NJ; pb.CO = d.Cout;
   pb.act_in = (d.gelu_mask >> (L - 1)) & 1u;
@@ -1144,6 +1148,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   jobs.add(w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID);
   LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
   jobs.add(w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout);
+  if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, w.ga, w.x1));   // dL/du_L's row spectrum
   }
 
   const float* gcur = has_proj ? w.ga : dy;   // dL/du_{l+1}

@@ -439,9 +439,9 @@ def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
         pw *= s
     npx = 256 if w > 128 else 128
     tiled = w % 32 == 0 and w <= 256 and npx % w == 0 and pw % npx == 0
-    # "loose rows" (any last dim in 32..320 that is not a multiple of 32, e.g. the PINO observers' padded time axis):
+    # "loose rows" (any other last dim in 32..320, e.g. the PINO observers' padded time axis 73, or 96 / 160):
     # 128-pixel tiles of the flattened plane, spectral rows gathered per tile (split-precision GEMM mode only)
-    loose = w % 32 != 0 and 32 <= w <= 320 and pw % 128 == 0 and _lib.lib().fno_get_gemm_mode() == 1
+    loose = (not tiled) and 32 <= w <= 320 and pw % 128 == 0 and _lib.lib().fno_get_gemm_mode() == 1
     if not (c in (32, 64) and (tiled or loose) and n_layers <= _lib.FNO_MAX_LAYERS):
         return False
     if modes is None:

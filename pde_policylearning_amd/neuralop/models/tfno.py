@@ -1,6 +1,7 @@
 """FNO / FNO2d / FNO3d with the reference constructor surface (neuralop/models/tfno.py:
 Lifting :11-20, Projection :23-38, FNO :107-211, FNO2d :342-458, FNO3d :467-580).
 forward() runs the whole model in the HIP engine (functional.fno_model)."""
+import torch
 import torch.nn.functional as TF
 from torch import nn
 
@@ -79,15 +80,18 @@ class FNO(nn.Module):
 
     def fused_supported(self, x):
         """Shapes the whole-model fused kernels cover (fno_model_plan_create): hidden width 32/64,
-        <= 4 input / output channels, projection_channels 256, last dim % 32 == 0 and <= 256."""
+        <= 4 input / output channels, projection_channels 256, and either rows that tile the 128 / 256-pixel workgroup tile
+        (last dim 32, 64, 128, 256) or "loose rows" (any last dim in 32..320 on planes that tile by 128 pixels: 96 x 96,
+        160 x 160, 192 x 192 grids ...; split-precision GEMM mode)."""
         w = x.shape[-1]
         npx = 256 if w > 128 else 128
         plane = 1
         for s in x.shape[2:]:
             plane *= s
+        tiled = w % 32 == 0 and w <= 256 and npx % w == 0 and plane % npx == 0
+        loose = (not tiled) and 32 <= w <= 320 and plane % 128 == 0 and F._lib.lib().fno_get_gemm_mode() == 1
         if not (self.hidden_channels in (32, 64) and self.in_channels <= 4 and self.out_channels <= 4
-                and self.projection_channels == 256 and w % 32 == 0 and w <= 256
-                and npx % w == 0 and plane % npx == 0 and not x.requires_grad and x.is_cuda):
+                and self.projection_channels == 256 and (tiled or loose) and not x.requires_grad and x.is_cuda):
             return False
         # the engine has the last word (e.g. 256-pixel tiles with many kept modes do not fit LDS)
         gelu_mask = 0

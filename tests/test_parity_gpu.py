@@ -181,7 +181,9 @@ def _fno_params(C, L, half_modes, cin=3, cout=1, seed_tag="p"):
 
 @pytest.mark.parametrize("C,S,modes,B,L", [(32, 32, (8, 8), 3, 4), (64, 64, (12, 10), 2, 2),
                                            (32, 128, (16, 16), 1, 3), (64, 256, (12, 12), 1, 1),
-                                           (64, 32, (16, 16), 2, 2)])     # 4 rows per tile x 8 modes: more Z rows than threads
+                                           (64, 32, (16, 16), 2, 2),      # 4 rows per tile x 8 modes: more Z rows than threads
+                                           (64, 96, (12, 12), 2, 4), (32, 160, (16, 12), 1, 3),     # "loose rows": 96 and 160 do not tile
+                                           (64, 48, (8, 8), 2, 2)])                                 # the 128 / 256-pixel tiles
 def test_fno2d_vs_oracle(dev, C, S, modes, B, L):
     half = [m // 2 for m in modes]
     p = _fno_params(C, L, half)
@@ -291,6 +293,28 @@ def test_pino_finetune_fullsize_properties(dev):
     assert abs(a[0] - 0.5 * (b[0] + c[0])) < 2e-6 * abs(a[0])
     assert abs(a[1] - 0.5 * (b[1] + c[1])) < 2e-6 * abs(a[1])
     assert rel_l2(_cpu(torch.cat([b[2], c[2]]) * 0.5), _cpu(a[2])) < 2e-6
+
+
+def test_unfused_fallback_with_direct_write_bucket(dev):
+    """A grid the fused model does not cover (plane not a multiple of 128 pixels) under a direct-write gradient bucket: the
+    layer-by-layer path must clear the gradients the bucket leaves alone and train like the plain autograd path (regression:
+    the fallback referenced `torch` without importing it)."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    torch.manual_seed(0)
+    model = FNO2d(8, 8, 32, in_channels=3, out_channels=1).to(dev)
+    x = torch.randn(2, 3, 40, 40, device=dev)                      # 1600 pixels: neither tiled nor loose
+    assert not model.fused_supported(x)
+    model(x).square().sum().backward()
+    ref = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    bucket = FlatGradBucket(model.parameters(), direct_module=model)
+    for _ in range(2):                                             # twice: stale gradients must not accumulate
+        bucket.zero()                                              # train_step's zero_grad: skips the direct-write segment
+        model(x).square().sum().backward()
+    for p, r in zip(model.parameters(), ref):
+        assert rel_l2(_cpu(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad),
+                      _cpu(torch.view_as_real(r) if r.is_complex() else r)) < 1e-5
 
 
 def test_fails_loudly_on_cpu_tensor(dev):
