@@ -90,6 +90,11 @@ int fno_spec_backward(const FnoSpecPlan* plan, int batch, const float* dy, const
  * with fno_skip='linear', GELU gate `index < n_layers - index` :149 -> Projection :23-38).
  * One fused kernel per block (skip 1x1 conv + last-dim inverse DFT + bias + gated GELU +
  * last-dim forward DFT of the next block), activations stored pre-activation.
+ * Grids: hidden width 32 or 64; rows (last dim) of 32 / 64 / 128 / 256 tile the kernels' 128- or 256-pixel tiles and take the
+ * row transforms as kernel epilogues; any other last dim in 32..320 on planes that are a multiple of 128 pixels (96 x 96,
+ * 160 x 160, the PINO observers' padded time axis 73, ...) runs in "loose rows" mode: 128-pixel tiles of the flattened plane,
+ * spectral rows gathered per tile, last-dim forward transforms as separate passes (split-precision GEMM mode only).
+ * fno_model_plan_create returns FNO_EUNSUPPORTED for everything else; callers then compose fno_spec_* / fno_pointwise_*.
  * ---------------------------------------------------------------------- */
 typedef struct FnoModelDesc {
   int ndim;            /* 2 or 3 */
