@@ -15,15 +15,14 @@ for case in range(n):
     L = random.randint(1, 5)
     cin, cout = random.randint(1, 4), random.choice([1, 1, 2, 3])
     if three_d:
-        dims = (random.choice([8, 16]), random.choice([8, 16, 24]), random.choice([32, 64]))
+        dims = (random.choice([8, 16]), random.choice([8, 16, 24]), random.choice([32, 64, 48, 40]))
         B = random.randint(1, 2)
     else:
-        dims = (random.choice([16, 32, 48, 64, 128]), random.choice([32, 64, 96, 128, 256]))
+        dims = (random.choice([16, 32, 48, 64, 96, 128, 160]), random.choice([32, 64, 96, 128, 256, 48, 160, 40, 50]))
         B = random.randint(1, 3)
     pw = 1
     for d in dims: pw *= d
-    npx = 256 if dims[-1] > 128 else 128
-    if pw % npx or npx % dims[-1]:
+    if pw % 128:                      # rows that tile the 128 / 256-pixel tile, and "loose" ones (48, 96, 160, 40, 50 ...)
         continue
     modes = tuple(2 * random.randint(1, min(8, d // 2 - 1 if i < len(dims) - 1 else d // 2)) for i, d in enumerate(dims))
     torch.manual_seed(case)
