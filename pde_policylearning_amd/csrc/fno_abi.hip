@@ -390,7 +390,36 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
   return launch("k_mode_gemm_dw", k_mode_gemm_dw, grid, dim3(256), 0, st, (const float2*)x, (const float2*)g,
                 (float2*)dw, B, Ktot, Cin, Cout);
 }
+static const int g_pack_flat = getenv("FNO_PACK_FLAT") ? 1 : 0;      // A/B switch: thread-per-element layout kernels
+// all layers of a stack in one launch each way (blockIdx.y = layer); wp / wpt nullable; `stride` = floats between layers
+static int nrest_of(const Geom& g) { return g.nlead == 2 ? g.modes[0] * g.modes[1] : g.modes[0]; }
+static int pack_w_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const CornerPtrsL& cp, int L, float* wp, float* wpt,
+                         size_t stride) {
+  const ModeMap mm = make_modemap(g, Cin, Cout);
+  const int nrest = nrest_of(g);
+  int ti = 8;                                  // input channels per workgroup: whole sectors of the transposed copy
+  while (ti > 1 && (Cin % ti != 0 || (size_t)ti * Cout * (g.wl_stride + 1) * 8 > 48 * 1024)) ti >>= 1;   // >= 3 workgroups per CU
+  const size_t blocks = (size_t)(1 << g.nlead) * nrest * (Cin / ti);
+  if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight pack grid too large");
+  return launch("k_pack_w", k_pack_w_tiled, dim3((unsigned)blocks, L), dim3(256), (size_t)ti * Cout * (g.wl_stride + 1) * 8, st, cp,
+                (float2*)wp, (float2*)wpt, mm, stride / 2, nrest, ti);
+}
+static int unpack_dw_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const float* dwp, const CornerPtrsMutL& cp, int L,
+                            size_t stride) {
+  const ModeMap mm = make_modemap(g, Cin, Cout);
+  const int nrest = nrest_of(g);
+  const size_t blocks = (size_t)(1 << g.nlead) * nrest * Cin;
+  if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight unpack grid too large");
+  return launch("k_unpack_dw", k_unpack_dw_tiled, dim3((unsigned)blocks, L), dim3(256), (size_t)Cout * (g.wl_stride + 1) * 8, st,
+                (const float2*)dwp, cp, mm, stride / 2, nrest);
+}
 static int pack_w(hipStream_t st, const Geom& g, int Cin, int Cout, const float* const* corners, float* wp, float* wpt) {
+  if (!g_pack_flat) {
+    CornerPtrsL cpl;
+    memset(&cpl, 0, sizeof(cpl));
+    for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (const float2*)corners[c];
+    return pack_w_layers(st, g, Cin, Cout, cpl, 1, wp, wpt, 0);
+  }
   CornerPtrs cp;
   for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (const float2*)corners[c] : nullptr;
   const ModeMap mm = make_modemap(g, Cin, Cout);
@@ -399,6 +428,12 @@ static int pack_w(hipStream_t st, const Geom& g, int Cin, int Cout, const float*
                 (float2*)wpt, mm);
 }
 static int unpack_dw(hipStream_t st, const Geom& g, int Cin, int Cout, const float* dwp, float* const* dcorners) {
+  if (!g_pack_flat) {
+    CornerPtrsMutL cpl;
+    memset(&cpl, 0, sizeof(cpl));
+    for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (float2*)dcorners[c];
+    return unpack_dw_layers(st, g, Cin, Cout, dwp, cpl, 1, 0);
+  }
   CornerPtrsMut cp;
   for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (float2*)dcorners[c] : nullptr;
   const ModeMap mm = make_modemap(g, Cin, Cout);
@@ -1033,6 +1068,8 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (const float2*)prm->spec_w[l][c];
     const ModeMap mm = make_modemap(g, C, C);
     const size_t n = (size_t)g.Ktot * C * C;
+    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, wpts, s.n_wp));
+    else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
   }
@@ -1203,6 +1240,8 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     size_t per = (size_t)g.modes[0] * g.wl_stride;
     if (g.nlead == 2) per *= g.modes[1];
     const size_t n = (size_t)(1 << g.nlead) * C * C * per;
+    if (!g_pack_flat) LAUNCHCHK(unpack_dw_layers(st, g, C, C, w.dwp + (size_t)l_lo * s.n_wp, cp, l_hi - l_lo + 1, s.n_wp));
+    else
     LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), l_hi - l_lo + 1), dim3(256),
                      0, st, (const float2*)(w.dwp + (size_t)l_lo * s.n_wp), cp, mm, (size_t)g.Ktot * C * C));
   }
@@ -1273,6 +1312,8 @@ extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (const float2*)prm->spec_w[j][c];
     const ModeMap mm = make_modemap(g, C, C);
     const size_t n = (size_t)g.Ktot * C * C;
+    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, n_out, wps, wpts, s.n_wp));
+    else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
   }
@@ -1364,6 +1405,7 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   size_t per = (size_t)g.modes[0] * g.wl_stride;
   if (g.nlead == 2) per *= g.modes[1];
   const size_t n = (size_t)(1 << g.nlead) * C * C * per;
+  if (!g_pack_flat) return unpack_dw_layers(st, g, C, C, w.dwp, cp, n_out, s.n_wp);
   return launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st,
                 (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C);
 }

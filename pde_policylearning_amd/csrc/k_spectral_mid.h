@@ -240,6 +240,71 @@ __global__ void k_unpack_dw_layers(const float2* __restrict__ dwp, CornerPtrsMut
   gw.p[l][corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
 }
 
+// LDS-tiled forms of the two layout changes.  The corner tensors are (i, o)-major with the kept modes innermost, the
+// packed arrays mode-major with (i, o) innermost: a thread-per-element copy is coalesced on one side only and moves 8 bytes
+// per 64-byte sector on the other (the PINO observers carry 0.2 - 1 GB of spectral weights per layer).  A workgroup owns
+// one (layer, corner, leading-mode position `rest`, input channel i): the tile [o][kl] (Cout x wl_stride complex) is read
+// along its contiguous side, transposed through LDS and written along the other's.
+//   grid (ncorner * nrest * Cin, layers), block 256, LDS Cout * (wl_stride + 1) float2
+FNO_DEV int tile_mode_base(const ModeMap& mm, int corner, int rest) {        // packed mode index of (corner, rest, kl = 0)
+  if (mm.nlead == 2) {
+    const int l1 = rest / mm.m[1], l2 = rest - l1 * mm.m[1];
+    return ((l1 + (corner >> 1) * mm.m[0]) * mm.K[1] + l2 + (corner & 1) * mm.m[1]) * mm.K[2];
+  }
+  return (rest + corner * mm.m[0]) * mm.K[1];
+}
+__global__ void __launch_bounds__(256) k_pack_w_tiled(CornerPtrsL cw, float2* __restrict__ wp, float2* __restrict__ wpt,
+                                                      ModeMap mm, size_t stride, int nrest, int TI) {
+  // TI consecutive input channels per workgroup: the transposed copy wpt[k][o][i] is then written in TI * 8-byte pieces
+  // (whole 64-byte sectors at TI = 8) instead of lone 8-byte elements
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* t = reinterpret_cast<float2*>(smem);     // [TI][Cout][wl + 1]
+  const int wl = mm.wl_stride, WLP = wl + 1, klive = mm.K[mm.nlead];
+  const int l = blockIdx.y;
+  const int nib = mm.Cin / TI;
+  const int i0 = (blockIdx.x % nib) * TI, rest = (blockIdx.x / nib) % nrest, corner = blockIdx.x / (nib * nrest);
+  const size_t per = (size_t)nrest * wl;
+  const float2* src = cw.p[l][corner] + (size_t)i0 * mm.Cout * per + (size_t)rest * wl;
+  const int nio = TI * mm.Cout;
+  for (int idx = threadIdx.x; idx < nio * klive; idx += 256) {      // live modes only (dialect C stores modes3 >= the live count)
+    const int io = idx / klive, kl = idx - io * klive;
+    t[io * WLP + kl] = src[(size_t)io * per + kl];
+  }
+  __syncthreads();
+  const int k0 = tile_mode_base(mm, corner, rest);
+  if (wp)
+    for (int idx = threadIdx.x; idx < klive * nio; idx += 256) {
+      const int kl = idx / nio, io = idx - kl * nio;
+      wp[l * stride + ((size_t)(k0 + kl) * mm.Cin + i0) * mm.Cout + io] = t[io * WLP + kl];
+    }
+  if (wpt)
+    for (int idx = threadIdx.x; idx < klive * nio; idx += 256) {
+      const int kl = idx / nio, r = idx - kl * nio, o = r / TI, ii = r - o * TI;
+      wpt[l * stride + ((size_t)(k0 + kl) * mm.Cout + o) * mm.Cin + i0 + ii] = t[(ii * mm.Cout + o) * WLP + kl];
+    }
+}
+// corner-layout gradients from mode-major dWp[k][i][o]; stored entries beyond the kept last-dim range get zero
+__global__ void __launch_bounds__(256) k_unpack_dw_tiled(const float2* __restrict__ dwp, CornerPtrsMutL gw, ModeMap mm,
+                                                         size_t stride, int nrest) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* t = reinterpret_cast<float2*>(smem);
+  const int wl = mm.wl_stride, WLP = wl + 1, klive = mm.K[mm.nlead];
+  const int l = blockIdx.y;
+  const int i = blockIdx.x % mm.Cin, rest = (blockIdx.x / mm.Cin) % nrest, corner = blockIdx.x / (mm.Cin * nrest);
+  const size_t per = (size_t)nrest * wl;
+  const int k0 = tile_mode_base(mm, corner, rest);
+  for (int idx = threadIdx.x; idx < klive * mm.Cout; idx += 256) {
+    const int kl = idx / mm.Cout, o = idx - kl * mm.Cout;
+    t[o * WLP + kl] = dwp[l * stride + ((size_t)(k0 + kl) * mm.Cin + i) * mm.Cout + o];
+  }
+  __syncthreads();
+  float2* dst = gw.p[l][corner] + (size_t)i * mm.Cout * per + (size_t)rest * wl;
+  for (int idx = threadIdx.x; idx < mm.Cout * wl; idx += 256) {
+    const int o = idx / wl, kl = idx - o * wl;
+    dst[(size_t)o * per + kl] = kl < klive ? t[o * WLP + kl] : make_float2(0.f, 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // O[b][k][o] = sum_i X[b][k][i] * W[k][i][o]          (conj_w: use conj(W), for the adjoint
 // with wpt[k][o][i] passed as w and Cin/Cout swapped)
