@@ -341,18 +341,19 @@ static bool mode_gemm_members_ok(int Cin, int Cout) {
   return g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64);
 }
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
-                     int conj_w, int nm = 1, size_t x_ms = 0, size_t w_ms = 0, size_t o_ms = 0) {
+                     int conj_w, int nm = 1, size_t x_ms = 0, size_t w_ms = 0, size_t o_ms = 0, int trans_w = 0) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
+  if (trans_w && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "transposed-weight contraction needs the matrix-core kernels");
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
     const dim3 grid(Ktot, (B + 63) / 64, nm), blk(2 * (2 * Cout / 32) * 64);
-    const size_t lds = ((size_t)64 * (2 * Cin + 1) + (size_t)2 * Cin * (2 * Cout + 32)) * 4;
+    const size_t lds = ((size_t)64 * (2 * Cin + 1) + (size_t)2 * Cin * (2 * Cout + 32)) * 4 + (trans_w ? (size_t)Cout * (Cin + 1) * 8 : 0);
     const float2 *xx = (const float2*)x, *ww = (const float2*)w;
     float2* oo = (float2*)out;
-    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
-    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
-    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
-    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2);
+    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
@@ -1068,7 +1069,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (const float2*)prm->spec_w[l][c];
     const ModeMap mm = make_modemap(g, C, C);
     const size_t n = (size_t)g.Ktot * C * C;
-    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, wpts, s.n_wp));
+    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) ? nullptr : wpts, s.n_wp));   // the matrix-core adjoint reads wps
     else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
@@ -1154,7 +1155,16 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   if (!ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   const float* u = (const float*)saved;
   const float* hats = u + (size_t)(L + 1) * s.n_act;
-  const float* wpts = hats + (size_t)L * s.n_hat + (size_t)L * s.n_wp;   // [k][o][i] packed weights from forward
+  const float* wps = hats + (size_t)L * s.n_hat;                          // [k][i][o] packed weights from forward
+  float* wpts = const_cast<float*>(wps) + (size_t)L * s.n_wp;            // [k][o][i]: only the VALU adjoint needs them
+  const bool adj_mfma = mode_gemm_members_ok(C, C) && !g_pack_flat;
+  if (!adj_mfma && !g_pack_flat) {       // VALU contraction (A/B switch): the forward may have skipped the transposed copy
+    CornerPtrsL cpw;
+    memset(&cpw, 0, sizeof(cpw));
+    for (int l = l_lo; l <= l_hi; ++l)
+      for (int c = 0; c < (1 << g.nlead); ++c) cpw.p[l - l_lo][c] = (const float2*)prm->spec_w[l][c];
+    LAUNCHCHK(pack_w_layers(st, g, C, C, cpw, l_hi - l_lo + 1, nullptr, wpts + (size_t)l_lo * s.n_wp, s.n_wp));
+  }
   JobList jobs;
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
@@ -1203,7 +1213,8 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     float* db_part_l = w.db_part + (size_t)l * s.grid * C;
     LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
     LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, w.ohat, dwp_l, B, g.Ktot, C, C));
-    LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
+    if (adj_mfma) LAUNCHCHK(mode_gemm(st, w.ohat, wps + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1, 1, 0, 0, 0, 1));
+    else LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
     LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
 
     BlkBwdArgs a;
@@ -1312,7 +1323,7 @@ extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (const float2*)prm->spec_w[j][c];
     const ModeMap mm = make_modemap(g, C, C);
     const size_t n = (size_t)g.Ktot * C * C;
-    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, n_out, wps, wpts, s.n_wp));
+    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, n_out, wps, mode_gemm_members_ok(C, C) ? nullptr : wpts, s.n_wp));
     else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
@@ -1356,7 +1367,16 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   FanWs f = carve_fanout(p, B, n_out, ws, ws_bytes, w.total);
   if (!ok || !f.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu (fno_fanout_workspace_bytes)", f.total, ws_bytes);
   const float* hat = (const float*)saved;
-  const float* wpts = hat + s.n_hat + (size_t)n_out * s.n_wp;
+  const float* wps = hat + s.n_hat;
+  float* wpts = const_cast<float*>(wps) + (size_t)n_out * s.n_wp;
+  const bool adj_mfma = mode_gemm_members_ok(C, C) && !g_pack_flat;
+  if (!adj_mfma && !g_pack_flat) {
+    CornerPtrsL cpw;
+    memset(&cpw, 0, sizeof(cpw));
+    for (int j = 0; j < n_out; ++j)
+      for (int c = 0; c < (1 << g.nlead); ++c) cpw.p[j][c] = (const float2*)prm->spec_w[j][c];
+    LAUNCHCHK(pack_w_layers(st, g, C, C, cpw, n_out, nullptr, wpts, s.n_wp));
+  }
   const int ks = bbwd_ksplit(p);
   for (int j = 0; j < n_out; ++j)
     if (!dy[j]) return fail(FNO_EINVAL, "fno_fanout_backward: dy[%d] is null", j);
@@ -1366,7 +1386,7 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
       LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], f.x1 + (size_t)j * s.n_x1));
     LAUNCHCHK(lead_forward(st, g, p->t, true, n_out * B, C, f.x1, f.tmp, f.ohat));
     LAUNCHCHK(mode_gemm_dw(st, hat, f.ohat, w.dwp, B, g.Ktot, C, C, n_out, 0, s.n_hat, s.n_wp));
-    LAUNCHCHK(mode_gemm(st, f.ohat, wpts, f.hat2, B, g.Ktot, C, C, 1, n_out, s.n_hat, s.n_wp, s.n_hat));
+    LAUNCHCHK(mode_gemm(st, f.ohat, adj_mfma ? wps : wpts, f.hat2, B, g.Ktot, C, C, 1, n_out, s.n_hat, s.n_wp, s.n_hat, adj_mfma ? 1 : 0));
     LAUNCHCHK(lead_inverse(st, g, p->t, n_out * B, C, f.hat2, f.tmp, f.z));
   }
   JobList jobs;
@@ -1380,7 +1400,8 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
       LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy[j], w.x1));
       LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
       LAUNCHCHK(mode_gemm_dw(st, hat, w.ohat, dwp_j, B, g.Ktot, C, C));
-      LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
+      if (adj_mfma) LAUNCHCHK(mode_gemm(st, w.ohat, wps + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1, 1, 0, 0, 0, 1));
+      else LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)j * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
       LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
     }
     BlkBwdArgs a;

@@ -434,7 +434,10 @@ template <int CI, int CO>
 __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
                                                                            const float2* __restrict__ w,
                                                                            float2* __restrict__ out, int B, int Ktot,
-                                                                           int conj_w, size_t x_ms, size_t w_ms, size_t o_ms) {
+                                                                           int conj_w, size_t x_ms, size_t w_ms, size_t o_ms,
+                                                                           int trans_w) {
+  // trans_w: w holds the (CO, CI) matrix of the FORWARD contraction and this launch contracts with its transpose
+  // (out[b][n] = sum_m x[b][m] w[n][m]): the adjoint reads the forward's packed weights, no transposed copy exists
   // blockIdx.z = member of a batch of independent contractions (fan-outs); *_ms = member strides in float2 (0: shared)
   x += blockIdx.z * x_ms; w += blockIdx.z * w_ms; out += blockIdx.z * o_ms;
   constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1, PB = 2 * CO + 32;
@@ -448,13 +451,29 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
   const int nb = min(64, B - b0);
   const float sg = conj_w ? -1.f : 1.f;
   const float2* wk = w + (size_t)k * CI * CO;
-  for (int i = tid; i < CI * CO; i += NT) {
-    const int ci = i / CO, o = i % CO;
-    float2 v = wk[i];
-    v.y *= sg;
-    float* r0 = ws + (2 * ci) * PB + 2 * o;
-    r0[0] = v.x; r0[1] = v.y;
-    r0[PB] = -v.y; r0[PB + 1] = v.x;
+  if (trans_w) {
+    // the stored matrix is (CO, CI): a coalesced copy into a padded LDS tile first, then the expanding transpose with
+    // consecutive lanes on consecutive output columns (a direct scatter would put a whole wave on one LDS bank)
+    float2* raw = reinterpret_cast<float2*>(ws + 2 * CI * PB);      // [CO][CI + 1]
+    for (int i = tid; i < CI * CO; i += NT) raw[(i / CI) * (CI + 1) + i % CI] = wk[i];
+    __syncthreads();
+    for (int i = tid; i < CI * CO; i += NT) {
+      const int o = i % CO, ci = i / CO;
+      float2 v = raw[o * (CI + 1) + ci];
+      v.y *= sg;
+      float* r0 = ws + (2 * ci) * PB + 2 * o;
+      r0[0] = v.x; r0[1] = v.y;
+      r0[PB] = -v.y; r0[PB + 1] = v.x;
+    }
+  } else {
+    for (int i = tid; i < CI * CO; i += NT) {
+      const int ci = i / CO, o = i % CO;
+      float2 v = wk[i];
+      v.y *= sg;
+      float* r0 = ws + (2 * ci) * PB + 2 * o;
+      r0[0] = v.x; r0[1] = v.y;
+      r0[PB] = -v.y; r0[PB + 1] = v.x;
+    }
   }
   for (int i = tid; i < 64 * CI; i += NT) {
     const int bb = i / CI, ci = i % CI;

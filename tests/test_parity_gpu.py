@@ -538,6 +538,28 @@ def test_mode_contraction_matrix_cores_equal_valu_kernels(dev, shape, modes, cou
             L.fno_set_mode_gemm(1)
     for a, b in zip(*res):
         assert rel_l2(a, b) < 1e-6
+    if shape[1] == cout and shape[-1] % 32 == 0:
+        # the same switch under the fused block stacks: on the matrix cores the adjoint contraction reads the forward's packed
+        # weights transposed on the fly, the VALU kernels need the transposed copy (re-packed by the backward pass) - also when
+        # the switch flips between a forward and its backward
+        skip = [torch.from_numpy(fill_named("mm.s", (C, C, 1), 0.1)).to(dev)]
+        bias = torch.from_numpy(fill_named("mm.b", (1, C), 0.1)).to(dev)
+        res = []
+        for fwd_mode, bwd_mode in ((1, 1), (0, 0), (1, 0), (0, 1)):
+            xe = x.clone().requires_grad_(True)
+            we = [w.clone().requires_grad_(True) for w in ws]
+            try:
+                L.fno_set_mode_gemm(fwd_mode)
+                y = F.fno_blocks(xe, skip, we, bias, modes, "ortho")
+                L.fno_set_mode_gemm(bwd_mode)
+                y.backward(dy)
+                torch.cuda.synchronize()
+            finally:
+                L.fno_set_mode_gemm(1)
+            res.append([_cpu(y), _cpu(xe.grad)] + [_cpu(w.grad) for w in we])
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert rel_l2(a, b) < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------
