@@ -53,6 +53,7 @@ extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
 // mode contraction on the fp32 matrix cores (default) or the VALU kernels (FNO_MODE_GEMM_VALU=1 / fno_set_mode_gemm(0)):
 // an A/B switch for profiling and for the parity tests, which run both
 static int g_mode_mfma = []() { const char* e = getenv("FNO_MODE_GEMM_VALU"); return (e && e[0] == '1') ? 0 : 1; }();
+static const int g_mode_gemv = getenv("FNO_NO_MODE_GEMV") ? 0 : 1;      // A/B switch: weight-streaming kernels for tiny batches
 extern "C" void fno_set_mode_gemm(int mfma) { g_mode_mfma = mfma ? 1 : 0; }
 extern "C" int fno_get_mode_gemm(void) { return g_mode_mfma; }
 
@@ -344,6 +345,30 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
                      int conj_w, int nm = 1, size_t x_ms = 0, size_t w_ms = 0, size_t o_ms = 0, int trans_w = 0) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
   if (trans_w && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "transposed-weight contraction needs the matrix-core kernels");
+  if (g_mode_mfma && g_mode_gemv && nm == 1 && B <= 4 && Cin <= 64 && Cout <= 64 && (long)Ktot * Cin * Cout >= (1L << 21)) {
+    // tiny batch, many modes: a stream over the weights (k_mode_gemv*); x / out hold B samples back to back
+    const float2 *xx = (const float2*)x, *ww = (const float2*)w;
+    float2* oo = (float2*)out;
+    if (!trans_w) {
+      const dim3 grid((Ktot + 3) / 4), blk(256);
+      switch (B) {
+        case 1: return launch("k_mode_gemm", k_mode_gemv<1>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        case 2: return launch("k_mode_gemm", k_mode_gemv<2>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        case 3: return launch("k_mode_gemm", k_mode_gemv<3>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        default: return launch("k_mode_gemm", k_mode_gemv<4>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+      }
+    } else if (conj_w) {
+      // here `Cin` counts the channels of x (= the forward's Cout) and the stored block is (Cout, Cin) = forward (Cin_f, Cout_f)
+      const dim3 grid(Ktot), blk(256);
+      const size_t lds = (size_t)Cout * (Cin + 1) * 8;
+      switch (B) {
+        case 1: return launch("k_mode_gemm", k_mode_gemv_t<1>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        case 2: return launch("k_mode_gemm", k_mode_gemv_t<2>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        case 3: return launch("k_mode_gemm", k_mode_gemv_t<3>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        default: return launch("k_mode_gemm", k_mode_gemv_t<4>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+      }
+    }
+  }
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
     const dim3 grid(Ktot, (B + 63) / 64, nm), blk(2 * (2 * Cout / 32) * 64);
@@ -371,6 +396,17 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
                         int nm = 1, size_t x_ms = 0, size_t g_ms = 0, size_t d_ms = 0) {
   if (Cout > 256) return fail(FNO_EUNSUPPORTED, "channels > 256");
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
+  if (g_mode_mfma && g_mode_gemv && nm == 1 && B <= 4 && Cin <= 64 && Cout <= 64 && (long)Ktot * Cin * Cout >= (1L << 21)) {
+    const dim3 grid((Ktot + 3) / 4), blk(256);
+    const float2 *xx = (const float2*)x, *gg = (const float2*)g;
+    float2* dd = (float2*)dw;
+    switch (B) {
+      case 1: return launch("k_mode_gemm_dw", k_mode_outer_dw<1>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      case 2: return launch("k_mode_gemm_dw", k_mode_outer_dw<2>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      case 3: return launch("k_mode_gemm_dw", k_mode_outer_dw<3>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      default: return launch("k_mode_gemm_dw", k_mode_outer_dw<4>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+    }
+  }
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
     const dim3 grid(Ktot, nm), blk((Cin / 32) * (2 * Cout / 32) * 64);
     const size_t lds = ((size_t)64 * 2 * Cin + (size_t)128 * (2 * Cout + 32)) * 4;

@@ -546,6 +546,104 @@ __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw
     op[((size_t)k * CI + mt * 32 + acc_row32(r, half)) * (2 * CO) + nt * 32 + l31] = acc[r];
 }
 
+// ---------------------------------------------------------------------------
+// Tiny batches (B <= 4: one or two samples per GPU of the PINO fine-tuning configurations, whose spectral weights are
+// 0.2 - 1 GB per layer): the contraction is a stream over the weights with almost no arithmetic, and the tile kernels
+// above keep one workgroup per CU busy staging 32 KB per mode.  Here a wave owns one mode: lane o streams column o of the
+// mode's (Cin, Cout) block (consecutive lanes -> consecutive addresses), the mode's spectrum values are wave-uniform
+// (readlane), nothing goes through LDS except the transposed variant's tile.  Cin, Cout <= 64.
+//   grid ceil(Ktot / 4), block 256 (4 modes)
+template <int NB>
+__global__ void __launch_bounds__(256) k_mode_gemv(const float2* __restrict__ x, const float2* __restrict__ w,
+                                                   float2* __restrict__ out, int Ktot, int Cin, int Cout, int conj_w) {
+  const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= Ktot) return;
+  const float sg = conj_w ? -1.f : 1.f;
+  float2 xv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) xv[b] = lane < Cin ? x[((size_t)b * Ktot + k) * Cin + lane] : make_float2(0.f, 0.f);
+  float sr[NB], si[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { sr[b] = 0.f; si[b] = 0.f; }
+  const float2* wk = w + (size_t)k * Cin * Cout + (lane < Cout ? lane : 0);
+#pragma unroll 8
+  for (int i = 0; i < Cin; ++i) {
+    float2 wv = wk[(size_t)i * Cout];
+    wv.y *= sg;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float ax = __shfl(xv[b].x, i, 64), ay = __shfl(xv[b].y, i, 64);
+      sr[b] = fmaf(ax, wv.x, sr[b]); sr[b] = fmaf(-ay, wv.y, sr[b]);
+      si[b] = fmaf(ax, wv.y, si[b]); si[b] = fmaf(ay, wv.x, si[b]);
+    }
+  }
+  if (lane < Cout) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[((size_t)b * Ktot + k) * Cout + lane] = make_float2(sr[b], si[b]);
+  }
+}
+// adjoint with the forward's weights: out[b][k][i] = sum_o g[b][k][o] conj(W[k][i][o]).  A workgroup owns one mode; the
+// (Cin, Cout) block is copied into a padded LDS tile along its rows (coalesced), then lane i walks its own row.
+//   grid Ktot, block 256, LDS Cin * (Cout + 1) float2
+template <int NB>
+__global__ void __launch_bounds__(256) k_mode_gemv_t(const float2* __restrict__ g, const float2* __restrict__ w,
+                                                     float2* __restrict__ out, int Ktot, int Cin, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* t = reinterpret_cast<float2*>(smem);       // [Cin][Cout + 1]
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const float2* wk = w + (size_t)k * Cin * Cout;
+  for (int e = tid; e < Cin * Cout; e += 256) t[(e / Cout) * (Cout + 1) + e % Cout] = wk[e];
+  __syncthreads();
+  if (tid >= 64) return;
+  float2 gv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) gv[b] = tid < Cout ? g[((size_t)b * Ktot + k) * Cout + tid] : make_float2(0.f, 0.f);
+  float sr[NB], si[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { sr[b] = 0.f; si[b] = 0.f; }
+  const float2* row = t + (tid < Cin ? tid : 0) * (Cout + 1);
+#pragma unroll 8
+  for (int o = 0; o < Cout; ++o) {
+    const float2 wv = row[o];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float ax = __shfl(gv[b].x, o, 64), ay = __shfl(gv[b].y, o, 64);
+      sr[b] = fmaf(ax, wv.x, sr[b]); sr[b] = fmaf(ay, wv.y, sr[b]);        // g * conj(w)
+      si[b] = fmaf(ay, wv.x, si[b]); si[b] = fmaf(-ax, wv.y, si[b]);
+    }
+  }
+  if (tid < Cin) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) out[((size_t)b * Ktot + k) * Cin + tid] = make_float2(sr[b], si[b]);
+  }
+}
+// dW[k][i][o] = sum_b conj(X[b][k][i]) G[b][k][o]: an outer product per mode, pure write streaming.
+//   grid ceil(Ktot / 4), block 256 (wave = mode, lane = o)
+template <int NB>
+__global__ void __launch_bounds__(256) k_mode_outer_dw(const float2* __restrict__ x, const float2* __restrict__ g,
+                                                       float2* __restrict__ dw, int Ktot, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= Ktot) return;
+  float2 xv[NB], gv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    xv[b] = lane < Cin ? x[((size_t)b * Ktot + k) * Cin + lane] : make_float2(0.f, 0.f);
+    gv[b] = lane < Cout ? g[((size_t)b * Ktot + k) * Cout + lane] : make_float2(0.f, 0.f);
+  }
+  float2* dk = dw + (size_t)k * Cin * Cout + lane;
+#pragma unroll 8
+  for (int i = 0; i < Cin; ++i) {
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float ax = __shfl(xv[b].x, i, 64), ay = __shfl(xv[b].y, i, 64);
+      sr = fmaf(ax, gv[b].x, sr); sr = fmaf(ay, gv[b].y, sr);              // conj(x) * g
+      si = fmaf(ax, gv[b].y, si); si = fmaf(-ay, gv[b].x, si);
+    }
+    if (lane < Cout) dk[(size_t)i * Cout] = make_float2(sr, si);
+  }
+}
+
 // dW[k][i][o] = sum_b conj(X[b][k][i]) * G[b][k][o]
 __global__ void __launch_bounds__(256) k_mode_gemm_dw(const float2* __restrict__ x, const float2* __restrict__ g,
                                                       float2* __restrict__ dw, int B, int Ktot, int Cin, int Cout) {
