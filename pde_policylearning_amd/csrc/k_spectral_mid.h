@@ -20,15 +20,25 @@
 // are all in flight together) and combined through LDS.  twT rows are
 // wave-uniform and NR is a compile-time constant -> wide scalar loads, no per-element guards.
 //   block (64, SEGS), grid (ceil(inner/64), outer)
-template <int NR, int SEGS = 8>
+template <int NR, int SEGS = 8, bool TLDS = false>
 __global__ void __launch_bounds__(64 * SEGS) k_axis_fwd(const float2* __restrict__ in, float2* __restrict__ out,
-                                                        const float2* __restrict__ twT, int n_in, int inner) {
+                                                        const float2* __restrict__ twT_g, int n_in, int inner) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* sh = reinterpret_cast<float2*>(smem);     // [SEGS][NR][64]
   const int ql = threadIdx.x;
   const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
+  // TLDS (wide kept extents): the (n_in, NR) table is copied into LDS first - it shares the space with the partial sums,
+  // which are only written after the sweep.  A table row of 40 complex values is five 16-dword scalar loads; with ~100
+  // SGPRs only one row is in flight per wave and the sweep waits on the scalar cache for every n (the table does not fit
+  // it), whereas broadcast LDS reads pipeline freely.
+  const float2* twT = twT_g;
+  if constexpr (TLDS) {
+    for (int i = threadIdx.y * 64 + threadIdx.x; i < n_in * NR; i += 64 * SEGS) sh[i] = twT_g[i];
+    __syncthreads();
+    twT = sh;
+  }
   float2 acc[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = make_float2(0.f, 0.f);
@@ -56,6 +66,7 @@ __global__ void __launch_bounds__(64 * SEGS) k_axis_fwd(const float2* __restrict
       }
     }
   }
+  if constexpr (TLDS) __syncthreads();              // every wave is done reading the table
 #pragma unroll
   for (int r = 0; r < NR; ++r) sh[(seg * NR + r) * 64 + ql] = acc[r];
   __syncthreads();
@@ -73,13 +84,21 @@ __global__ void __launch_bounds__(64 * SEGS) k_axis_fwd(const float2* __restrict
 // Each thread holds its column's NK inputs in registers and sweeps its share of r (16 waves per
 // block share the sweep); tw rows are wave-uniform, NK compile-time -> wide scalar loads.
 //   block (64, SEGS), grid (ceil(inner/64), outer); SEGS = 16, or 8 when NK > 24 (register budget of the NK inputs)
-template <int NK, int SEGS = 16>
+template <int NK, int SEGS = 16, bool TLDS = false>
 __global__ void __launch_bounds__(64 * SEGS) k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
-                                                   const float2* __restrict__ tw, int n_out, int inner) {
+                                                   const float2* __restrict__ tw_g, int n_out, int inner) {
   const int ql = threadIdx.x;
   const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int q = blockIdx.x * 64 + ql;
   const int o = blockIdx.y;
+  const float2* tw = tw_g;
+  if constexpr (TLDS) {        // the (n_out, NK) table through LDS instead of the scalar cache (see k_axis_fwd)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* tws = reinterpret_cast<float2*>(smem);
+    for (int i = threadIdx.y * 64 + threadIdx.x; i < n_out * NK; i += 64 * SEGS) tws[i] = tw_g[i];
+    __syncthreads();
+    tw = tws;
+  }
   if (q >= inner) return;
   float2 v[NK];
 #pragma unroll
