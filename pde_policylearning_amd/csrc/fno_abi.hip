@@ -72,11 +72,23 @@ extern "C" int fno_debug_trace_dump(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+// events come from a pool that survives fno_profile_reset(): creating two events per launch inside the profiled steps
+// slows the host enough to leave gaps between the kernels (the measured durations then carry the ramp of an idle GPU)
+static std::vector<hipEvent_t> g_evpool;
+static size_t g_evused = 0;
+static hipEvent_t prof_event() {
+  if (g_evused == g_evpool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    g_evpool.push_back(e);
+  }
+  return g_evpool[g_evused++];
+}
 extern "C" void fno_profile_enable(int on) { g_prof = on != 0; }
 extern "C" void fno_profile_reset(void) {
-  for (auto& r : g_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   g_recs.clear();
   g_agg.clear();
+  g_evused = 0;
 }
 static void prof_aggregate() {
   if (g_recs.empty()) return;
@@ -88,10 +100,9 @@ static void prof_aggregate() {
     auto it = idx.find(r.name);
     if (it == idx.end()) { idx[r.name] = g_agg.size(); g_agg.push_back({r.name, ms, 1}); }
     else { g_agg[it->second].ms += ms; g_agg[it->second].n += 1; }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
   }
   g_recs.clear();
+  g_evused = 0;
 }
 extern "C" int fno_profile_count(void) { prof_aggregate(); return (int)g_agg.size(); }
 extern "C" int fno_profile_get(int i, const char** name, float* total_ms, int* launches) {
@@ -119,8 +130,8 @@ static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 bloc
   ProfRec rec;
   if (g_prof) {
     rec.name = name;
-    hipEventCreate(&rec.a);
-    hipEventCreate(&rec.b);
+    rec.a = prof_event();
+    rec.b = prof_event();
     hipEventRecord(rec.a, st);
   }
   hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<KArgs>(args)...);
