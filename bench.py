@@ -49,8 +49,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r01_v25_pmc_traffic.json"
-PMC_SQ_CSV = "r01_v25_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r01_v26_pmc_traffic.json"
+PMC_SQ_CSV = "r01_v26_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def kernel_model(cfg):
