@@ -799,6 +799,7 @@ struct FnoModelPlan {
   Tables t;
   int NPX;      // pixels per workgroup tile (128 or 256)
   bool loose;   // rows do not tile the pixel tile (last dim 96, 160, 73, ...): spectral rows gathered per tile, separate row-DFT passes
+  mutable bool u0_skipped = false;   // the last forward pass left u_0 (the lifting output) unwritten: block 0 recomputes it
   int ncu;      // compute units of the device the plan was made on
 };
 
@@ -992,12 +993,21 @@ static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const Pw
   }
   return fail(FNO_EUNSUPPORTED, "lifting %d -> %d", p->d.Cin, C);
 }
+// block 0 of a model with a lifting layer computes u_0 = W_l x + b_l itself (forward on load, backward from the input rows it
+// stages anyway) when both of its kernels are the split-precision 128-pixel ones: u_0 then never travels through HBM
+static const int g_no_lift_fuse = getenv("FNO_NO_LIFT_FUSE") ? 1 : 0;      // A/B switch
+static bool lift_fused(const FnoModelPlan* p) {
+  return !g_no_lift_fuse && p->d.Cin > 0 && g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !p->loose;
+}
 template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
                      (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
   if (p->loose)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+                  lds, st, a);
+  if (a.lw)
+    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   if (p->NPX == 128)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
@@ -1036,6 +1046,12 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       ldsl = base + kch * per_mode;
     }
     return launch("k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+  }
+  if (a.lw) {
+    if (!(g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024))
+      return fail(FNO_EUNSUPPORTED, "block 0 cannot recompute the lifting in this GEMM mode (the forward pass skipped u_0)");
+    return launch("k_block_bwd", k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+                  bbwd_x3_lds(C, 128, a), st, a);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
     return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
@@ -1140,7 +1156,8 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     // lifting (tfno.py:19-20) + row DFT of its output
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
-    a.u = u; a.x1 = p->loose ? nullptr : w.x1; a.tfwd = p->t.tfwd_f;
+    p->u0_skipped = lift_fused(p);
+    a.u = p->u0_skipped ? nullptr : u; a.x1 = p->loose ? nullptr : w.x1; a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
@@ -1157,6 +1174,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     LAUNCHCHK(spectral_mid_fwd(p, st, B, w, wps + (size_t)l * s.n_wp, hats + (size_t)l * s.n_hat));
     memset(&a, 0, sizeof(a));
     a.x = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act;
+    if (l == 0 && has_lift && p->u0_skipped) { a.x = x; a.lw = prm->lift_w; a.lb = prm->lift_b; a.CL = d.Cin; }
     a.w = prm->skip_w[l];
     a.bias = prm->spec_bias ? prm->spec_bias + (size_t)l * C : nullptr;
     a.z = w.z; a.tinv = p->t.tinv_f;
@@ -1285,6 +1303,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_l; a.db_part = db_part_l;
     a.xin = (l == 0 && has_lift) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
+    if (l == 0 && has_lift && p->u0_skipped) { a.lw = prm->lift_w; a.lb = prm->lift_b; }
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;

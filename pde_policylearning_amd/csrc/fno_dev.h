@@ -225,6 +225,50 @@ struct SplitTilePrefetch {
   }
 };
 
+FNO_DEV float4 ld4(const float* p);
+// lifting parameters lw (C, CL), lb (C) -> LDS [C][4] (zero-padded columns) + [C]
+template <int C>
+FNO_DEV void stage_lift_params(float* lws, const float* lw, const float* lb, int CL, int tid, int nt) {
+  for (int i = tid; i < 4 * C; i += nt) lws[i] = (i & 3) < CL ? lw[(i >> 2) * CL + (i & 3)] : 0.f;
+  for (int i = tid; i < C; i += nt) lws[4 * C + i] = lb[i];
+}
+// The same LDS image for block 0 of a model with a lifting layer, computed instead of loaded: the tile is
+// u_0 = W_l x + b_l of the <= 4-channel model input (tfno.py:11-20), so the 64-channel u_0 is never written to or read from
+// HBM.  px = idx % NPX with NT a multiple of NPX: a thread's items all sit on ONE pixel, whose CL input values are loaded
+// once; lw (C, CL) and lb (C) are wave-uniform per item (cg) and come through the scalar cache.
+template <int NPX, int NT, int C>
+struct LiftSplitTilePrefetch {
+  using S = SplitTilePrefetch<NPX, NT, C>;
+  static_assert(NT % NPX == 0 && S::ITEMS % NT == 0, "one pixel per thread");
+  float xin[4];
+  FNO_DEV void issue(const float* src, size_t row_stride, int CL, int tid) {
+    const int px = tid % NPX;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xin[k] = k < CL ? src[(size_t)k * row_stride + px] : 0.f;
+  }
+  // lws: LDS copy of the lifting parameters, [C][4] weights (columns >= CL zero) followed by [C] biases (stage_lift_params)
+  FNO_DEV void commit(unsigned short* xb, const float* lws, int tid) {
+#pragma unroll
+    for (int i = 0; i < S::ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int px = idx % NPX, cg = idx / NPX;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        const float4 wv = ld4(lws + 4 * c);
+        v[j] = fmaf(wv.w, xin[3], fmaf(wv.z, xin[2], fmaf(wv.y, xin[1], fmaf(wv.x, xin[0], lws[4 * C + c]))));
+      }
+      bf16x8 h, m, l;
+      split3x8(v, h, m, l);
+      unsigned short* dst = xb + px * S::PBH + cg * 8;
+      st8h(dst, h);
+      st8h(dst + S::TERM, m);
+      st8h(dst + 2 * S::TERM, l);
+    }
+  }
+};
+
 // Spectral K-extension for rows that do not tile the workgroup's pixel tile ("loose rows": odd row lengths such as the
 // PINO observers' padded T axis, W >= 32): acc[c][px] += sum_s Z[row(px)][s][c] . T[s][w(px)] for one 32-pixel block that
 // starts at flattened plane index f.  A block overlaps at most two rows; each gets its own pass with the table column

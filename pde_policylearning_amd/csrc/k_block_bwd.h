@@ -40,6 +40,8 @@ struct BlkBwdArgs {
   int PW, W, P, K2in, K2out, NJ;
   int act_in;
   int loose;           // rows do not tile the pixel tile (see PwFwdArgs.loose); k_block_bwd_x3 only
+  const float* lw;     // LIFT variant of k_block_bwd_x3 (block 0 of a model with a lifting layer): u_0 = lw xin + lb is
+  const float* lb;     // recomputed from the model input instead of read (lw (C, CL), lb (C)); uin is ignored
   int kch;             // loose rows: kept last-dim modes per K-extension chunk (0 = all at once); the spectral rows and
                        // the table of a chunk are staged right before it is applied, so many kept modes still fit LDS
   int tiles_per_plane, ntiles;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 //   R3   fp32 C x PITCH: g as loaded (for dbias and the pixel-major split pass), later the gout tile
 // Per tile:  commit (GELU, row-major splits) | dW GEMM + dbias | split pass + dg | dx GEMM, x gelu',
 // gout store | row DFT / lifting gradients - five barriers, as in the fp32 kernel.
-template <int C, int NPX, bool LOOSE = false>
+template <int C, int NPX, bool LOOSE = false, bool LIFT = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_block_bwd_x3(BlkBwdArgs a) {
   using Cfg = BlkBwdCfg<C, NPX>;
   constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
@@ -337,12 +339,22 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 
   using PF = TilePrefetch<NPX, NT, C, C>;
   PF pfg, pfu;
+  float4 xl[4];                  // LIFT: the lifting input under this thread's pixel group
+  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
+  if constexpr (LIFT) { stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT); __syncthreads(); }
+  static_assert(!LIFT || NT % (NPX / 4) == 0, "LIFT: one pixel group per thread");
   float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, tid);
-    pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
+    if constexpr (LIFT) {     // this thread's 4 pixels of the <= 4 input rows (q = tid % (NPX / 4) for all its items)
+      const float* xb = a.xin + (size_t)b * a.CL * a.PW + px0 + 4 * (tid % (NPX / 4));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xl[k] = k < a.CL ? ld4(xb + (size_t)k * a.PW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
+    }
     if (tid < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
@@ -373,7 +385,20 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
       const float4 gv = pfg.v[i];
       st4(r3 + c * PITCH + 4 * q, gv);
       put_row4(gr, c, q, gv);
-      float4 uv = pfu.v[i];
+      float4 uv;
+      if constexpr (LIFT) {      // u_0 = W_l x + b_l, never stored by the forward pass
+        const float bc = lws[4 * C + c];
+        const float4 wv = ld4(lws + 4 * c);
+        const float wk[4] = {wv.x, wv.y, wv.z, wv.w};
+        uv = make_float4(bc, bc, bc, bc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uv.x = fmaf(wk[k], xl[k].x, uv.x); uv.y = fmaf(wk[k], xl[k].y, uv.y);
+          uv.z = fmaf(wk[k], xl[k].z, uv.z); uv.w = fmaf(wk[k], xl[k].w, uv.w);
+        }
+      } else {
+        uv = pfu.v[i];
+      }
       if (a.act_in) {
         gelu_both(uv.x, uv.x, dgv[i].x);
         gelu_both(uv.y, uv.y, dgv[i].y);

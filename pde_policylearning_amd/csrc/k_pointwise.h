@@ -44,6 +44,9 @@ struct PwFwdArgs {
   int PW, W, P, K2in, K2out, NJ;
   int act_in, act_out;
   int loose;          // rows do not tile the pixel tile (W >= 32, any remainder): spectral rows per tile vary, no x1 epilogue
+  const float* lw;    // LIFT variant of k_pw_fwd_x3 (block 0 computes u_0 = lw x + lb itself): lifting weight (C, CL) ...
+  const float* lb;    // ... and bias (C); x is then the (B, CL, PW) model input
+  int CL;
   int tiles_per_plane, ntiles;
 };
 
@@ -223,7 +226,7 @@ static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ
 // NTW = 32-pixel column tiles per wave.  NTW = 2 halves the workgroup (4 waves at C = 64, NPX = 128)
 // so that TWO workgroups share a CU at the same 256-VGPR budget per wave: their phases (split /
 // MFMA / epilogue / row DFT) drift apart and the matrix pipe of one overlaps the VALU work of the other.
-template <int C, int NPX, int NTW, bool LOOSE = false>
+template <int C, int NPX, int NTW, bool LOOSE = false, bool LIFT = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;
   constexpr int NTG = NTN / NTW;          // wave groups along the pixel dimension
@@ -269,11 +272,16 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     return a.z ? nrows * a.K2in * C / 2 : 0;
   };
   PF pf;
+  LiftSplitTilePrefetch<NPX, NT, C> pfl;
+  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
+  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);     // visible after the first tile's barrier? no: sync here
+  if constexpr (LIFT) __syncthreads();
   float4 zpf = make_float4(0.f, 0.f, 0.f, 0.f);
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, tid);
+    if constexpr (LIFT) pfl.issue(a.x + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, tid);
+    else pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, tid);
     if (tid < zc4(px0)) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
@@ -284,7 +292,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
-    pf.commit(xb, a.act_in != 0, tid);
+    if constexpr (LIFT) pfl.commit(xb, lws, tid);
+    else pf.commit(xb, a.act_in != 0, tid);
     const int zcount4 = zc4(px0);
     if (tid < zcount4) st4(zs + 4 * tid, zpf);
     for (int i = tid + NT; i < zcount4; i += NT)   // rare tail (small workgroups): straight from L2
