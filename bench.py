@@ -49,8 +49,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r01_v26_pmc_traffic.json"
-PMC_SQ_CSV = "r01_v26_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r01_v27_pmc_traffic.json"
+PMC_SQ_CSV = "r01_v27_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def kernel_model(cfg):
@@ -263,7 +263,8 @@ def main():
                 if pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
                     pt = pj["kernels"]
                     base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
-                    key = next(k for k in pt if k.split("<")[0] in (base, base + "_x3"))
+                    cands = [k for k in pt if k.split("<")[0] in (base, base + "_x3")]
+                    key = next((k for k in cands if not k.endswith(", true>")), cands[0])   # not the block-0 LIFT variants
                     roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                                   "separate passes, corrected; same command and workload)")
