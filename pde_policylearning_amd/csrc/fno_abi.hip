@@ -692,7 +692,7 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, const f
     while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
     const size_t lds2 = (size_t)C * (rb * g.W + 1) * 4;
     static const int chan_mfma = getenv("FNO_ROW_INV_VALU") ? 0 : 1;
-    if (chan_mfma && C % 32 == 0 && g.W <= 128) {            // truncated inverse DFT on the fp32 matrix cores
+    if (chan_mfma && C % 32 == 0 && g.W >= 32 && g.W <= 128) {   // truncated inverse DFT on the fp32 matrix cores (short rows would waste the 32-column tiles)
       const size_t tabb = (size_t)2 * g.Klast * (((g.W + 31) / 32) * 32 + 4) * 4;
       static const int flat = getenv("FNO_ROW_INV_ROWTILES") ? 0 : 1;
       const size_t ldsf = (size_t)C * (ROWFLAT_CH + 4) * 4 + tabb;
