@@ -304,7 +304,7 @@ static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2
     static const int tlds = getenv("FNO_AXIS_TABLE_SMEM") ? 0 : 1;       // A/B switch: table rows through the scalar cache
     static const int tmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
     const size_t red = (size_t)SEGS * NS * 64 * 8, tab = (size_t)n_in * NS * 8;
-    if (tlds && NS >= tmin && std::max(red, tab) <= 96 * 1024)
+    if (tlds && NS >= tmin && (NS >= 32 || n_in >= 64) && std::max(red, tab) <= 96 * 1024)      // short sweeps: the copy does not pay
       return launch("k_axis_fwd", k_axis_fwd<NS, SEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), std::max(red, tab), st,
                     in, out, tw, n_in, inner);
     return launch("k_axis_fwd", k_axis_fwd<NS, SEGS>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), red, st, in, out, tw, n_in,
@@ -313,7 +313,7 @@ static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2
   constexpr int ISEGS = NS > 24 ? 8 : 16;
   static const int itlds = getenv("FNO_AXIS_TABLE_SMEM") ? 0 : 1;
   static const int itmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
-  if (itlds && NS >= itmin && (size_t)n_out * NS * 8 <= 96 * 1024)
+  if (itlds && NS >= itmin && (NS >= 32 || n_out >= 64) && (size_t)n_out * NS * 8 <= 96 * 1024)
     return launch("k_axis_inv", k_axis_inv<NS, ISEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), (size_t)n_out * NS * 8,
                   st, in, out, tw, n_out, inner);
   return launch("k_axis_inv", k_axis_inv<NS, ISEGS>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), 0, st, in, out, tw,
