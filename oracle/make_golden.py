@@ -268,6 +268,53 @@ def gen_fno_models(outdir):
              shapes={k: np.array(v.shape) for k, v in model.state_dict().items()})
 
 
+def gen_fno_models_fp64(outdir):
+    """Error-budget vectors for the three full-model fixtures: the same inputs and parameters evaluated in float64.
+
+    The reference itself cannot run in float64: FactorizedSpectralConv.forward hard-codes `x.float()` before the
+    transform and a `torch.cfloat` output spectrum (neuralop/models/spectral_convolution.py:324, :326).  The float64
+    evaluation is therefore oracle/fno_oracle.py::fno_forward (pinned bit-for-bit to the reference in float32 by the
+    fixtures above) on float64 copies of the SAME float32 inputs / parameters.  Stored next to it: how far the
+    reference's OWN float32 result is from that float64 value, per parameter (`ref32_err`), which is the budget the
+    GPU tests compare the engine's error against (tests/test_parity_gpu.py::test_fno_model_fp64_error_budget)."""
+    from neuralop.models import FNO2d, FNO3d
+    from oracle import fno_oracle as O
+    cfgs = {
+        "fno2d_cfg1": (FNO2d, (8, 8, 32), (4, 3, 64, 64)),
+        "fno2d_cfg2small": (FNO2d, (12, 12, 64), (2, 3, 128, 128)),
+        "fno3d_small": (FNO3d, (8, 8, 8, 32), (1, 3, 32, 32, 32)),
+    }
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64).reshape(-1)
+        b = np.asarray(b, np.float64).reshape(-1)
+        return float(np.sqrt(((a - b) ** 2).sum()) / np.sqrt((b ** 2).sum()))
+    for cname, (ctor, args, shp) in cfgs.items():
+        torch.manual_seed(0)
+        model = ctor(*args, in_channels=3, out_channels=1)
+        refill_parameters(model)
+        x = input_fill(cname + ".x", shp)
+        tgt = input_fill(cname + ".target", (shp[0], 1, *shp[2:]))
+        y32 = model(x)
+        l32 = _lp_rel_sum(y32, tgt)
+        l32.backward()
+        g32 = grads_of(model)
+        p64 = {k: v.detach().double().requires_grad_(True) for k, v in model.state_dict().items()}
+        y64 = O.fno_forward(p64, x.double(), args[:-1])
+        l64 = O.lp_loss_rel_sum(y64, tgt.double())
+        l64.backward()
+        g64 = {k: p64[k].grad.numpy() for k in g32}
+        ref32_err = {k: np.array([rel(g32[k], g64[k])]) for k in g32}
+        gnorm64 = {k: np.array([np.sqrt((g64[k] ** 2).sum())]) for k in g64}
+        # same subsets as the float32 fixtures: small parameters whole, a leading slab of the big spectral weights
+        keep = {k: (v if v.size <= 20000 else v.reshape(-1)[:4096].copy()) for k, v in g64.items()}
+        print(f"    {cname}: y ref32-vs-fp64 {rel(y32.detach().numpy(), y64.detach().numpy()):.2e}; "
+              f"worst grad {max(float(v[0]) for v in ref32_err.values()):.2e}")
+        save(os.path.join(outdir, f"{cname}_fp64.npz"), y64=y64, loss64=np.array([float(l64.detach())]), grads64=keep,
+             gnorm64=gnorm64, ref32_err=ref32_err,
+             y_ref32_err=np.array([rel(y32.detach().numpy(), y64.detach().numpy())]))
+
+
 def gen_observer_adam(outdir):
     """Trainer counterpart of run_pde_observers.py:185-193 (FNO2dObserver, LpLoss sum,
     Adam lr 1e-3 wd 1e-4): 3 steps, record the loss trajectory."""
@@ -528,7 +575,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_fno_models_fp64, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

@@ -305,7 +305,7 @@ static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2
     static const int tmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
     const size_t red = (size_t)SEGS * NS * 64 * 8, tab = (size_t)n_in * NS * 8;
     if (tlds && NS >= tmin && (NS >= 32 || n_in >= 64) && std::max(red, tab) <= 96 * 1024)      // short sweeps: the copy does not pay
-      return launch("k_axis_fwd", k_axis_fwd<NS, SEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), std::max(red, tab), st,
+      return launch("k_axis_fwd_tlds", k_axis_fwd<NS, SEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), std::max(red, tab), st,
                     in, out, tw, n_in, inner);
     return launch("k_axis_fwd", k_axis_fwd<NS, SEGS>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), red, st, in, out, tw, n_in,
                   inner);
@@ -314,7 +314,7 @@ static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2
   static const int itlds = getenv("FNO_AXIS_TABLE_SMEM") ? 0 : 1;
   static const int itmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
   if (itlds && NS >= itmin && (NS >= 32 || n_out >= 64) && (size_t)n_out * NS * 8 <= 96 * 1024)
-    return launch("k_axis_inv", k_axis_inv<NS, ISEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), (size_t)n_out * NS * 8,
+    return launch("k_axis_inv_tlds", k_axis_inv<NS, ISEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), (size_t)n_out * NS * 8,
                   st, in, out, tw, n_out, inner);
   return launch("k_axis_inv", k_axis_inv<NS, ISEGS>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), 0, st, in, out, tw,
                 n_out, inner);
@@ -375,20 +375,20 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
     if (!trans_w) {
       const dim3 grid((Ktot + 3) / 4), blk(256);
       switch (B) {
-        case 1: return launch("k_mode_gemm", k_mode_gemv<1>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
-        case 2: return launch("k_mode_gemm", k_mode_gemv<2>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
-        case 3: return launch("k_mode_gemm", k_mode_gemv<3>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
-        default: return launch("k_mode_gemm", k_mode_gemv<4>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        case 1: return launch("k_mode_gemv", k_mode_gemv<1>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        case 2: return launch("k_mode_gemv", k_mode_gemv<2>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        case 3: return launch("k_mode_gemv", k_mode_gemv<3>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
+        default: return launch("k_mode_gemv", k_mode_gemv<4>, grid, blk, 0, st, xx, ww, oo, Ktot, Cin, Cout, conj_w);
       }
     } else if (conj_w) {
       // here `Cin` counts the channels of x (= the forward's Cout) and the stored block is (Cout, Cin) = forward (Cin_f, Cout_f)
       const dim3 grid(Ktot), blk(256);
       const size_t lds = (size_t)Cout * (Cin + 1) * 8;
       switch (B) {
-        case 1: return launch("k_mode_gemm", k_mode_gemv_t<1>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
-        case 2: return launch("k_mode_gemm", k_mode_gemv_t<2>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
-        case 3: return launch("k_mode_gemm", k_mode_gemv_t<3>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
-        default: return launch("k_mode_gemm", k_mode_gemv_t<4>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        case 1: return launch("k_mode_gemv_t", k_mode_gemv_t<1>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        case 2: return launch("k_mode_gemv_t", k_mode_gemv_t<2>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        case 3: return launch("k_mode_gemv_t", k_mode_gemv_t<3>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
+        default: return launch("k_mode_gemv_t", k_mode_gemv_t<4>, grid, blk, lds, st, xx, ww, oo, Ktot, Cout, Cin);
       }
     }
   }
@@ -424,10 +424,10 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
     const float2 *xx = (const float2*)x, *gg = (const float2*)g;
     float2* dd = (float2*)dw;
     switch (B) {
-      case 1: return launch("k_mode_gemm_dw", k_mode_outer_dw<1>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
-      case 2: return launch("k_mode_gemm_dw", k_mode_outer_dw<2>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
-      case 3: return launch("k_mode_gemm_dw", k_mode_outer_dw<3>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
-      default: return launch("k_mode_gemm_dw", k_mode_outer_dw<4>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      case 1: return launch("k_mode_outer_dw", k_mode_outer_dw<1>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      case 2: return launch("k_mode_outer_dw", k_mode_outer_dw<2>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      case 3: return launch("k_mode_outer_dw", k_mode_outer_dw<3>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
+      default: return launch("k_mode_outer_dw", k_mode_outer_dw<4>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
     }
   }
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
@@ -1045,7 +1045,7 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       al.kch = kch < a.K2in ? kch : 0;
       ldsl = base + kch * per_mode;
     }
-    return launch("k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+    return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
   }
   if (a.lw) {
     if (!(g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024))

@@ -1,0 +1,119 @@
+// Is the bf16 MFMA's fp32 accumulation biased?  (a) alignment probes: C = 1, sixteen products of +-2^-25 each;
+// (b) statistics over many random tiles: SIGNED mean error of the 3-way split GEMM against fp64, for zero-mean and for
+// positive-mean operands, single accumulator vs separate accumulators for the small terms, next to the fp32 MFMA.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_bias_test.hip -o tools/mfma_bias_test.bin && tools/mfma_bias_test.bin
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ inline unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ inline float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ inline void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  h = f2bf(x); float r = x - bf2f(h);
+  m = f2bf(r); r -= bf2f(m);
+  l = f2bf(r);
+}
+#define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+__global__ void k_probe(float* out) {
+  const int lane = threadIdx.x;
+  // A[row][k] = a0 for all, B[k][col] = b0: every product a0*b0, 16 of them per output
+  for (int t = 0; t < 6; ++t) {
+    float a0 = 0.f, b0 = 0.f, c0 = 1.f;
+    switch (t) {
+      case 0: a0 = 0x1p-12f; b0 = 0x1p-13f; break;            // + 2^-25 x 16 = + 2^-21 = 4 ulp(1)
+      case 1: a0 = -0x1p-12f; b0 = 0x1p-13f; break;           // - 2^-25 x 16
+      case 2: a0 = 0x1p-12f; b0 = 0x1.8p-14f; break;          // + 0.75 * 2^-25 x 16 = 3 ulp
+      case 3: a0 = -0x1p-12f; b0 = 0x1.8p-14f; break;
+      case 4: a0 = 0x1p-12f; b0 = 0x1p-16f; break;            // 2^-28 x 16 = 2^-24 = half ulp(1)
+      case 5: a0 = 0x1p-12f; b0 = 0x1.8p-16f; break;          // 0.75 ulp in total
+    }
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = f2bf(a0); b[j] = f2bf(b0); }
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = c0;
+    acc = MF(a, b, acc);
+    if (lane == 0) out[t] = acc[0] - 1.0f;
+  }
+}
+
+// one wave per tile: C[32][32] = A[32][K] B[K][32]
+template <int VAR>
+__global__ void k_gemm(const float* A, const float* B, float* C, int K) {
+  A += (size_t)blockIdx.x * 32 * K; B += (size_t)blockIdx.x * K * 32; C += (size_t)blockIdx.x * 1024;
+  const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+  f32x16 acc, acs;
+  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acs[i] = 0.f; }
+  if (VAR == 2) {
+    for (int s = 0; s < K / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * K + 2 * s + hh], B[(2 * s + hh) * 32 + r], acc, 0, 0, 0);
+  } else {
+    for (int kb = 0; kb < K / 16; ++kb) {
+      bf16x8 a[3], b[3];
+      for (int j = 0; j < 8; ++j) {
+        const int k = kb * 16 + 8 * hh + j;
+        unsigned short h, m, l;
+        split3(A[r * K + k], h, m, l); a[0][j] = h; a[1][j] = m; a[2][j] = l;
+        split3(B[k * 32 + r], h, m, l); b[0][j] = h; b[1][j] = m; b[2][j] = l;
+      }
+      if (VAR == 0) {
+        acc = MF(a[2], b[0], acc); acc = MF(a[0], b[2], acc); acc = MF(a[1], b[1], acc);
+        acc = MF(a[1], b[0], acc); acc = MF(a[0], b[1], acc); acc = MF(a[0], b[0], acc);
+      } else if (VAR == 1) {      // small terms (weights 2^-16, 2^-8) in their own accumulator
+        acs = MF(a[2], b[0], acs); acs = MF(a[0], b[2], acs); acs = MF(a[1], b[1], acs);
+        acs = MF(a[1], b[0], acs); acs = MF(a[0], b[1], acs); acc = MF(a[0], b[0], acc);
+      } else if (VAR == 3) {      // three accumulators by weight
+        acs = MF(a[2], b[0], acs); acs = MF(a[0], b[2], acs); acs = MF(a[1], b[1], acs);
+        f32x16& am = *(&acs);     // (placeholder, same as VAR 1 for 2^-16 terms)
+        (void)am;
+        acc = MF(a[0], b[0], acc);
+        acs = MF(a[1], b[0], acs); acs = MF(a[0], b[1], acs);
+      }
+    }
+    for (int i = 0; i < 16; ++i) acc[i] += acs[i];
+  }
+  for (int i = 0; i < 16; ++i) C[((i & 3) + 8 * (i >> 2) + 4 * hh) * 32 + r] = acc[i];
+}
+
+int main() {
+  float* dout; hipMalloc(&dout, 64);
+  hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dout);
+  float po[6]; hipMemcpy(po, dout, 24, hipMemcpyDeviceToHost);
+  const char* nm[6] = {"16 x +2^-25 (exact +4 ulp)", "16 x -2^-25 (exact -4 ulp = -8 half-ulps)", "16 x +0.75*2^-25 (exact +3 ulp)",
+                       "16 x -0.75*2^-25", "16 x +2^-28 (exact +0.5 ulp)", "16 x +1.5*2^-28 (exact +0.75 ulp)"};
+  for (int t = 0; t < 6; ++t) printf("probe %d: C=1, %-44s -> result - 1 = %+.4f ulp(2^-23)\n", t, nm[t], po[t] / 0x1p-23f);
+
+  const int T = 2048;
+  for (int K : {64, 128}) for (int dist = 0; dist < 3; ++dist) {
+    std::vector<float> A((size_t)T * 32 * K), B((size_t)T * K * 32);
+    std::mt19937 rng(7); std::normal_distribution<float> nd(0.f, 1.f);
+    // dist 0: both zero-mean; 1: B positive (|N|), A zero-mean; 2: both positive
+    for (auto& v : A) { v = nd(rng) * 0.3f; if (dist == 2) v = fabsf(v); }
+    for (auto& v : B) { v = nd(rng); if (dist >= 1) v = fabsf(v); }
+    float *dA, *dB, *dC; hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, (size_t)T * 4096);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+    std::vector<double> ref((size_t)T * 1024);
+    for (int t = 0; t < T; ++t) for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+      double s = 0; for (int k = 0; k < K; ++k) s += (double)A[((size_t)t * 32 + i) * K + k] * B[((size_t)t * K + k) * 32 + j];
+      ref[(size_t)t * 1024 + i * 32 + j] = s;
+    }
+    std::vector<float> C((size_t)T * 1024);
+    for (int var = 0; var < 3; ++var) {
+      if (var == 0) hipLaunchKernelGGL(k_gemm<0>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 1) hipLaunchKernelGGL(k_gemm<1>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 2) hipLaunchKernelGGL(k_gemm<2>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+      double se = 0, se2 = 0, sr2 = 0, sabs = 0, sref = 0;
+      for (size_t i = 0; i < C.size(); ++i) { const double e = C[i] - ref[i]; se += e; se2 += e * e; sr2 += ref[i] * ref[i]; sabs += fabs(ref[i]); sref += ref[i]; }
+      printf("K=%3d dist=%d %-26s rel-L2 %.3e   sum(err)/sum|ref| %+.3e   sum(err)/|sum(ref)| %+.3e\n", K, dist,
+             var == 0 ? "x3 one accumulator" : var == 1 ? "x3 small terms separate" : "fp32 MFMA", sqrt(se2 / sr2), se / sabs, se / fabs(sref));
+    }
+    hipFree(dA); hipFree(dB); hipFree(dC);
+  }
+  return 0;
+}
