@@ -14,6 +14,7 @@
 
 #include "../../include/fnoengine.h"
 #include "k_block_bwd.h"
+#include "k_block_bwd2.h"
 #include "k_chanflow.h"
 #include "k_pointwise.h"
 #include "k_projection.h"
@@ -1026,16 +1027,31 @@ static size_t bbwd_x3_lds(int C, int npx, const BlkBwdArgs& a) {
           (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(npx / a.W) * a.K2in * C * 2 : 0) +
           (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
 }
+// k_block_bwd_t (k_block_bwd2.h): two swizzled [3][C][128] bf16 images, the fp32 gout tile, two lifting-input buffers, tables
+static size_t bbwd_t_lds(int C, const BlkBwdArgs& a) {
+  return (size_t)6 * C * 256 +
+         ((size_t)C * 132 + (a.xin ? 2 * 8 * 132 : 0) +
+          (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(128 / a.W) * a.K2in * C * 2 : 0) +
+          (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
+}
+// k_block_bwd_g2: per group two [3][64][64] bf16 images, a 64 x 68 fp32 half-tile, the tile's spectral rows, two
+// lifting-input buffers; shared tables; two barrier counters
+static size_t bbwd_g2_lds(const BlkBwdArgs& a) {
+  return (size_t)4 * 3 * 64 * 128 +
+         ((size_t)2 * 64 * 68 + (a.zg ? (size_t)2 * (128 / a.W) * a.K2in * 64 * 2 + (size_t)2 * a.K2in * a.W : 0) +
+          (a.xin ? 2 * 2 * 8 * 68 : 0) + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0) + 4) * 4;
+}
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   const size_t pitch = p->NPX + 4;
+  static const int v1 = getenv("FNO_BBWD_V1") ? 1 : 0;        // A/B switch: the first-generation split-precision kernel
   if (p->loose) {
     if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
     BlkBwdArgs al = a;
     const int rows = 128 / a.W + 2;
     BlkBwdArgs nz = a;
     nz.zg = nullptr;
-    const size_t base = bbwd_x3_lds(C, 128, nz);                          // everything but the spectral rows and their table
+    const size_t base = v1 ? bbwd_x3_lds(C, 128, nz) : bbwd_t_lds(C, nz);   // everything but the spectral rows and their table
     const size_t per_mode = ((size_t)2 * a.W + (size_t)rows * C * 2) * 4;
     size_t ldsl = base;
     if (a.zg) {
@@ -1045,14 +1061,34 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       al.kch = kch < a.K2in ? kch : 0;
       ldsl = base + kch * per_mode;
     }
-    return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+    if (v1)
+      return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+    return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+  }
+  // C = 64, rows of 32 / 64 / 128 pixels: two independent 4-wave groups per workgroup (k_block_bwd_g2)
+  static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
+  if constexpr (C == 64) {
+    if (g_gemm_x3 && FNO_BBWD_X3 && !v1 && !no_g2 && p->NPX == 128 && (a.W == 32 || a.W == 64 || a.W == 128) &&
+        (!a.x1g || a.NJ <= 2) && a.ntiles >= 2 && bbwd_g2_lds(a) <= 160 * 1024) {
+      const int g2 = grid;      // the host sums `grid` partial slabs per output: groups without a tile write zeros
+      const size_t lds2 = bbwd_g2_lds(a);
+      const bool two = a.x1g && a.W == 128 && a.NJ == 2;
+      if (a.lw && !a.x1g && !a.gadd) return launch("k_block_bwd", k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+      // (gradient addends and two 16-output blocks per wave do not fit the register budget yet: k_block_bwd_t takes those)
+      if (!a.lw && !a.xin && !a.gadd && !two)
+        return launch("k_block_bwd", k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+    }
   }
   if (a.lw) {
     if (!(g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024))
       return fail(FNO_EUNSUPPORTED, "block 0 cannot recompute the lifting in this GEMM mode (the forward pass skipped u_0)");
+    if (!v1 && bbwd_t_lds(C, a) <= 160 * 1024)
+      return launch("k_block_bwd", k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
     return launch("k_block_bwd", k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
   }
+  if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !v1 && bbwd_t_lds(C, a) <= 160 * 1024)
+    return launch("k_block_bwd", k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
     return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);

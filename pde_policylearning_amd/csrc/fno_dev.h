@@ -33,6 +33,10 @@ FNO_DEV f32x4 mfma16(float a, float b, f32x4 c) {
 #else
 #define FNO_SIMD_PARTNER_PRIO(wave, nwaves) do { } while (0)
 #endif
+// FNO_TRACE_WHICH selects the traced kernel: 1 = projection backward, 2 = block backward (a middle block)
+#ifndef FNO_TRACE_WHICH
+#define FNO_TRACE_WHICH 1
+#endif
 #ifdef FNO_TRACE
 // Debug build only (-DFNO_TRACE): per-phase shader-clock stamps of workgroup 0, read back with
 // fno_debug_trace_dump (tools/trace_phases.py).  g_trace[wave][slot]

@@ -1,0 +1,738 @@
+// Backward of one fused FNO block, second generation ("transposed" layout).  Same mathematics, arguments and partial-slab
+// outputs as k_block_bwd_x3 (k_block_bwd.h; reference semantics: autograd of fno_block.py:123-170 +
+// spectral_convolution.py:303-347), restructured around three facts measured on gfx950:
+//   * the bf16 MFMA's fp32 accumulation is biased (tools/mfma_bias_test.hip: -1e-8 of |result| per element when small
+//     and large products share one accumulator), which the DC-type gradients (bias, k = 0 modes) amplify by sqrt(#pixels):
+//     the hh products and the five cross terms of the 3-way split now go to SEPARATE accumulators, summed once in fp32;
+//   * ds_read_b64_tr_b16 delivers a [channel][pixel] bf16 image column-wise: ONE split of g serves both GEMMs (row reads for
+//     dW, transposed reads for dx) - the pixel-major image, its fp32 staging tile, the second split pass and its two
+//     barriers are gone;
+//   * dx is computed TRANSPOSED (D[pixel][channel]: lane <-> channel, registers <-> 4-pixel runs), which is the layout the
+//     tile is loaded in (lane <-> channel row, 16-byte runs of 4 pixels): gelu'(u) stays in registers from the commit to
+//     the epilogue (no LDS round trip), the bias gradient is a lane-local sum, gout leaves as 16-byte stores.
+// Per tile: commit (GELU, one split per operand -> two swizzled images) | barrier | dW GEMM, dx GEMM + spectral
+// K-extension, x gelu', gout store, gout tile -> LDS | barrier | row DFT (or lifting gradients): two barriers instead of five.
+#pragma once
+#include "fno_dev.h"
+#include "k_block_bwd.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+// [rows][128 x bf16] image with 256-byte rows: byte offset of 16-byte chunk `ch` (8 pixels) of row `row`.  The XOR makes the
+// b128 row reads (lane <-> row), the transposed b64 reads (4 rows x 16 pixels per 16 lanes) and the b64 stores of 16
+// consecutive rows spread over the banks.
+FNO_DEV int swz_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+FNO_DEV s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+}
+FNO_DEV bf16x8 cat4(s16x4 lo, s16x4 hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+// 3-way split GEMM step with the hh products and the cross terms in separate accumulators (see above)
+FNO_DEV void mfma_x3s(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+}
+// 4 consecutive pixels of one row -> the three bf16 terms, 8 bytes each, at byte offset `off` of the three term planes
+FNO_DEV void put_split4(unsigned char* img, int term_bytes, int off, const float4& t) {
+  const float tv[4] = {t.x, t.y, t.z, t.w};
+  unsigned short hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split3(tv[j], hh[j], mm[j], ll[j]);
+  *reinterpret_cast<uint2*>(img + off) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
+  *reinterpret_cast<uint2*>(img + term_bytes + off) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
+  *reinterpret_cast<uint2*>(img + 2 * term_bytes + off) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
+}
+
+// kext_loose_rows (fno_dev.h) for the transposed accumulator: the table value rides on the A operand (lane <-> pixel), the
+// spectral row on the B operand (lane <-> channel); each lane supplies the same two values as before.
+template <int C>
+FNO_DEV f32x16 kext_loose_rows_t(f32x16 acc, const float* zs, const float* tinv_s, int K2, int W, int f, int r_lo, int mt,
+                                 int l31, int half) {
+  const int ra = f / W;
+  const int w0 = f - ra * W;
+  const int wl = w0 + l31;
+  {
+    const float* zr = zs + ((size_t)((ra - r_lo) * K2) * C + mt * 32 + l31) * 2 + half;
+    const bool in = wl < W;
+    const float* tv = tinv_s + half * W + (in ? wl : 0);
+#pragma unroll 2
+    for (int s = 0; s < K2; ++s) acc = mfma32(in ? tv[2 * s * W] : 0.f, zr[s * C * 2], acc);
+  }
+  if (w0 + 31 >= W) {
+    const float* zr = zs + ((size_t)((ra + 1 - r_lo) * K2) * C + mt * 32 + l31) * 2 + half;
+    const bool in = wl >= W;
+    const float* tv = tinv_s + half * W + (in ? wl - W : 0);
+#pragma unroll 2
+    for (int s = 0; s < K2; ++s) acc = mfma32(in ? tv[2 * s * W] : 0.f, zr[s * C * 2], acc);
+  }
+  return acc;
+}
+
+template <int C, int NPX, bool LOOSE = false, bool LIFT = false>
+__global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(BlkBwdArgs a) {
+  using Cfg = BlkBwdCfg<C, NPX>;
+  static_assert(NPX == 128, "images are 128 pixels wide");
+  constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
+  constexpr int NT = NW * 64;
+  constexpr int KB = C / 16;
+  constexpr int PITCH = NPX + 4;
+  constexpr int TERM = C * 256;                         // bytes per term plane of an image
+  constexpr int PXK = NPX / KSPLIT;
+  static_assert(PXK % 16 == 0, "dW k blocks");
+  constexpr int LJ = (C / 16 + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* gimg = reinterpret_cast<unsigned char*>(smem);       // g,          [3][C][128] bf16, swizzled
+  unsigned char* aimg = gimg + 3 * TERM;                              // a = act(u), [3][C][128] bf16, swizzled
+  float* r3 = reinterpret_cast<float*>(aimg + 3 * TERM);              // C x PITCH fp32: the gout tile (row DFT / lifting gradients)
+  float* xls = r3 + C * PITCH;                                         // 2 x 8 x PITCH: lifting input rows (block 0), by tile parity
+  float* tinv_s = xls + (a.xin ? 2 * 8 * PITCH : 0);
+  const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
+  const int KC = (LOOSE && a.kch > 0 && a.kch < a.K2in) ? a.kch : a.K2in;
+  const bool chunked = KC < a.K2in;
+  float* zs = tinv_s + (a.zg ? 2 * KC * a.W : 0);
+  float* tfwd_s = zs + (a.zg ? R * KC * C * 2 : 0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int mt = wave / NTN, nt = wave % NTN;
+  const int n0 = nt * 32;
+  const int crow = mt * 32 + l31;                       // this lane's channel row (loads, images, dx columns)
+  const int dtl = wave % TILES, dkp = wave / TILES;     // dW job
+  const int dmt = dtl / MT, dnt = dtl % MT;
+
+  if (a.zg && !chunked)
+    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
+  if (a.x1g)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  auto zc4 = [&](int px0) {
+    const int nrows = LOOSE ? (px0 + NPX - 1) / a.W - px0 / a.W + 1 : R;
+    return (a.zg && !chunked) ? nrows * a.K2in * C / 2 : 0;
+  };
+
+  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i, split into (h, m, l)
+  bf16x8 wfrag[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
+    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+  }
+  // LIFT: u_0[px][c] = sum_k x[k][px] Wl[c][k] + bl[c] as fp32 MFMAs; B[k][n = c] with k = half + 2 s, the bias rides on k = CL
+  constexpr int NKL = 3;
+  float wl[NKL];
+  if constexpr (LIFT) {
+#pragma unroll
+    for (int s = 0; s < NKL; ++s) {
+      const int k = half + 2 * s;
+      wl[s] = k < a.CL ? a.lw[crow * a.CL + k] : (k == a.CL ? a.lb[crow] : 0.f);
+    }
+  }
+
+  f32x16 dwtot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dwtot[r] = 0.0f;
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};                // channel grow0 + 8 i, this lane's 4 pixels of every tile
+  f32x4 dl[LJ];
+#pragma unroll
+  for (int j = 0; j < LJ; ++j) dl[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the NEXT tile's operands.  u in the dx accumulator's layout (row crow, pixels n0 + 8 i + 4 half .. + 3: gelu' stays in
+  // registers); g only feeds the image and the bias sums, so it comes in whole lines (8 lanes per 128-byte row segment)
+  float4 gq[4], uq[4];
+  const int grow0 = mt * 32 + (lane >> 3);
+  float xa[NKL];                // LIFT: x[k = half + 2 s][pixel n0 + l31] of the next tile
+  float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto issue = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)      // g: whole 128-byte lines per 8 lanes (row grow0 + 8 i, pixels n0 + 4 (lane & 7) ..)
+      gq[i] = ld4(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+    if constexpr (LIFT) {
+#pragma unroll
+      for (int s = 0; s < NKL; ++s) {
+        const int k = half + 2 * s;
+        xa[s] = k < a.CL ? a.xin[((size_t)b * a.CL + k) * a.PW + px0 + n0 + l31] : (k == a.CL ? 1.f : 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) uq[i] = ld4(a.uin + ro + 8 * i);
+    }
+    if (tid < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+
+  int tslot = 0, par = 0;
+  FNO_TRACE_IF(FNO_TRACE_WHICH == 2 && a.x1g != nullptr);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, par ^= 1) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    float* xlt = xls + par * 8 * PITCH;
+    FNO_STAMP(tslot + 0);
+    // ---- commit: one split per operand into the swizzled images; gelu'(u) stays in registers ----------------------
+    float4 dg[4];
+    {
+      f32x16 u0;
+      if constexpr (LIFT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u0[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NKL; ++s)
+          if (2 * s <= a.CL) u0 = mfma32(xa[s], wl[s], u0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int off = swz_off(crow, (n0 >> 3) + i) + 8 * half;
+        const float4 gv = gq[i];
+        dbsum[i] += (gv.x + gv.y) + (gv.z + gv.w);
+        put_split4(gimg, TERM, swz_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv);
+        float4 uv;
+        if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
+        else uv = uq[i];
+        if (a.act_in) {
+          gelu_both(uv.x, uv.x, dg[i].x);
+          gelu_both(uv.y, uv.y, dg[i].y);
+          gelu_both(uv.z, uv.z, dg[i].z);
+          gelu_both(uv.w, uv.w, dg[i].w);
+        }
+        put_split4(aimg, TERM, off, uv);
+      }
+    }
+    const int zcount4 = zc4(px0);
+    if (tid < zcount4) st4(zs + 4 * tid, zv);
+    for (int i = tid + NT; i < zcount4; i += NT)      // more spectral rows than threads (short rows, many modes)
+      st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
+    if (a.xin) stage_rows<NPX, NT>(xlt, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
+    FNO_STAMP(tslot + 1);
+    __syncthreads();
+    FNO_STAMP(tslot + 2);
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+
+    // ---- dW[o][i] += sum_px g[o][px] a[i][px]: row reads of both images, 8 consecutive pixels per lane ----------------
+    // (one accumulator for all six products: a per-element bias of 1e-8 is harmless here, nothing sums dW any further)
+    {
+      const int ro = dmt * 32 + l31, ri = dnt * 32 + l31;
+#pragma unroll 2
+      for (int kq = 0; kq < PXK / 16; ++kq) {
+        const int ch = dkp * (PXK / 8) + 2 * kq + half;
+        const int og = swz_off(ro, ch), oa = swz_off(ri, ch);
+        bf16x8 af[3], bf[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          af[t] = *reinterpret_cast<const bf16x8*>(gimg + t * TERM + og);
+          bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * TERM + oa);
+        }
+        dwtot = mfma_x3(af, bf, dwtot);
+      }
+    }
+    FNO_STAMP(tslot + 3);
+    // ---- dx^T[px][i] = sum_o g[o][px] W[o][i]: A = transposed reads of the g image, B = the W fragments -----------------
+    f32x16 acc;
+    {
+      f32x16 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
+      // lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p + 3 of its 4 x 16 block; groups 0 / 1 = pixels
+      // 0-15 / 16-31 of k half 0, groups 2 / 3 the same pixels of k half 1
+      const int tq = l15 >> 2, tp = l15 & 3;
+      const int px = n0 + 16 * (quad & 1) + 4 * tp;
+      const int orow = 8 * (quad >> 1) + tq;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {      // (full unroll: wfrag must be indexed statically)
+        bf16x8 af[3];
+        const int o0 = swz_off(kb * 16 + orow, px >> 3) + 2 * (px & 7);
+        const int o1 = swz_off(kb * 16 + orow + 4, px >> 3) + 2 * (px & 7);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
+        mfma_x3s(af, wfrag[kb], hi, lo);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+    }
+    if constexpr (LOOSE) {
+      if (a.zg && !chunked) acc = kext_loose_rows_t<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
+      else if (a.zg) {
+        const int r_lo = px0 / a.W, nrows = (px0 + NPX - 1) / a.W - r_lo + 1;
+        for (int k0 = 0; k0 < a.K2in; k0 += KC) {
+          const int kc = min(KC, a.K2in - k0);
+          __syncthreads();                        // every wave is done with the previous chunk (or the previous tile's last)
+          for (int i = tid; i < 2 * kc * a.W; i += NT) tinv_s[i] = a.tinv[2 * k0 * a.W + i];
+          const int per_row4 = kc * C / 2;
+          for (int i = tid; i < nrows * per_row4; i += NT) {
+            const int r = i / per_row4, rem = i - r * per_row4;
+            st4(zs + 4 * i, ld4(a.zg + (((size_t)b * a.P + r_lo + r) * a.K2in + k0) * C * 2 + 4 * rem));
+          }
+          __syncthreads();
+          acc = kext_loose_rows_t<C>(acc, zs, tinv_s, kc, a.W, px0 + n0, r_lo, mt, l31, half);
+        }
+      }
+    } else if (a.zg) {
+      const float* zr = zs + (((n0 / a.W) * a.K2in) * C + crow) * 2 + half;
+      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+#pragma unroll 2
+      for (int s = 0; s < a.K2in; ++s) acc = mfma32(tv[2 * s * a.W], zr[s * C * 2], acc);
+    }
+    FNO_STAMP(tslot + 4);
+    // ---- epilogue: (+ gradient addend) x gelu'(u), gout store, gout tile for the row DFT ---------------------------------
+    {
+      const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+      float* r3p = r3 + crow * PITCH + n0 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+        if (a.gadd) {
+          const float4 ad = ld4(a.gadd + ro + 8 * i);
+          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+        }
+        if (a.act_in) { v.x *= dg[i].x; v.y *= dg[i].y; v.z *= dg[i].z; v.w *= dg[i].w; }
+        if (a.gout) st4(a.gout + ro + 8 * i, v);
+        if (a.x1g || a.xin) st4(r3p + 8 * i, v);
+      }
+    }
+    FNO_STAMP(tslot + 5);
+    __syncthreads();          // images are free for the next commit; the gout tile is complete
+    FNO_STAMP(tslot + 6);
+    if (a.x1g) row_dft_epilogue<C, NPX, NW>(r3, tfwd_s, a.W + 4, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+    if (a.xin) {
+      // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]
+#pragma unroll
+      for (int j = 0; j < LJ; ++j) {
+        const int jm = wave + j * NW;
+        if (jm < C / 16) {
+          const float* arow = r3 + (jm * 16 + l15) * PITCH + quad;
+          const float* br = xlt + (l15 < a.CL ? l15 : 0) * PITCH + quad;
+          const float cst = l15 == a.CL ? 1.0f : 0.0f;
+          for (int s = 0; s < NPX / 4; ++s) {
+            const float bf = (l15 < a.CL) ? br[4 * s] : cst;
+            dl[j] = mfma16(arow[4 * s], bf, dl[j]);
+          }
+        }
+      }
+    }
+    FNO_STAMP(tslot + 7);
+    // no barrier here: the next commit writes the images, zs and the other xls buffer, none of which this phase reads;
+    // r3 is rewritten only behind the next tile's first barrier
+    tslot += 8;
+  }
+
+  // ---- write partial slabs ---------------------------------------------------
+  {
+    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPLIT + dkp) * C * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dwtot[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) smem[(nt * 8 + (lane & 7)) * C + grow0 + 8 * i] = dbsum[i];
+  __syncthreads();
+  if (tid < C) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8 * NTN; ++k) v += smem[k * C + tid];
+    a.db_part[(size_t)blockIdx.x * C + tid] = v;
+  }
+  if (a.xin) {
+#pragma unroll
+    for (int j = 0; j < LJ; ++j) {
+      const int jm = wave + j * NW;
+      if (jm < C / 16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          a.dwl_part[((size_t)blockIdx.x * C + jm * 16 + quad * 4 + r) * 16 + l15] = dl[j][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Two-group variant (C = 64, rows of 32 / 64 / 128 pixels).  The 8 waves of a workgroup form TWO independent groups of four
+// (waves 0-3 and 4-7: one wave of each group per SIMD).  Each group walks its own 128-pixel tiles in two 64-pixel halves
+// with its own images and its own barrier (a counter in LDS: s_barrier would tie the groups together), so that the groups
+// drift apart and one group's commit (VALU) runs beside the other's GEMMs (matrix pipe) on every SIMD - what two
+// workgroups per CU would give, at one copy of the tables and within the 160 KB of LDS.
+//   LDS: per group  g image | a image ([3][64][64] bf16 each, 128-byte rows, swizzled) | fp32 gout half-tile 64 x 68 |
+//        spectral rows | 2 x lifting-input rows;  shared: inverse / forward row tables, two barrier counters.
+// ---------------------------------------------------------------------------
+// [rows][64 x bf16] image with 128-byte rows: byte offset of 16-byte chunk `ch` (0..7) of row `row`.  Two rows share a
+// 256-byte bank row; the XOR keeps b128 row reads (16-lane groups), transposed b64 reads (4 rows x 16 pixels) conflict-free
+// and b64 stores of 16 consecutive rows 2-way.
+FNO_DEV int swz64_off(int row, int ch) { return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))); }
+
+// barrier of one 4-wave group: arrive on an LDS counter, poll until all four have (epoch counts arrivals so far)
+FNO_DEV void group_barrier(unsigned* cnt, unsigned& epoch, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads / writes are done
+  epoch += 4;
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
+// LIFT: block 0 of a model with a lifting layer (u_0 recomputed from the model input, lifting gradients instead of a row DFT);
+// GADD: a gradient addend is added to dx (fan-out chains); NJP: 16-output blocks of the row DFT per wave when a row spans both halves
+template <bool LIFT = false, bool GADD = false, int NJP = 1>
+__global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
+  constexpr int C = 64, GPX = 64, KB = C / 16, PITCH = GPX + 4, XPITCH = GPX + 4;
+  constexpr int TERM = C * 128;                  // bytes per term plane
+  constexpr int IMG = 3 * TERM;                  // one image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep tile / address math scalar
+  const int grp = wave >> 2, wg = wave & 3, gtid = tid & 255;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int mt = wg >> 1, nt = wg & 1;
+  const int n0 = nt * 32;
+  const int crow = mt * 32 + l31;
+  const int R2 = 128 / a.W;                      // rows per 128-pixel tile (1, 2 or 4)
+  const int zrow_f = a.K2in * C * 2;             // floats per spectral row
+  // ---- LDS carve ----
+  unsigned char* base = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* gimg = base + grp * 2 * IMG;
+  unsigned char* aimg = gimg + IMG;
+  float* r3 = reinterpret_cast<float*>(base + 4 * IMG) + grp * C * PITCH;
+  float* after = reinterpret_cast<float*>(base + 4 * IMG) + 2 * C * PITCH;
+  float* zs = after + (a.zg ? grp * R2 * zrow_f : 0);
+  after += a.zg ? 2 * R2 * zrow_f : 0;
+  float* xls = after + (a.xin ? grp * 2 * 8 * XPITCH : 0);
+  after += a.xin ? 2 * 2 * 8 * XPITCH : 0;
+  float* tinv_s = after;
+  after += a.zg ? 2 * a.K2in * a.W : 0;
+  float* tfwd_s = after;
+  after += a.x1g ? 16 * a.NJ * (a.W + 4) : 0;
+  unsigned* bar = reinterpret_cast<unsigned*>(after) + grp;
+
+  if (a.zg)
+    for (int i = tid; i < 2 * a.K2in * a.W; i += 512) tinv_s[i] = a.tinv[i];
+  if (a.x1g)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += 512) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  if (tid < 2) reinterpret_cast<unsigned*>(after)[tid] = 0u;
+  __syncthreads();
+  unsigned epoch = 0;
+
+  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i
+  bf16x8 wfrag[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
+    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+  }
+  constexpr int NKL = 3;
+  float wl[NKL];
+  if constexpr (LIFT) {
+#pragma unroll
+    for (int s = 0; s < NKL; ++s) {
+      const int k = half + 2 * s;
+      wl[s] = k < a.CL ? a.lw[crow * a.CL + k] : (k == a.CL ? a.lb[crow] : 0.f);
+    }
+  }
+
+  f32x16 dwtot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dwtot[r] = 0.0f;
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f};                   // lifting gradients: job wg (16 channels)
+  f32x4 dft0[NJP], dft1[NJP];                         // W = 128: row-DFT accumulators of jobs wg (, wg + 4), carried over the halves
+
+  float4 gq[4], uq[4];
+  const int grow0 = mt * 32 + (lane >> 3);
+  float xa[NKL];
+  float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int zc4 = a.zg ? R2 * a.K2in * C / 2 : 0;     // float4s of spectral rows per 128-pixel tile
+  auto issue = [&](int tile, int h) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * 128 + 64 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      gq[i] = ld4(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+    if constexpr (LIFT) {
+#pragma unroll
+      for (int s = 0; s < NKL; ++s) {
+        const int k = half + 2 * s;
+        xa[s] = k < a.CL ? a.xin[((size_t)b * a.CL + k) * a.PW + px0 + n0 + l31] : (k == a.CL ? 1.f : 0.f);
+      }
+    } else {
+#ifdef FNO_EXP_UCOAL      // timing experiment only (wrong results): u in whole lines like g
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        uq[i] = ld4(a.uin + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+#else
+      const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) uq[i] = ld4(a.uin + ro + 8 * i);
+#endif
+    }
+    if (h == 0 && gtid < zc4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * zrow_f + 4 * gtid);
+  };
+  const int tile0 = blockIdx.x * 2 + grp, tstep = 2 * gridDim.x;
+  if (tile0 < a.ntiles) issue(tile0, 0);
+#ifndef FNO_G2_STAGGER
+#define FNO_G2_STAGGER 55
+#endif
+  // identical programs started together stay in lockstep (both groups in their VALU phase, then both on the matrix pipe);
+  // starting group 1 about half a period late puts its commits beside group 0's GEMMs
+  if (FNO_G2_STAGGER > 0 && grp == 1) __builtin_amdgcn_s_sleep(FNO_G2_STAGGER);
+
+  int par = 0;
+  FNO_TRACE_IF(FNO_TRACE_WHICH == 2 && a.x1g != nullptr);
+  int tslot = 0;
+  for (int tile = tile0; tile < a.ntiles; tile += tstep) {
+    const int b = tile / a.tiles_per_plane;
+    const int pxt = (tile % a.tiles_per_plane) * 128;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h, par ^= 1) {
+      const int px0 = pxt + 64 * h;
+      float* xlt = xls + par * 8 * XPITCH;
+      FNO_STAMP(tslot + 0);
+      // ---- commit ---------------------------------------------------------------------------------------------------
+      float4 dg[4];
+      {
+        f32x16 u0;
+        if constexpr (LIFT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u0[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < NKL; ++s)
+            if (2 * s <= a.CL) u0 = mfma32(xa[s], wl[s], u0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 gv = gq[i];
+          dbsum[i] += (gv.x + gv.y) + (gv.z + gv.w);
+          put_split4(gimg, TERM, swz64_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv);
+          float4 uv;
+          if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
+          else uv = uq[i];
+          if (a.act_in) {
+            gelu_both(uv.x, uv.x, dg[i].x);
+            gelu_both(uv.y, uv.y, dg[i].y);
+            gelu_both(uv.z, uv.z, dg[i].z);
+            gelu_both(uv.w, uv.w, dg[i].w);
+          }
+          put_split4(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv);
+        }
+      }
+      if (h == 0) {
+        if (gtid < zc4) st4(zs + 4 * gtid, zv);
+        for (int i = gtid + 256; i < zc4; i += 256)
+          st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + pxt / a.W) * zrow_f + 4 * i));
+      }
+      if constexpr (LIFT) {      // lifting input rows of this half: [k][64 px]
+        for (int idx = gtid; idx < a.CL * (GPX / 4); idx += 256) {
+          const int k = idx / (GPX / 4), q = idx % (GPX / 4);
+          st4(xlt + k * XPITCH + 4 * q, ld4(a.xin + ((size_t)b * a.CL + k) * a.PW + px0 + 4 * q));
+        }
+      }
+      FNO_STAMP(tslot + 1);
+      group_barrier(bar, epoch, lane);
+      FNO_STAMP(tslot + 2);
+#ifndef FNO_G2_PRIO
+#define FNO_G2_PRIO 1
+#endif
+      // the matrix-pipe phase gets issue priority over the other group's VALU phase on this SIMD: its MFMAs and LDS reads are
+      // latency-bound, the VALU stream fills the gaps (tools/simd_share_test.hip: VALU beside bf16 MFMA runs at 87 %)
+      if (FNO_G2_PRIO) __builtin_amdgcn_s_setprio(2);
+      // ---- dW[o][i] += sum_px g[o][px] a[i][px]: wave wg owns one 32 x 32 tile over the 64 pixels of the half -------------
+      {
+        const int ro = mt * 32 + l31, ri = nt * 32 + l31;
+#pragma unroll 2
+        for (int kq = 0; kq < GPX / 16; ++kq) {
+          const int ch = 2 * kq + half;
+          const int og = swz64_off(ro, ch), oa = swz64_off(ri, ch);
+          bf16x8 af[3], bf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            af[t] = *reinterpret_cast<const bf16x8*>(gimg + t * TERM + og);
+            bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * TERM + oa);
+          }
+          dwtot = mfma_x3(af, bf, dwtot);
+        }
+      }
+      FNO_STAMP(tslot + 3);
+      // ---- dx^T[px][i] = sum_o g[o][px] W[o][i] ---------------------------------------------------------------------------
+      f32x16 acc;
+      {
+        f32x16 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
+        const int tq = l15 >> 2, tp = l15 & 3;
+        const int px = n0 + 16 * (quad & 1) + 4 * tp;
+        const int orow = 8 * (quad >> 1) + tq;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          bf16x8 af[3];
+          const int o0 = swz64_off(kb * 16 + orow, px >> 3) + 2 * (px & 7);
+          const int o1 = swz64_off(kb * 16 + orow + 4, px >> 3) + 2 * (px & 7);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
+          mfma_x3s(af, wfrag[kb], hi, lo);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+      }
+      if (a.zg) {      // spectral K-extension: all table / spectrum values of a group of 4 modes are in flight together
+        const int pl = 64 * h + n0;                    // position of this wave's 32 pixels in the 128-pixel tile
+        const float* zr = zs + ((pl / a.W) * a.K2in * C + crow) * 2 + half;
+        const float* tv = tinv_s + half * a.W + pl % a.W + l31;
+        for (int s0 = 0; s0 < a.K2in; s0 += 4) {
+          float zq[4], tq4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool in = s0 + j < a.K2in;
+            zq[j] = in ? zr[(s0 + j) * C * 2] : 0.f;
+            tq4[j] = in ? tv[2 * (s0 + j) * a.W] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (s0 + j < a.K2in) acc = mfma32(tq4[j], zq[j], acc);
+        }
+      }
+      if (FNO_G2_PRIO) __builtin_amdgcn_s_setprio(0);
+      FNO_STAMP(tslot + 4);
+      // the next half's operands: issued behind the GEMMs (32 registers that must not be live beside the weight fragments and
+      // the accumulators); their latency is covered by the epilogue, the row DFT and the other group's work on this SIMD
+      {
+        const int nh = h ^ 1, ntile = h ? tile + tstep : tile;
+        if (ntile < a.ntiles) issue(ntile, nh);
+      }
+      // ---- epilogue -------------------------------------------------------------------------------------------------------
+      {
+        const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+        float* r3p = r3 + crow * PITCH + n0 + 4 * half;
+        float4 ad[4];
+        if constexpr (GADD) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ad[i] = ld4(a.gadd + ro + 8 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 v = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+          if constexpr (GADD) { v.x += ad[i].x; v.y += ad[i].y; v.z += ad[i].z; v.w += ad[i].w; }
+          if (a.act_in) { v.x *= dg[i].x; v.y *= dg[i].y; v.z *= dg[i].z; v.w *= dg[i].w; }
+#ifdef FNO_EXP_STCOAL     // timing experiment only (wrong results): gout in whole lines
+          if (a.gout) st4(a.gout + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7), v);
+#elif !defined(FNO_EXP_NOSTORE)
+          if (a.gout) st4(a.gout + ro + 8 * i, v);
+#endif
+          if (LIFT || a.x1g) st4(r3p + 8 * i, v);
+        }
+      }
+      FNO_STAMP(tslot + 5);
+      group_barrier(bar, epoch, lane);
+      FNO_STAMP(tslot + 6);
+      // ---- row DFT of gout (truncated, fp32 MFMA 16x16x4) -----------------------------------------------------------------
+      if (!LIFT && a.x1g) {
+        if (a.W == 128) {
+          // a row spans both halves: jobs (16-channel block, 16-output block) = wg, wg + 4; this half adds 4 of the 8 k steps
+#pragma unroll
+          for (int jj = 0; jj < NJP; ++jj) {
+            const int job = wg + 4 * jj;
+            if (job < 4 * a.NJ) {
+              const int n16 = job & 3, jt = job >> 2;
+              if (h == 0) { dft0[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; dft1[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+              const float* tf = tfwd_s + (size_t)(jt * 16 + l15) * (a.W + 4) + 4 * quad + 64 * h;
+              const float* xr = r3 + (n16 * 16 + l15) * PITCH + 4 * quad;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 av = ld4(tf + 16 * q);
+                const float4 bv = ld4(xr + 16 * q);
+                dft0[jj] = mfma16(av.x, bv.x, dft0[jj]);
+                dft1[jj] = mfma16(av.y, bv.y, dft1[jj]);
+                dft0[jj] = mfma16(av.z, bv.z, dft0[jj]);
+                dft1[jj] = mfma16(av.w, bv.w, dft1[jj]);
+              }
+              if (h == 1) {
+                const int prow = pxt / a.W;
+                const int c = n16 * 16 + l15;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                  const int k2 = jt * 8 + quad * 2 + pr;
+                  if (k2 < a.K2out)
+                    *reinterpret_cast<float2*>(a.x1g + ((((size_t)b * a.P + prow) * a.K2out + k2) * C + c) * 2) =
+                        make_float2(dft0[jj][2 * pr] + dft1[jj][2 * pr], dft0[jj][2 * pr + 1] + dft1[jj][2 * pr + 1]);
+                }
+              }
+            }
+          }
+        } else {
+          // rows of 32 / 64 pixels lie inside the half: complete jobs (channel block, row, output block)
+          const int RH = GPX / a.W;
+          const int njobs = 4 * RH * a.NJ;
+          for (int job = wg; job < njobs; job += 4) {
+            const int n16 = job & 3, rr = (job >> 2) % RH, jt = (job >> 2) / RH;
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            const float* tf = tfwd_s + (size_t)(jt * 16 + l15) * (a.W + 4) + 4 * quad;
+            const float* xr = r3 + (n16 * 16 + l15) * PITCH + rr * a.W + 4 * quad;
+            for (int q = 0; q < a.W / 16; ++q) {
+              const float4 av = ld4(tf + 16 * q);
+              const float4 bv = ld4(xr + 16 * q);
+              d0 = mfma16(av.x, bv.x, d0);
+              d1 = mfma16(av.y, bv.y, d1);
+              d0 = mfma16(av.z, bv.z, d0);
+              d1 = mfma16(av.w, bv.w, d1);
+            }
+            const int prow = px0 / a.W + rr;
+            const int c = n16 * 16 + l15;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const int k2 = jt * 8 + quad * 2 + pr;
+              if (k2 < a.K2out)
+                *reinterpret_cast<float2*>(a.x1g + ((((size_t)b * a.P + prow) * a.K2out + k2) * C + c) * 2) =
+                    make_float2(d0[2 * pr] + d1[2 * pr], d0[2 * pr + 1] + d1[2 * pr + 1]);
+            }
+          }
+        }
+      }
+      if constexpr (LIFT) {      // lifting gradients: job wg = 16 channels, dl[c][n] += sum_px gout[c][px] xext[n][px]
+        const float* arow = r3 + (wg * 16 + l15) * PITCH + quad;
+        const float* br = xlt + (l15 < a.CL ? l15 : 0) * XPITCH + quad;
+        const float cst = l15 == a.CL ? 1.0f : 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < GPX / 4; ++s) {
+          const float bf = (l15 < a.CL) ? br[4 * s] : cst;
+          dl = mfma16(arow[4 * s], bf, dl);
+        }
+      }
+      FNO_STAMP(tslot + 7);
+      tslot += 8;
+    }
+  }
+
+  // ---- partial slabs: one dW slab per group; bias and lifting gradients summed over both groups ---------------------------
+  {
+    float* dst = a.dw_part + ((size_t)blockIdx.x * 2 + grp) * C * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row32(r, half)) * C + nt * 32 + l31] = dwtot[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) smem[((grp * 2 + nt) * 8 + (lane & 7)) * C + grow0 + 8 * i] = dbsum[i];
+  float* dls = smem + 32 * C;                      // [grp][64 channels][16]
+  if constexpr (LIFT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dls[(grp * C + wg * 16 + quad * 4 + r) * 16 + l15] = dl[r];
+  }
+  __syncthreads();
+  if (tid < C) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += smem[k * C + tid];
+    a.db_part[(size_t)blockIdx.x * C + tid] = v;
+  }
+  if constexpr (LIFT)
+    for (int i = tid; i < C * 16; i += 512) a.dwl_part[(size_t)blockIdx.x * C * 16 + i] = dls[i] + dls[C * 16 + i];
+}

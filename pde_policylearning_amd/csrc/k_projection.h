@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
 
   int tslot = 0;
-  FNO_TRACE_IF(true);
+  FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
   FNO_SIMD_PARTNER_PRIO(wave, NW);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;

@@ -24,7 +24,7 @@ L = _lib.lib()
 buf = (C.c_ulonglong * (16 * 256))()
 L.fno_debug_trace_dump.argtypes = [C.c_void_p, C.c_size_t]
 assert L.fno_debug_trace_dump(buf, 16 * 256) == 0
-for w in (0, 3):
+for w in [int(v) for v in os.environ.get("WAVES", "0,3").split(",")]:
     row = [buf[w * 256 + i] for i in range(256)]
     print(f"wave {w}:")
     for t in range(4, 10):
