@@ -18,6 +18,7 @@
 #include "k_chanflow.h"
 #include "k_pointwise.h"
 #include "k_projection.h"
+#include "k_projection2.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
 #include "k_pino_loss2.h"
@@ -1139,8 +1140,24 @@ static size_t pbwd_x3_lds(int C, int npx, int nco) {
   return ((size_t)3 * npx * (C + 8) + (size_t)3 * C * (npx + 8) + (size_t)3 * 64 * (npx + 8)) * 2 +
          ((size_t)nco * npx + kHID + (size_t)nco * kHID) * 4;
 }
+// second-generation projection backward (k_projection2.h): C = 64, one output channel, 128-pixel tiles, split-precision mode
+static size_t pbwd_t_lds(const ProjBwdArgs& a) {
+  return (size_t)3 * 64 * 256 + (size_t)2 * 3 * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
+}
+static bool use_pbwd_t(int C, int CO, int npx) {
+  static const int v1 = getenv("FNO_PBWD_V1") ? 1 : 0;        // A/B switch: the first-generation kernel
+  return !v1 && g_gemm_x3 && C == 64 && CO == 1 && npx == 128;
+}
+// W1 -> bf16x3 fragments in the order the selected projection-backward kernel reads them
+static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsigned short* wa3, int HID, int C, bool t_order) {
+  const int nitems = (HID / 32) * (C / 16) * 64 + (HID / 32) * 2 * (C / 32) * 64;
+  if (t_order) return launch("k_pack_w1_x3", k_pack_w1_t, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
+  return launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
+}
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
+    return launch("k_proj_bwd", k_proj_bwd_t<kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(a), st, a);
   // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
   if (a.wa1 && a.CO == 1 && p->NPX == 128 && pbwd_x3_lds(C, 128, 1) <= 160 * 1024)
     return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
@@ -1290,9 +1307,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
   if (g_gemm_x3) {
-    const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;
-    LAUNCHCHK(launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, prm->proj_w1, w.wa1,
-                     w.wa3, kHID, C));
+    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX)));
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
@@ -1989,6 +2004,10 @@ static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
 }
 template <int C, int HID, bool RELU>
 static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
+  if constexpr (C == 64) {
+    if (use_pbwd_t(C, 1, 128))
+      return launch("k_proj_bwd", k_proj_bwd_t<HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(a), st, a);
+  }
   const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
   return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
@@ -2028,8 +2047,7 @@ extern "C" int fno_projection_backward_act(int B, int C, int hidden, int Cout, s
   ProjWs w = carve_proj(C, hidden, ws, ws_bytes);
   if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  const int nitems = (hidden / 32) * (C / 16) * 64 + (hidden / 32) * 2 * (C / 32) * 64;
-  LAUNCHCHK(launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, w.wa1, w.wa3, hidden, C));
+  LAUNCHCHK(pack_w1_x3(st, w1, w.wa1, w.wa3, hidden, C, use_pbwd_t(C, 1, 128)));
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
   pb.x = x; pb.dy = dy; pb.w1 = w1; pb.b1 = b1; pb.w2 = w2; pb.gout = dx; pb.wa1 = w.wa1; pb.wa3 = w.wa3;

@@ -184,6 +184,20 @@ FNO_DEV f32x16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
   return acc;
 }
+// Buffer loads: the 128-bit resource descriptor and the scalar offset live in SGPRs, each lane supplies one 32-bit byte
+// offset - no 64-bit per-lane pointers (which the compiler otherwise keeps, one pair per unrolled load, in VGPRs).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+FNO_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+FNO_DEV float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  // (bit_cast of the WHOLE result: picking elements out of the builtin's own vector type compiles to a one-dword load)
+  const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+FNO_DEV bf16x8 buf_ld8h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 FNO_DEV bf16x8 ld8h(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
 FNO_DEV void st8h(unsigned short* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 

@@ -1,0 +1,307 @@
+// Backward of the fused projection MLP, second generation (C = 64; same arguments, partial-slab outputs and mathematics as
+// k_proj_bwd_x3 in k_projection.h; reference: autograd of neuralop/models/tfno.py:23-38).  Built on the block backward's
+// findings (k_block_bwd2.h): every GEMM whose result feeds the dx chain keeps the hh products and the cross terms of the
+// 3-way split in separate accumulators; ONE [channel][pixel] image of a = act(u_L) serves the recompute (transposed
+// reads) and dW1 (row reads); the hidden chunk is computed TRANSPOSED (P1^T[pixel][hidden]: lane <-> hidden row), so
+//   * b1 / W2 are per-lane scalars, the dW2 / db1 reductions are lane-local sums (no DPP butterflies, no LDS reads),
+//   * the dP1 chunk goes to its row-major image as 8-byte stores of 4 consecutive pixels (was: 48 two-byte stores),
+//   * dx^T[pixel][channel] accumulates in ONE tile per wave (pixel block nt, channel block hm): no partial-sum exchange.
+// The dP1 image is double-buffered: ONE barrier per 64-row chunk; the wave group that owns a chunk's dW1 (48 MFMAs) runs
+// beside its SIMD partners' recompute + GELU phase of the next chunk.
+//   per chunk:  A1 recompute (24 MFMAs) | E gelu, gelu', dP1 split -> dr[ch & 1] | barrier | A3 dx += (24) | owners: dW1 (48)
+#pragma once
+#include "fno_dev.h"
+#include "k_block_bwd2.h"
+#include "k_projection.h"
+
+// W1 (HID, C) fp32 -> bf16x3 fragments for k_proj_bwd_t: wa1 as k_pack_w1_x3; the dx product's B fragments in natural k order
+//   wb3[(((ch*4 + kb)*MT + cb)*3 + t)*64 + lane][j] = term t of W1[ch*64 + kb*16 + 8*(lane>>5) + j][cb*32 + (lane&31)]
+__global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
+                            int HID, int C) {
+  const int KB = C / 16, MT = C / 32;
+  const int n1 = (HID / 32) * KB * 64, n3 = (HID / 16) * MT * 64;
+  const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  float v[8];
+  bf16x8 h, m, l;
+  if (it < n1) {
+    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
+    split3x8(v, h, m, l);
+    unsigned short* dst = wa1 + ((size_t)((mt * KB + kb) * 3) * 64 + ln) * 8;
+    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
+  } else if (it < n1 + n3) {
+    const int i3 = it - n1;
+    const int ln = i3 & 63, cb = (i3 >> 6) % MT, kh = (i3 >> 6) / MT;      // kh = ch*4 + kb: 16-row block of W1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(kh * 16 + 8 * (ln >> 5) + j) * C + cb * 32 + (ln & 31)];
+    split3x8(v, h, m, l);
+    unsigned short* dst = wb3 + ((size_t)((kh * MT + cb) * 3) * 64 + ln) * 8;
+    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
+  }
+}
+
+template <int HID, bool RELU = false>
+__global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
+  constexpr int C = 64, NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32;
+  constexpr int NCH = HID / 64, CPW = NCH / 2;
+  constexpr int PITCH = NPX + 4;
+  constexpr int ATERM = C * 256, DTERM = 64 * 256;          // bytes per term plane of the a image / one dP1 buffer
+  static_assert(NCH % 2 == 0, "two owner groups");
+  static_assert((size_t)C * PITCH * 4 <= (size_t)3 * DTERM, "the gout tile aliases dP1 buffer 0");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* aimg = reinterpret_cast<unsigned char*>(smem);             // a = act(u_L): [3][C][128] bf16, swizzled
+  unsigned char* dr0 = aimg + 3 * ATERM;                                     // dP1 chunk, two buffers [3][64][128] bf16, swizzled
+  float* douts = reinterpret_cast<float*>(dr0 + 2 * 3 * DTERM);              // dy row of the tile (NPX)
+  float* r3 = reinterpret_cast<float*>(dr0);                                 // after the chunk loop: gout tile C x PITCH
+  float* tfwd_s = douts + NPX;                                               // 16*NJ x (W + 4): forward row table (if x1g)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int hm = wave >> 2, nt = wave & 3;
+  const int n0 = nt * 32;
+  const int dmt = nt >> 1, dnt = nt & 1;          // dW1 tile of an owner wave: hidden 32-block, channel 32-block
+  // transposed-read lane roles (k_block_bwd2.h): lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p + 3
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int tpx = n0 + 16 * (quad & 1) + 4 * tp;
+  const int trow = 8 * (quad >> 1) + tq;
+
+  f32x16 dw1acc[CPW];
+#pragma unroll
+  for (int k = 0; k < CPW; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw1acc[k][r] = 0.f;
+  float sdb1[NCH], sdw2[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) { sdb1[ch] = 0.f; sdw2[ch] = 0.f; }
+
+  // ONE set of weight fragments, time-shared: the recompute's (wa1) during A1, the dx product's (wb3) during A3.  Buffer loads:
+  // descriptor + fragment offset in SGPRs, one 32-bit lane offset
+  const __amdgpu_buffer_rsrc_t rs_wa1 = make_rsrc(a.wa1, (unsigned)((HID / 32) * KB * 3 * 64 * 16));
+  const __amdgpu_buffer_rsrc_t rs_wb3 = make_rsrc(a.wa3, (unsigned)((HID / 16) * MT * 3 * 64 * 16));
+  bf16x8 wf[KB][3];
+  auto load_wa1 = [&](int ch) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[kb][t] = buf_ld8h(rs_wa1, lane * 16, (((ch * 2 + hm) * KB + kb) * 3 + t) * 1024);
+  };
+  auto load_wb3 = [&](int ch) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[kb][t] = buf_ld8h(rs_wb3, lane * 16, ((((ch * 4 + kb) * MT + hm) * 3) + t) * 1024);
+  };
+  // the tile's rows of u_L: thread (c = tid / 32 + 16 i, q = tid % 32) loads 16 bytes; per-sample descriptor
+  float4 xq[4];
+  const int xvoff = ((tid >> 5) * a.PW + 4 * (tid & 31)) * 4;
+  auto issue_x = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
+#ifdef PBT_GLOBAL_X
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xq[i] = ld4(a.x + ((size_t)b * C + (tid >> 5) + 16 * i) * a.PW + px0 + 4 * (tid & 31));
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xq[i] = buf_ld4(rs, xvoff, (16 * i * a.PW + px0) * 4);
+#endif
+  };
+  if ((int)blockIdx.x < a.ntiles) issue_x(blockIdx.x);
+  if (a.x1g)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  load_wa1(0);
+
+  int tslot = 0;
+  FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    FNO_STAMP(tslot + 0);
+    // ---- commit: a = act(u) -> swizzled [c][px] image (one split) -----------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (tid >> 5) + 16 * i, q = tid & 31;
+      float4 t = xq[i];
+      if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
+      put_split4(aimg, ATERM, swz_off(c, q >> 1) + 8 * (q & 1), t);
+    }
+    if (tid < NPX) douts[tid] = a.dy[(size_t)b * a.PW + px0 + tid];
+    FNO_STAMP(tslot + 1);
+    __syncthreads();
+    FNO_STAMP(tslot + 2);
+    f32x16 dxh, dxl;         // dx^T: hh products / cross terms (summed once, in the epilogue)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dxh[r] = 0.f; dxl[r] = 0.f; }
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      unsigned char* dr = dr0 + (ch & 1) * 3 * DTERM;
+      // per-lane constants of this chunk: hidden row ch*64 + hm*32 + l31 (L2-resident; used after the recompute)
+      const float b1v = a.b1[ch * 64 + hm * 32 + l31], w2v = a.w2[ch * 64 + hm * 32 + l31];
+      if (ch == 1) FNO_STAMP(tslot + 3);
+      // ---- A1: P1^T[px][hid] = sum_c a[c][px] W1[hid][c]: A = transposed reads of the a image, B = W1 fragments ---------
+      f32x16 acc;
+      {
+        f32x16 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          bf16x8 af[3];
+          const int o0 = swz_off(kb * 16 + trow, tpx >> 3) + 2 * (tpx & 7);
+          const int o1 = swz_off(kb * 16 + trow + 4, tpx >> 3) + 2 * (tpx & 7);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(aimg + t * ATERM + o0), lds_tr16(aimg + t * ATERM + o1));
+          mfma_x3s(af, wf[kb], hi, lo);
+          __builtin_amdgcn_sched_barrier(0);      // keep at most one k block of operand fragments live
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+      }
+      load_wb3(ch);            // the dx product's fragments arrive while the GELU phase runs
+      if (ch == 1) FNO_STAMP(tslot + 4);
+      // ---- E: lane <-> hidden row; registers <-> pixels n0 + (r&3) + 8 (r>>2) + 4 half ------------------------------------
+      {
+        float sdb = 0.f, sdw = 0.f;
+        const int hrow = hm * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 dy4 = ld4(douts + n0 + 8 * i + 4 * half);
+          const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+          float dp[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float p1 = acc[4 * i + j] + b1v;
+            float gl, dg;
+            if constexpr (RELU) { gl = fmaxf(p1, 0.f); dg = p1 > 0.f ? 1.f : 0.f; }
+            else gelu_both(p1, gl, dg);
+            dp[j] = dg * (w2v * dyv[j]);
+            sdw = fmaf(gl, dyv[j], sdw);
+            sdb += dp[j];
+          }
+          put_split4(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dp[0], dp[1], dp[2], dp[3]));
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+          if (k == ch) { sdb1[k] += sdb; sdw2[k] += sdw; }
+      }
+      if (ch == 1) FNO_STAMP(tslot + 5);
+      __syncthreads();         // dr[ch & 1] is complete; every reader of dr[(ch + 1) & 1] (chunk ch - 1) is done
+      if (ch == 1) FNO_STAMP(tslot + 6);
+      // the next tile's rows: issued in the last chunk, so that their 16 registers are not live through the whole tile
+      if (ch == NCH - 1) {
+        const int nt2 = tile + gridDim.x;
+        if (nt2 < a.ntiles) issue_x(nt2);
+      }
+      // ---- A3: dx^T[px][c] += sum_hid dP1[hid][px] W1[hid][c]: A = transposed reads of the dP1 image ----------------------
+      {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          bf16x8 af[3];
+          const int o0 = swz_off(kb * 16 + trow, tpx >> 3) + 2 * (tpx & 7);
+          const int o1 = swz_off(kb * 16 + trow + 4, tpx >> 3) + 2 * (tpx & 7);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(dr + t * DTERM + o0), lds_tr16(dr + t * DTERM + o1));
+          mfma_x3s(af, wf[kb], dxh, dxl);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the next chunk's recompute fragments (the owners' dW1 phase hides their latency; the other group waits for them)
+      load_wa1(ch + 1 < NCH ? ch + 1 : 0);      // (last chunk: the next tile's chunk 0)
+      if (ch == 1) FNO_STAMP(tslot + 7);
+      // ---- B: dW1[hid][c] += sum_px dP1[hid][px] a[c][px] by the group that owns this chunk --------------------------------
+      if (hm == (ch & 1)) {
+        __builtin_amdgcn_s_setprio(2);
+        const int ro = dmt * 32 + l31, rc = dnt * 32 + l31;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+          if (k == (ch >> 1)) {
+        f32x16 dacc = dw1acc[k];
+#pragma unroll 1
+        for (int kq = 0; kq < NPX / 16; ++kq) {
+          const int chn = 2 * kq + half;
+          const int od = swz_off(ro, chn), oa = swz_off(rc, chn);
+          bf16x8 af[3], bf[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            af[t] = *reinterpret_cast<const bf16x8*>(dr + t * DTERM + od);
+            bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * ATERM + oa);
+          }
+          dacc = mfma_x3(af, bf, dacc);
+        }
+        dw1acc[k] = dacc;
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (ch == 1) FNO_STAMP(tslot + 8);
+    }
+    FNO_STAMP(tslot + 9);
+    // ---- epilogue: x act'(u), gout store (before the barrier: the last chunk's dW1 owners are still on the matrix pipe),
+    //      then the gout tile for the row DFT ----------------------------------------------------------------------------
+    {
+      const int crow = hm * 32 + l31;
+      const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] = make_float4(dxh[4 * i] + dxl[4 * i], dxh[4 * i + 1] + dxl[4 * i + 1], dxh[4 * i + 2] + dxl[4 * i + 2],
+                           dxh[4 * i + 3] + dxl[4 * i + 3]);
+      if (a.act_in) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
+        float4 uq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uq[i] = buf_ld4(rs, (crow * a.PW + n0 + 4 * half) * 4, (px0 + 8 * i) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i].x *= gelu_grad_f(uq[i].x); v[i].y *= gelu_grad_f(uq[i].y);
+          v[i].z *= gelu_grad_f(uq[i].z); v[i].w *= gelu_grad_f(uq[i].w);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st4(a.gout + ro + 8 * i, v[i]);
+      FNO_STAMP(tslot + 10);
+      __syncthreads();       // every wave is done with dP1 buffer 0 (= r3) and with the a image
+      if (a.x1g) {
+        float* r3p = r3 + crow * PITCH + n0 + 4 * half;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st4(r3p + 8 * i, v[i]);
+      }
+    }
+    if (a.x1g) {
+      __syncthreads();
+      row_dft_epilogue<C, NPX, 8>(r3, tfwd_s, a.W + 4, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      FNO_STAMP(tslot + 11);
+#ifdef PBT_TRAIL_BARRIER
+      __syncthreads();
+#endif
+      // no barrier here: r3 (dP1 buffer 0) is rewritten by the next tile's first chunk, behind the commit barrier, which a
+      // wave only reaches after it has left the row DFT; the commit itself writes the a image, which nobody reads any more
+    }
+    tslot += 12;
+  }
+
+  // ---- partial slabs ---------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    const int ch = 2 * k + hm;
+    float* dst = a.dw1_part + (size_t)blockIdx.x * HID * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
+  }
+  {
+    const size_t slab = (size_t)blockIdx.x * NTN + nt;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const float vb = sdb1[ch] + __shfl_xor(sdb1[ch], 32, 64);
+      const float vw = sdw2[ch] + __shfl_xor(sdw2[ch], 32, 64);
+      if (half == 0) {
+        const int hid = ch * 64 + hm * 32 + l31;
+        a.db1_part[slab * HID + hid] = vb;
+        a.dw2_part[slab * HID + hid] = vw;
+      }
+    }
+  }
+}
