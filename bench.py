@@ -49,17 +49,45 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r01_v27_pmc_traffic.json"
-PMC_SQ_CSV = "r01_v27_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r02_pmc_traffic.json"
+PMC_SQ_CSV = "r02_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+
+
+def source_hash():
+    """sha1 over the engine's device + ABI sources: ties a committed counter file to the kernels it was collected on
+    (the git sha cannot: committing the profile changes it)."""
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "pde_policylearning_amd", "csrc")
+    for f in sorted(os.listdir(src)) + ["../../include/fnoengine.h"]:
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def git_sha():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def kernel_model(cfg):
-    """Algorithmic FLOPs and HBM bytes PER LAUNCH of each hot kernel."""
-    B, C = cfg["batch"], cfg["width"]
+    """Algorithmic FLOPs and HBM bytes PER LAUNCH of each hot kernel.  The observer workloads run the
+    same block / projection kernels on (batch, 64 channels, plane) activations: same formulas, their plane size."""
+    B = cfg["batch"]
+    C = cfg.get("width", 64)
+    size = cfg["size"]
+    if cfg["kind"] in ("pino2d", "pino2d_train"):
+        size = size[:2] + (size[2] + 2 * round(size[2] * 0.0625),)      # T padded both ends (pad_ratio 0.0625)
+    if cfg["kind"] in ("pino_ff", "pino_ff_pde"):
+        size = size + (1,)
     PW = 1
-    for s in cfg["size"]:
+    for s in size:
         PW *= s
-    HID, CO, CIN = 256, 1, 3
+    HID, CO, CIN = (128 if cfg["kind"].startswith("pino") else 256), 1, 3
     act = 4.0 * B * C * PW                       # bytes of one (B, C, ...) activation
     gemm = 2.0 * B * PW * C * C                  # one 1x1 conv
     proj = 2.0 * B * PW * (C * HID + HID * CO)
@@ -69,7 +97,29 @@ def kernel_model(cfg):
         "k_proj_fwd": dict(bytes=act + 4.0 * B * CO * PW, flops=proj),
         "k_proj_bwd": dict(bytes=2 * act + 4.0 * B * CO * PW, flops=2 * proj),
         "k_block_bwd": dict(bytes=3 * act, flops=2 * gemm),
+        # Adam on the flat bucket: reads p, g, m, v and writes p, m, v
+        "k_adam": dict(bytes=28.0 * cfg.get("n_params", 0), flops=12.0 * cfg.get("n_params", 0)),
     }
+
+
+def spawn_ranks(n, cmd, extra_env=None):
+    """Start `cmd` n times, one process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, a free
+    rendezvous port on 127.0.0.1); returns (rank 0's stdout, worst return code).  The other ranks' stdout is discarded, every
+    rank's stderr passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    return out0, max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -88,6 +138,14 @@ def main():
                          "launch-bound small configurations)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one child process per GPU, started BEFORE anything here touches the GPU (never exec / re-exec a process
+        # that has initialised it); rank 0's JSON line is the children's only stdout and becomes ours
+        out0, rc = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        sys.exit(rc)
+
     import torch
     import torch.distributed as dist
 
@@ -105,9 +163,8 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.gpus != world and not force_dist:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -183,8 +240,7 @@ def main():
         decoder = MeanStdDecoder(0.1 * rnd(32, 32), 0.5 + torch.rand((32, 32), generator=gen).to(dev), device=dev)
         loss_fn = FullFieldObjective(decoder, [-10, -8, -6], env, 1.0)
         tgt = (rnd(B, 1, 3, 32, 32), 1 + 0.5 * rnd(B, 1, 32, 131, 32), 0.3 * rnd(B, 1, 32, 130, 32), 0.3 * rnd(B, 1, 32, 131, 32))
-    if not fused_model:
-        args.no_cpu_baseline = True
+    cfg = dict(cfg, n_params=sum(p.numel() * (2 if p.is_complex() else 1) for p in model.parameters()))
 
     def step():
         return train_step(model, bucket, opt, inputs, tgt, loss_fn)
@@ -237,7 +293,7 @@ def main():
         L.fno_profile_enable(0)
         prof = _lib.profile_summary()
         L.fno_profile_reset()
-        km = kernel_model(cfg) if fused_model else {}
+        km = kernel_model(cfg)
         tot = sum(ms for _, ms, _ in prof)
         for name, ms, n in sorted(prof, key=lambda r: -r[1]):
             avg = ms / n
@@ -257,13 +313,17 @@ def main():
             else:
                 roofline = dict(kernel=dom["name"], bound="hbm", achieved=dom["GBps"], peak=PEAK_HBM_GBS,
                                 unit="GB/s", frac=round(f_h, 4), traffic=None)
-            # HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_traffic.py)
+            # HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_traffic.py): quoted only when the file
+            # was collected on THESE kernel sources (source_hash) and this workload
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON)))
-                if pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
+                if pj.get("source_hash") != source_hash():
+                    roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} was collected on other kernel sources "
+                                                  f"({pj.get('source_hash')} != {source_hash()}): not quoted")
+                elif pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
                     pt = pj["kernels"]
                     base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
-                    cands = [k for k in pt if k.split("<")[0] in (base, base + "_x3")]
+                    cands = [k for k in pt if k.split("<")[0] in (base, base + "_x3", base + "_t", base + "_g2")]
                     key = next((k for k in cands if not k.endswith(", true>")), cands[0])   # not the block-0 LIFT variants
                     roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
@@ -275,14 +335,14 @@ def main():
             # (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs
             try:
                 import csv
-                if args.config == "fno2d_128x128_w64_m12_b64":
+                if args.config == "fno2d_128x128_w64_m12_b64" and roofline.get("traffic") is not None:
                     base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
                     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", PMC_SQ_CSV))):
-                        if r["kernel"] in (base + "_x3", base):
+                        if r["kernel"] in (base + "_x3", base, base + "_t", base + "_g2"):
                             roofline["matrix_pipe_busy"] = round(float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0
                                                                  / (float(r["GRBM_GUI_ACTIVE"]) / 8.0), 3)
                             roofline["matrix_pipe_busy_source"] = f"profiles/{PMC_SQ_CSV} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, own pass)"
-                            if r["kernel"].endswith("_x3"):
+                            if r["kernel"].endswith(("_x3", "_t", "_g2")):
                                 break
             except Exception:
                 pass
@@ -293,43 +353,96 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import fno_oracle as O
+        from oracle import observers_oracle as OO
         ncores = os.cpu_count() or 1
-        bs = 4 if cfg["kind"] == "2d" else 1
-        bs = min(bs, B)
-        pc = {}
-        for k, v in model.state_dict().items():
-            pc[k] = v.detach().cpu().clone().requires_grad_(True)
-        xs, ts = x[:bs].cpu(), tgt[:bs].cpu()
+        kind = cfg["kind"]
+        bs = min({"2d": 8, "rno2d": 2, "rno2d_shipped": 8, "pino_ff": 4, "pino_ff_pde": 4}.get(kind, 1), B)
+        pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        cin = [t[:bs].detach().cpu() for t in inputs]
+        if kind in ("2d", "3d"):
+            ts = tgt[:bs].cpu()
+
+            def cpu_loss():
+                return O.lp_loss_rel_sum(O.fno_forward(pc, cin[0], cfg["modes"]), ts)
+        elif kind.startswith("rno2d"):
+            ts = tgt[:bs].cpu()
+            width = 64 if kind == "rno2d" else 34
+
+            def cpu_loss():
+                return O.lp_loss_rel_sum(OO.rno2d_forward(pc, cin[0], 12, 12, width, 0, 1), ts)
+        elif kind in ("pino_ff", "pino_ff_pde"):
+            # (the channel-flow physics term of pino_ff_pde is not part of the CPU sample: model + LpLoss only, said in `sample`)
+            ts = (tgt[0] if isinstance(tgt, tuple) else tgt)[:bs].cpu()
+
+            def cpu_loss():
+                y = OO.pinobserver_fullfield_forward(pc, cin[0], cin[1], [64] * 5, [(12, 12, 12)] * 4, [0.0, 0.0625])
+                return O.lp_loss_rel_sum(y.reshape(bs, -1), ts.reshape(bs, -1)) if y.numel() == ts.numel() else y.square().sum()
+        else:
+            from oracle import pino_loss_oracle as P
+            m = cfg.get("modes", 8)
+            S = cfg["size"][0]
+            ts = None if kind == "pino2d_train" else tgt[:bs].cpu()
+
+            def cpu_loss():
+                y = OO.pinobserver2d_forward(pc, cin[0], cin[1], [64] * 5, [(m, m, m)] * 4, [0.0625, 0.0625])
+                if kind == "pino2d_train":     # 5 * IC + PDE residual (train_pino.py:86-106)
+                    lic, lf = P.pino_loss(y.reshape(y.shape[:4]), cin[0][:, :, :, 0, -1], P.forcing(S), 1.0 / cin[1].reshape(bs), 0.5)
+                    return 5.0 * lic + lf
+                return O.lp_loss_rel_sum(y, ts)
 
         def cpu_step():
             for v in pc.values():
                 v.grad = None
-            y = O.fno_forward(pc, xs, cfg["modes"])
-            O.lp_loss_rel_sum(y, ts).backward()
+            cpu_loss().backward()
 
-        # torch's CPU FFT/einsum stop scaling (and then degrade badly) long before a many-core
-        # host is full: measured on the 256-core GPU box, 8 threads 22.9 fields/s, 64 threads
-        # 6.7, 256 threads 0.02.  Time a short sweep and keep the best; `cores` reports the
-        # thread count actually used for the quoted number.
-        best = None
-        for nthr in [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]:
+        # torch's CPU FFT/einsum stop scaling (and then degrade badly) long before a many-core host is full (measured on the
+        # 256-core GPU box at config 2: 8 threads 22.9 fields/s, 64 threads 6.7, 256 threads 0.02).  Reported: the best of a
+        # 4/8/16/32-thread sweep (`value`, `cores`) AND the all-cores figure asked for by SURVEY section 8d (`all_cores`),
+        # each on a time-bounded sample.
+        def timed(nthr, budget, max_it):
             torch.set_num_threads(nthr)
+            t_w = time.perf_counter()
             cpu_step()                                   # warm-up at this thread count
+            if time.perf_counter() - t_w > budget:       # one step already exceeds the budget: that step is the sample
+                return bs / (time.perf_counter() - t_w), 1, time.perf_counter() - t_w
             n_it, t_c0 = 0, time.perf_counter()
             while True:
                 cpu_step()
                 n_it += 1
                 el = time.perf_counter() - t_c0
-                if el > 3.0 or n_it >= 12:
-                    break
-            rate = bs * n_it / el
+                if el > budget or n_it >= max_it:
+                    return bs * n_it / el, n_it, el
+        best = None
+        for nthr in [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]:
+            rate, n_it, el = timed(nthr, 3.0, 12)
             if best is None or rate > best[0]:
                 best = (rate, nthr, n_it, el)
+        allc = None
+        if ncores > 32:
+            try:
+                import signal
+
+                def _alarm(*_):
+                    raise TimeoutError()
+                signal.signal(signal.SIGALRM, _alarm)
+                signal.alarm(25)                          # the all-cores run can take minutes per step: bounded
+                r_all, n_all, el_all = timed(ncores, 6.0, 4)
+                signal.alarm(0)
+                allc = dict(value=round(r_all, 3), cores=ncores, iters=n_all, seconds=round(el_all, 1))
+            except TimeoutError:
+                allc = dict(value=None, cores=ncores, note="one step did not finish within 25 s")
+            finally:
+                try:
+                    signal.alarm(0)
+                except Exception:
+                    pass
         rate, nthr, n_it, el = best
         cpu_baseline = dict(value=round(rate, 3), unit="fields/s", cores=nthr, kind="port",
-                            sample=f"oracle (CPU restatement of the reference, torch ops) zero_grad+fwd+LpLoss+bwd on "
+                            sample=f"oracle (CPU restatement of the reference, torch ops) zero_grad+fwd+loss+bwd on "
                                    f"{bs} fields of the same shape; best of a 4/8/16/32-thread sweep on a "
-                                   f"{ncores}-core host: {nthr} threads, {n_it} iters in {el:.1f}s")
+                                   f"{ncores}-core host: {nthr} threads, {n_it} iters in {el:.1f}s"
+                                   + ("; physics term not included" if kind == "pino_ff_pde" else ""),
+                            all_cores=allc)
 
     if rank == 0:
         out = {
@@ -345,7 +458,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "gemm_mode": "bf16x3-split (fp32 operands as 3 bf16 terms, 6 products, fp32 accumulate on the bf16 matrix pipe)"
+                         if _lib.lib().fno_get_gemm_mode() == 1 else "f32 (v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
+            "n_ranks": dist.get_world_size() if dist_on else 1,
+            "git_sha": git_sha(),
+            "source_hash": source_hash(),
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
                        "step": "zero_grad+fwd+" + {"pino_ff_pde": "decode+LpLoss(sum)+channel-flow pde_loss", "pino2d_train": "5*IC+PDE residual loss"}.get(cfg["kind"], "LpLoss(sum)") + "+bwd" +
                                ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",

@@ -284,3 +284,28 @@ def test_multistep_lr_matches_torch():
             sch2 = MultiStepLR(opt2, milestones=[1], gamma=0.1)
             sch2.load_state_dict(sch.state_dict())
             assert opt2.lr == opt.lr and sch2.last_epoch == 7
+
+
+def test_bench_self_launch_spawns_one_process_per_rank(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (bench.spawn_ranks): each child sees its RANK /
+    LOCAL_RANK / WORLD_SIZE and a common rendezvous address, only rank 0's stdout comes back, a failing rank fails the job.
+    Exercised here with a stand-in script that joins a gloo group (no GPU)."""
+    import json
+    import sys
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, json, sys\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(os.environ['RANK']) + 1.0])\n"
+        "dist.all_reduce(t)\n"
+        "print(json.dumps({'rank': dist.get_rank(), 'world': dist.get_world_size(), 'sum': float(t), 'local': os.environ['LOCAL_RANK']}))\n"
+        "r = dist.get_rank()\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == r)\n")
+    out, rc = bench.spawn_ranks(2, [sys.executable, str(script)])
+    rec = json.loads(out.strip().splitlines()[-1])
+    assert rc == 0 and rec == {"rank": 0, "world": 2, "sum": 3.0, "local": "0"}
+    out, rc = bench.spawn_ranks(2, [sys.executable, str(script)], extra_env={"FAIL_RANK": "1"})
+    assert rc != 0

@@ -31,7 +31,10 @@ def main():
     kernels = {k: dict(fetch_bytes=2 * fe[k] * 1024, write_bytes=wr.get(k, 0.0) * 1024,
                        raw_FETCH_SIZE=fe[k], raw_WRITE_SIZE=wr.get(k, 0.0))
                for k in fe if k.startswith("k_")}
-    json.dump(dict(workload="fno2d_128x128_w64_m12_b64", note="per-launch averages; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact; separate --pmc passes",
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    workload = sys.argv[4] if len(sys.argv) > 4 else "fno2d_128x128_w64_m12_b64"
+    json.dump(dict(workload=workload, source_hash=bench.source_hash(), git_sha=bench.git_sha(), note="per-launch averages; FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact; separate --pmc passes",
                    kernels=kernels), open(out, "w"), indent=1)
 
 
