@@ -28,7 +28,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3  # dense fp32 MFMA (v_mfma_f32_32x32x2_f32), same g
 CONFIGS = {
     # name: (ctor args, input shape per GPU)
     "fno2d_128x128_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(128, 128)),
-    "fno2d_64x64_w32_m8_b4": dict(kind="2d", modes=(8, 8), width=32, batch=4, size=(64, 64)),
+    "fno2d_64x64_w32_m8_b4": dict(kind="2d", modes=(8, 8), width=32, batch=4, size=(64, 64), graph=True),   # launch-bound
     "fno3d_64_w32_m8_b16": dict(kind="3d", modes=(8, 8, 8), width=32, batch=16, size=(64, 64, 64)),
     # a grid whose rows do not tile the kernels' 128-pixel tile ("loose rows": spectral rows gathered per tile)
     "fno2d_96x96_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(96, 96)),
@@ -36,7 +36,7 @@ CONFIGS = {
     # convolutions run in the engine (fno_spec_*), the channels-last pointwise glue is still torch ops; no
     # roofline / cpu_baseline legs.
     "rno2d_128x128_w64_m12_b32": dict(kind="rno2d", batch=32, size=(128, 128)),            # cfg 3 as named (256 / 8 GPUs)
-    "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32)),        # configs/matlab_rno.yaml values
+    "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32), graph=True),   # configs/matlab_rno.yaml values; launch-bound
     "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32)),     # the YAML's active model
     # the same model with the loop's loss: decode + LpLoss on the planes + pde_loss_weight 1.0 * channel-flow term (matlab_rno.yaml:56,62)
     "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32)),
@@ -134,9 +134,12 @@ def main():
                     help="N > 1: exchange all gradients in one all-reduce after the backward pass instead of starting "
                          "the late layers' segment while the early layers are still being differentiated")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the whole step once into a hipGraph and replay it (single GPU; pays off on the "
-                         "launch-bound small configurations)")
+                    help="capture the whole step once into a hipGraph and replay it (single GPU; the default for the "
+                         "launch-bound small configurations, marked graph=True in CONFIGS)")
+    ap.add_argument("--eager", action="store_true", help="never replay a hipGraph, also where it is the workload's default")
     args = ap.parse_args()
+    if CONFIGS[args.config].get("graph") and not args.eager and args.gpus == 1:
+        args.graph = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-launch: one child process per GPU, started BEFORE anything here touches the GPU (never exec / re-exec a process

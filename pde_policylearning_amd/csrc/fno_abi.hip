@@ -942,7 +942,7 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
   w.x1 = c.take<float>(s.n_x1);
   w.tmp = c.take<float>(s.n_tmp);
   w.hat = c.take<float>(s.n_hat);
-  w.ohat = c.take<float>(s.n_hat);
+  w.ohat = c.take<float>((size_t)p->d.n_layers * s.n_hat);   // the gradient spectrum of EVERY layer (one batched weight-gradient contraction)
   w.z = c.take<float>(s.n_x1);
   w.wp = c.take<float>(s.n_wp);
   w.wpt = c.take<float>(s.n_wp);
@@ -1334,15 +1334,21 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     float* t = gnext; gnext = gspare; gspare = t;
   }
   const int ks = bbwd_ksplit(p);
+  static const int no_batch_dw = getenv("FNO_NO_BATCH_DW") ? 1 : 0;       // A/B switch: one weight-gradient contraction per layer
+  const bool batch_dw = !no_batch_dw && l_hi > l_lo && mode_gemm_members_ok(C, C) && g_mode_mfma &&
+                        !(g_mode_gemv && B <= 4 && (long)g.Ktot * C * C >= (1L << 21));
   for (int l = l_hi; l >= l_lo; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
     float* dwp_l = w.dwp + (size_t)l * s.n_wp;
     float* dw_part_l = w.dw_part + (size_t)l * s.grid * ks * C * C;
     float* db_part_l = w.db_part + (size_t)l * s.grid * C;
-    LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, w.ohat));
-    LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, w.ohat, dwp_l, B, g.Ktot, C, C));
-    if (adj_mfma) LAUNCHCHK(mode_gemm(st, w.ohat, wps + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1, 1, 0, 0, 0, 1));
-    else LAUNCHCHK(mode_gemm(st, w.ohat, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
+    // G_l is kept per layer: dW_l = conj(Xhat_l) G_l does not feed the dx chain, so all layers of this part share ONE
+    // contraction launch behind the loop (layer index on the grid) instead of one 72-workgroup launch each
+    float* ohat_l = w.ohat + (size_t)(batch_dw ? l : 0) * s.n_hat;
+    LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, ohat_l));
+    if (!batch_dw) LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, ohat_l, dwp_l, B, g.Ktot, C, C));
+    if (adj_mfma) LAUNCHCHK(mode_gemm(st, ohat_l, wps + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1, 1, 0, 0, 0, 1));
+    else LAUNCHCHK(mode_gemm(st, ohat_l, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
     LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
 
     BlkBwdArgs a;
@@ -1370,6 +1376,9 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     gcur = gnext;
     { float* t = gnext; gnext = gspare; gspare = t; }
   }
+  if (batch_dw)
+    LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l_lo * s.n_hat, w.ohat + (size_t)l_lo * s.n_hat, w.dwp + (size_t)l_lo * s.n_wp, B,
+                           g.Ktot, C, C, l_hi - l_lo + 1, s.n_hat, s.n_hat, s.n_wp));
   LAUNCHCHK(jobs.run(st));
   {
     CornerPtrsMutL cp;

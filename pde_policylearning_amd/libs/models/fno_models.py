@@ -26,10 +26,11 @@ class FNO2dObserver(nn.Module):
         being rebuilt on the CPU and copied every call."""
         b, sx, sy = shape[0], shape[1], shape[2]
         key = (sx, sy, str(device))
-        g = self._grid_cache.get(key)
+        cache = self.__dict__.setdefault("_grid_cache", {})      # (dropped from whole-module checkpoints)
+        g = cache.get(key)
         if g is None:
             gx = torch.linspace(0, 1, sx, dtype=torch.float64).to(torch.float32).reshape(1, sx, 1, 1)
             gy = torch.linspace(0, 1, sy, dtype=torch.float64).to(torch.float32).reshape(1, 1, sy, 1)
             g = torch.cat((gx.expand(1, sx, sy, 1), gy.expand(1, sx, sy, 1)), dim=-1).to(device)
-            self._grid_cache[key] = g
+            cache[key] = g
         return g.expand(b, sx, sy, 2)

@@ -183,9 +183,25 @@ class RNO_layer(nn.Module):
         return torch.stack(seq, dim=1) if self.return_sequences else h
 
 
+# width-64 twins of narrow models (see RNO2d._wide_twin): keyed by the configuration, parameters on the meta device
+_WIDE_TWINS = {}
+ENGINE_WIDTHS = (32, 64)
+
+
+def _pad_to(t, shape):
+    """Zero-pad every dimension of t at its end up to `shape` (differentiable: the gradient is the leading slice)."""
+    if tuple(t.shape) == tuple(shape):
+        return t
+    pads = []
+    for have, want in zip(reversed(t.shape), reversed(shape)):
+        pads += [0, want - have]
+    return TF.pad(t, pads)
+
+
 class RNO2d(nn.Module):
     def __init__(self, modes1, modes2, width, recurrent_index, layer_num=3, pad_amount=None, pad_dim='1'):
         super().__init__()
+        self._ctor = (modes1, modes2, recurrent_index, layer_num, pad_amount, pad_dim)
         self.modes1 = modes2           # the reference overwrites modes1 with modes2 (rno.py:301-302)
         self.width, self.pad_amount, self.pad_dim = width, pad_amount, pad_dim
         self.recurrent_index = recurrent_index
@@ -247,7 +263,27 @@ class RNO2d(nn.Module):
             x = pred.reshape(pred.shape[0], 1, pred.shape[1], pred.shape[2], pred.shape[3])
         return torch.stack(outs, dim=1)
 
+    def _wide_twin(self):
+        """A width the fused kernels do not tile (the shipped YAML's 34, configs/matlab_rno.yaml:80) runs EXACTLY as the same
+        network embedded in 64 channels: every parameter zero-padded to the shapes of a width-64 twin.  Padded input columns
+        are zero, so the padded channels (which the scalar gate biases make non-zero) never reach a real channel, and the
+        gradient of a padded weight entry is discarded by the pad's adjoint (a slice); the regressor head widens 4 * 34 ->
+        256 hidden units the same way.  The twin is a structure only (meta-device parameters, shared per configuration)."""
+        key = self._ctor
+        if key not in _WIDE_TWINS:
+            m1, m2, ri, ln, pa, pd = key
+            with torch.device("meta"):
+                _WIDE_TWINS[key] = RNO2d(m1, m2, 64, ri, layer_num=ln, pad_amount=pa, pad_dim=pd)
+        return _WIDE_TWINS[key]
+
     def forward(self, x, v_plane=None, timestep=2):
+        if (x.is_cuda and self.width not in ENGINE_WIDTHS and self.width < 64
+                and not getattr(self, "no_width_padding", False)):
+            twin = self._wide_twin()
+            twin.train(self.training)          # dropout of the regressor follows THIS module's mode
+            shapes = {k: v.shape for k, v in twin.named_parameters()}
+            padded = {k: _pad_to(v, shapes[k]) for k, v in self.named_parameters()}
+            return torch.func.functional_call(twin, padded, (x,), {"v_plane": v_plane, "timestep": timestep})
         return self.predict(x, num_steps=x.shape[1])[:, self.recurrent_index]
 
     def count_params(self):

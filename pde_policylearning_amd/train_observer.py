@@ -52,6 +52,7 @@ def build_parser():
     ap.add_argument("--learning-rate", type=float, default=1e-3)
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)                  # run_pde_observers.py:25
+    ap.add_argument("--no-shuffle", action="store_true", help="keep the (time-ordered) sample order; the reference shuffles")
     ap.add_argument("--save-path", default=None, help="whole-module checkpoint written whenever the test rel-L2 improves "
                     "(run_pde_observers.py:307-315: torch.save(observer_model, './outputs/<path>_<exp>.pth'))")
     return ap
@@ -65,9 +66,33 @@ def save_if_best(model, test_l2, best, path, rank, log):
         return best
     if path and rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save(model, path)
+        # the trainer hangs run-time state on the modules (the overlap hook = the FlatGradBucket with its gradient buffer,
+        # process group and pending Work handle; direct-write flags; cached device grids): not part of a checkpoint
+        stripped = []
+        for m in model.modules():
+            for k in ("_grad_overlap", "_direct_grads", "_grid_cache"):
+                if k in m.__dict__:
+                    stripped.append((m, k, m.__dict__.pop(k)))
+        try:
+            torch.save(model, path)
+        finally:
+            for m, k, v in stripped:
+                m.__dict__[k] = v
         log(f"Best model saved at {path}!")
     return test_l2
+
+
+def make_train_loader(train_ds, args, world):
+    """run_pde_observers.py:29,90: DataLoader(train, batch_size, shuffle=train_shuffle (default True), drop_last=False).
+    The permutation comes from a generator seeded with args.seed, so every rank draws the same order and shard_batch cuts
+    the same global batch; only the data-parallel case drops the ragged tail (the global batch must split evenly)."""
+    shuffle = not getattr(args, "no_shuffle", False)
+    gen = torch.Generator().manual_seed(int(args.seed)) if shuffle else None
+    loader = DataLoader(train_ds, batch_size=args.batch_size * world, shuffle=shuffle, drop_last=world > 1, generator=gen)
+    if len(loader) == 0:
+        raise ValueError(f"empty training epoch: {len(train_ds)} samples < global batch {args.batch_size * world} "
+                         f"(batch_size {args.batch_size} x {world} ranks, the ragged tail is dropped under data parallelism)")
+    return loader
 
 
 def run(args, log=print):
@@ -88,7 +113,7 @@ def run(args, log=print):
     ds_args = types.SimpleNamespace(model_timestep=1)
     train_ds = PDEDataset(ds_args, args.data_folder, idx[:args.ntrain].tolist(), args.downsample_rate, args.x_range, args.y_range)
     test_ds = PDEDataset(ds_args, args.data_folder, idx[-args.ntest:].tolist(), args.downsample_rate, args.x_range, args.y_range)
-    train_loader = DataLoader(train_ds, batch_size=args.batch_size * world, shuffle=False, drop_last=True)
+    train_loader = make_train_loader(train_ds, args, world)
     test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
     if args.model == "FNO2dObserver":
         model = FNO2dObserver(args.modes, args.modes, args.width).to(dev)
@@ -145,7 +170,7 @@ def run_full_field(args, idx, dev, rank, world, log):
     mk = lambda ix: FullFieldNSDataset(ds_args, args.data_folder, ix.tolist(), args.plane_indexs, args.downsample_rate,
                                        args.x_range, args.y_range)
     train_ds, test_ds = mk(idx[:args.ntrain]), mk(idx[-args.ntest:])
-    train_loader = DataLoader(train_ds, batch_size=args.batch_size * world, shuffle=False, drop_last=True)
+    train_loader = make_train_loader(train_ds, args, world)
     test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
     P, L = len(args.plane_indexs), 4
     model = PINObserverFullField(plane_num=P, modes1=[args.modes] * L, modes2=[args.modes] * L, modes3=[args.modes] * L,

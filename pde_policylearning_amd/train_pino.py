@@ -57,10 +57,11 @@ def train_ns(model, train_u_loader, val_loader, optimizer, scheduler, device, co
             u, a_in, re = (shard_batch(t, rank, world) for t in (u, a_in, re))
         loss = train_step(model, bucket, optimizer, (a_in, re), (u, a_in, re), objective)
         scheduler.step()
-        if e % log_every == 0 or e == tcfg['num_iter'] - 1:
+        evaluate = val_loader is not None and e % tcfg['eval_step'] == 0       # train_pino.py:112-118: every eval_step iterations,
+        if e % log_every == 0 or e == tcfg['num_iter'] - 1 or evaluate:          # whatever the logging cadence is
             rec = {k: float(v) for k, v in objective.last_terms.items()}
             rec.update({'iter': e, 'train loss': float(loss) * world})
-            if val_loader is not None and e % tcfg['eval_step'] == 0:
+            if evaluate:
                 rec['val error'] = eval_ns(model, val_loader, lploss, device)[0]
             history.append(rec)
             if rank == 0:

@@ -121,10 +121,16 @@ class MultiStepLR(object):
         return [self.optimizer.lr]
 
     def state_dict(self):
-        return dict(milestones=self.milestones, gamma=self.gamma, base_lr=self.base_lr, last_epoch=self.last_epoch)
+        import collections
+        return dict(milestones=collections.Counter(self.milestones), gamma=self.gamma, base_lrs=[self.base_lr],
+                    last_epoch=self.last_epoch, _step_count=self.last_epoch + 1, _last_lr=[self.optimizer.lr])
 
     def load_state_dict(self, sd):
-        self.milestones, self.gamma, self.base_lr, self.last_epoch = sd["milestones"], sd["gamma"], sd["base_lr"], sd["last_epoch"]
+        """This class's own state or torch.optim.lr_scheduler.MultiStepLR's (milestones as a Counter, base_lrs list)."""
+        ms = sd["milestones"]
+        self.milestones = sorted(ms.elements()) if hasattr(ms, "elements") else sorted(ms)
+        self.gamma, self.last_epoch = sd["gamma"], sd["last_epoch"]
+        self.base_lr = sd["base_lr"] if "base_lr" in sd else sd["base_lrs"][0]
         self._apply()
 
 
@@ -174,6 +180,7 @@ class FlatGradBucket(object):
         and the remaining parameters are laid out at the tail of the bucket, which is the only part zero() clears."""
         self.direct_module = direct_module
         self.params = [p for p in params if p.requires_grad]
+        self.user_order = list(self.params)       # the order an optimizer built on the same iterable would number them in
         self.group = process_group
         direct_ids = set()
         if direct_module is not None:
@@ -304,17 +311,52 @@ class FusedAdam(object):
                     self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
 
     def state_dict(self):
+        """torch.optim.Adam's layout ({'state': {i: step / exp_avg / exp_avg_sq}, 'param_groups': [...]}, parameters numbered
+        in the order the bucket was given them), so that train_pino's {'model', 'optim', 'scheduler'} checkpoints
+        (libs/pino_utils/utils.py:178-194) load into torch.optim.Adam and back."""
         if self.capturable:
             self.step_count = int(self.step_dev.item())
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas,
-                    eps=self.eps, weight_decay=self.weight_decay)
+        pos = {id(p): i for i, p in enumerate(self.bucket.user_order)}
+        state = {}
+        for p, m, v in zip(self.bucket.params, self.bucket.views(self.exp_avg), self.bucket.views(self.exp_avg_sq)):
+            if self.step_count > 0:
+                state[pos[id(p)]] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.detach().clone(),
+                                         exp_avg_sq=v.detach().clone())
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(self.bucket.user_order))))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
+        """Accepts torch.optim.Adam's state_dict (a reference checkpoint's 'optim' entry) or this class's own."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("FusedAdam.load_state_dict: expected torch.optim.Adam's {'state', 'param_groups'} layout")
+        group = sd["param_groups"][0]
+        order = self.bucket.user_order
+        if len(group["params"]) != len(order):
+            raise ValueError(f"optimizer state holds {len(group['params'])} parameters, the bucket {len(order)}")
+        self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+        self.weight_decay = group["weight_decay"]
+        mv = {id(p): (m, v) for p, m, v in zip(self.bucket.params, self.bucket.views(self.exp_avg),
+                                                self.bucket.views(self.exp_avg_sq))}
+        steps = set()
+        with torch.no_grad():
+            for i, p in enumerate(order):
+                st = sd["state"].get(group["params"][i], sd["state"].get(i))
+                m, v = mv[id(p)]
+                if st is None:
+                    m.zero_(); v.zero_()
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+                m.copy_(st["exp_avg"].to(m.device)); v.copy_(st["exp_avg_sq"].to(v.device))
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state with different step counts per parameter ({sorted(steps)}): one flat Adam step "
+                             "cannot represent it")
+        self.step_count = steps.pop() if steps else 0
         if self.capturable:
             self.step_dev.fill_(self.step_count)
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -1628,3 +1628,63 @@ def test_pino_stack_chained_on_preactivations(dev, dims, width, modes):
         for a, b in zip(g1, g2):
             a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
             assert float((a - b).norm()) <= 2e-5 * float(b.norm()), (route, tuple(a.shape))
+
+
+@pytest.mark.gpu
+def test_fused_adam_state_round_trips_through_torch_adam(dev):
+    """train_pino's checkpoints carry the optimizer and scheduler state in torch's own layout
+    (libs/pino_utils/utils.py:178-194: optimizer.state_dict()): FusedAdam / trainer.MultiStepLR state loads into
+    torch.optim.Adam / MultiStepLR and back, whatever order the bucket keeps its parameters in, and both continue on the
+    same trajectory."""
+    from pde_policylearning_amd.libs.models.pino_models import PINObserverFullField
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, MultiStepLR, train_step
+    torch.manual_seed(3)
+    mk = lambda: PINObserverFullField(plane_num=2, modes1=[4] * 4, modes2=[4] * 4, modes3=[3] * 4, fc_dim=32, layers=[16] * 5,
+                                      in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+    m1, m2 = mk(), mk()
+    m2.load_state_dict(m1.state_dict())
+    bucket = FlatGradBucket(m1.parameters(), direct_module=m1)          # reorders: spectral weights first
+    assert [id(p) for p in bucket.params] != [id(p) for p in bucket.user_order]
+    opt = FusedAdam(bucket, lr=2e-3, weight_decay=1e-4)
+    sch = MultiStepLR(opt, milestones=[2, 4], gamma=0.5)
+    ref = torch.optim.Adam(m2.parameters(), lr=2e-3, weight_decay=1e-4)
+    rsch = torch.optim.lr_scheduler.MultiStepLR(ref, milestones=[2, 4], gamma=0.5)
+    loss_fn = FusedLpLoss(size_average=False)
+    data = [(torch.randn(3, 16, 16, 1, 1, device=dev), torch.rand(3, 1, device=dev) * 100 + 100,
+             torch.randn(3, 2, 16, 16, 1, device=dev)) for _ in range(5)]
+
+    def ref_step(x, re, tgt):
+        ref.zero_grad()
+        O.lp_loss_rel_sum(m2(x, re).reshape(3, -1), tgt.reshape(3, -1)).backward()
+        ref.step()
+        rsch.step()
+    for x, re, tgt in data[:3]:
+        train_step(m1, bucket, opt, (x, re), tgt, loss_fn)
+        sch.step()
+        ref_step(x, re, tgt)
+    # our state -> torch optimizer / scheduler built from scratch
+    ref2 = torch.optim.Adam(m2.parameters(), lr=1.0)
+    ref2.load_state_dict(opt.state_dict())
+    rsch2 = torch.optim.lr_scheduler.MultiStepLR(ref2, milestones=[1], gamma=0.1)
+    rsch2.load_state_dict(sch.state_dict())
+    assert abs(ref2.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12 and rsch2.last_epoch == rsch.last_epoch
+    for a, b in zip(ref.state_dict()["state"].values(), ref2.state_dict()["state"].values()):
+        assert float(a["step"]) == float(b["step"])
+        ea, eb = (torch.view_as_real(t) if t.is_complex() else t for t in (a["exp_avg"], b["exp_avg"]))
+        assert float((ea - eb).norm()) <= 2e-5 * float(ea.norm()) + 1e-12
+    # torch state -> a fresh FusedAdam / MultiStepLR; both continue identically
+    m3 = mk()
+    m3.load_state_dict(m2.state_dict())
+    b3 = FlatGradBucket(m3.parameters(), direct_module=m3)
+    opt3 = FusedAdam(b3, lr=1.0)
+    opt3.load_state_dict(ref.state_dict())
+    sch3 = MultiStepLR(opt3, milestones=[1], gamma=0.1)
+    sch3.load_state_dict(rsch.state_dict())
+    assert abs(opt3.lr - ref.param_groups[0]["lr"]) < 1e-12 and opt3.step_count == 3
+    for x, re, tgt in data[3:]:
+        train_step(m3, b3, opt3, (x, re), tgt, loss_fn)
+        sch3.step()
+        ref_step(x, re, tgt)
+    for (n, a), b in zip(m3.named_parameters(), m2.parameters()):
+        a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a.detach(), b.detach()))
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()), n

@@ -10,7 +10,7 @@ $T python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "headline done" >> $out/${tag}_progress.log
 if [ -z "$quick" ]; then
 $T python3 bench.py --config fno2d_64x64_w32_m8_b4 --steps 50 > $out/${tag}_bench_cfg1.json 2>> $out/${tag}_bench.err
-$T python3 bench.py --config fno2d_64x64_w32_m8_b4 --no-cpu-baseline --steps 50 --graph > $out/${tag}_bench_cfg1_graph.json 2>> $out/${tag}_bench.err
+$T python3 bench.py --config fno2d_64x64_w32_m8_b4 --no-cpu-baseline --steps 50 --eager > $out/${tag}_bench_cfg1_eager.json 2>> $out/${tag}_bench.err
 $T python3 bench.py --config fno3d_64_w32_m8_b16 --steps 10 > $out/${tag}_bench_fno3d.json 2>> $out/${tag}_bench.err
 for c in rno2d_128x128_w64_m12_b32 rno2d_32x32_w34_m12_b32 pino_fullfield_32x32_w64_m12_b32 pino_fullfield_pde_32x130x32_w64_m12_b32 \
          pinobserver2d_128x128x65_w64_m8_b2 pino_finetune_128x128x65_w64_m8_b4 pino_finetune_256x256x65_w64_m20_b1; do
