@@ -224,10 +224,15 @@ def main():
     if overlap:
         # [projection | blocks L-1..1] go on the wire (async RCCL all-reduce) while block 0 and the lifting are differentiated
         bucket = FlatGradBucket.for_fno(model, split_layer=1)
-        bucket.force_collective = force_dist
     else:
         # fused FNO: every gradient is written in place; PINO observers: their spectral weights (> 99 % of the bytes) are
         bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model or cfg["kind"].startswith("pino") else None)
+    bucket.force_collective = force_dist
+    if not fused_model:
+        # layer-ordered segments go on the wire as their gradients complete; dead last-dim slices of the dialect-C weights
+        # (PINObserverFullField at T = 1: 11/12 of 906 MB) are never exchanged.  Single GPU: the plan is only reported.
+        from pde_policylearning_amd.trainer import enable_dp_exchange
+        enable_dp_exchange(bucket, model, tuple(t[:1] for t in inputs))
     opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
     if cfg["kind"] == "pino2d_train":
@@ -465,6 +470,10 @@ def main():
                          if _lib.lib().fno_get_gemm_mode() == 1 else "f32 (v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
             "n_ranks": dist.get_world_size() if dist_on else 1,
+            "gradient_exchange": {"bucket_bytes": 4 * bucket.flat.numel(), "wire_bytes_per_rank_per_step": bucket.planned_wire_bytes(),
+                                  "segments": len(getattr(bucket, "_segments", None) or [1]),
+                                  "kind": "overlapped late-layer segment + rest" if overlap else
+                                          ("segmented, live slices of dialect-C weights only" if not fused_model else "single all-reduce")},
             "git_sha": git_sha(),
             "source_hash": source_hash(),
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,

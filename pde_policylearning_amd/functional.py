@@ -55,6 +55,17 @@ def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, in
     return plan
 
 
+# Listeners for gradients the engine writes straight into the caller's storage (direct_grads): autograd never sees those
+# tensors, so a data-parallel trainer that starts a gradient exchange as soon as a segment is complete
+# (trainer.FlatGradBucket.enable_segmented_exchange) learns about them here.  Called with the list of written tensors.
+DIRECT_WRITE_HOOKS = []
+
+
+def _notify_direct(tensors):
+    for h in DIRECT_WRITE_HOOKS:
+        h(tensors)
+
+
 class _SpectralConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, modes, norm, weight_last_extent, direct, *weights):
@@ -104,6 +115,7 @@ class _SpectralConvFn(torch.autograd.Function):
             _lib.check(L.fno_spec_backward(ctx.plan, ctx.B, _ptr(dy), _ptr(xhat), wp, _ptr(dx),
                                            dwp, _ptr(db), _ptr(ws), nws, _stream()), "spec_backward")
         if direct is not None:                     # written in place into the caller's gradient storage
+            _notify_direct(direct)
             return (dx, db, None, None, None, None) + (None,) * len(ws_list)
         return (dx, db, None, None, None, None) + (tuple(dws) if need_dw else (None,) * len(ws_list))
 
@@ -424,6 +436,8 @@ class _FNOBlocksFn(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
                                                C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "blocks_backward")
+        if ctx.direct is not None:
+            _notify_direct(ctx.direct)
         return (None, dx, g_sb) + tuple(g_skip) + ((None,) * len(g_spec) if ctx.direct is not None else tuple(g_spec))
 
 
@@ -1038,6 +1052,8 @@ class _SpectralLayerFn(torch.autograd.Function):
             _lib.check(L.fno_pointwise_backward(B, Cc, pw, _ptr(u), _ptr(w2), _ptr(dy), _ptr(da), 1 if input_gelu else 0, _ptr(du),
                                                 _ptr(dw), _ptr(db), _ptr(ws2), nws2, _stream()), "pointwise_backward")
         gw = (None,) * len(ws_list) if (direct is not None or not need_dws) else tuple(dws)
+        if direct is not None:
+            _notify_direct(direct)
         return (du, dw.view(wshape), db, None, None, None, None, None) + gw
 
 

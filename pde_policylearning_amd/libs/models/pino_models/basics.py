@@ -44,6 +44,7 @@ class SpectralConv3d(nn.Module):
     def engine_call(self, x):
         """(corner weights in the engine's order, kept modes, stored last-dim extent) for an input of x's shape"""
         k3 = min(x.shape[-1] // 2 + 1, self.modes3)
+        self._live_last = k3      # last-dim modes that receive a gradient (trainer.live_last_of: live-slice gradient exchange)
         return [self.weights1, self.weights3, self.weights2, self.weights4], (self.modes1, self.modes2, k3), self.modes3
 
     def forward(self, x):
@@ -51,6 +52,7 @@ class SpectralConv3d(nn.Module):
         # (basics.py:125-139); the engine takes (lo,lo), (lo,hi), (hi,lo), (hi,hi).  Only
         # min(Nz/2+1, modes3) last-dim modes are live (:119,:125-126); the rest get zero gradient.
         k3 = min(x.shape[-1] // 2 + 1, self.modes3)
+        self._live_last = k3
         return F.spectral_conv(x, [self.weights1, self.weights3, self.weights2, self.weights4], None,
                                (self.modes1, self.modes2, k3), "backward", weight_last_extent=self.modes3,
                                direct_grads=getattr(self, "_direct_grads", False))

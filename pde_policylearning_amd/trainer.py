@@ -235,13 +235,121 @@ class FlatGradBucket(object):
         self.check_views()
         if not self._collective_needed():
             self._inflight = None
+            for sg in getattr(self, "_segments", []):
+                sg["work"], sg["pending"] = None, set(sg["ids"])
             return
+        if getattr(self, "_segments", None) is not None:
+            self.wire_bytes = self.wire_bytes if any(sg["work"] is not None for sg in self._segments) else 0
+            self._finish_segments()
+            self.wire_bytes_last, self.wire_bytes = self.wire_bytes, 0
+            return
+        self.wire_bytes_last = 4 * self.flat.numel()
         work, self._inflight = getattr(self, "_inflight", None), None
         if work is not None:
             dist.all_reduce(self.flat[self._late_numel:], op=dist.ReduceOp.SUM, group=self.group)
             work.wait()
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- segmented exchange: any model, segments go on the wire as their gradients complete ---------------------------
+    def enable_segmented_exchange(self, min_bytes=16 << 20, live_last=None):
+        """Cut the bucket into segments of consecutive parameters (>= min_bytes each, big parameters alone) and start an
+        ASYNC all-reduce of a segment as soon as the backward pass has produced all of its gradients: autograd's
+        post-accumulate hooks for ordinary parameters, functional.DIRECT_WRITE_HOOKS for gradients the engine writes in
+        place.  all_reduce() then waits for the segments in flight and exchanges what is left.  Same sums as the single
+        exchange: every element is reduced exactly once.
+
+        live_last: {parameter: k} for dialect-C spectral weights (.., m3) of which only the last-dim slice [..., :k] can
+        receive a gradient (libs/models/pino_models/basics.py:119-139 zero-pads the spectrum to modes3: with Nz/2+1 <
+        modes3 the rest of the weight never sees data).  Their dead slices are exactly zero on every rank, so only the live
+        slice is packed and exchanged (PINObserverFullField at T = 1: 1/12 of 906 MB)."""
+        from . import functional as F
+        live_last = live_last or {}
+        self._live = {id(p): int(k) for p, k in live_last.items() if int(k) < p.shape[-1]}
+        segs, cur, cur_bytes, off = [], None, 0, 0
+        for p in self.params:
+            n = self._nfloat(p)
+            sliced = id(p) in self._live
+            if cur is None or cur_bytes >= min_bytes or sliced != cur["sliced"]:
+                cur = dict(start=off, end=off, params=[], sliced=sliced)
+                segs.append(cur)
+                cur_bytes = 0
+            cur["params"].append(p)
+            cur["end"] = off + n
+            cur_bytes += 4 * n
+            off += n
+        for sg in segs:
+            sg["ids"] = {id(p) for p in sg["params"]}
+            sg["pending"], sg["work"], sg["pack"] = set(sg["ids"]), None, None
+            if sg["sliced"]:
+                nlive = sum(self._nfloat(p) // p.shape[-1] * self._live[id(p)] for p in sg["params"])
+                sg["pack"] = torch.zeros(nlive, dtype=torch.float32, device=self.flat.device)
+        self._segments = segs
+        self._seg_of = {i: sg for sg in segs for i in sg["ids"]}
+        self._by_ptr = {}
+        self.wire_bytes = 0
+        for p, v in zip(self.params, self.views(self.flat)):
+            self._by_ptr[(torch.view_as_real(v) if v.is_complex() else v).data_ptr()] = p
+            p.register_post_accumulate_grad_hook(self._arrived)
+        F.DIRECT_WRITE_HOOKS.append(self._direct_written)
+        return self
+
+    def planned_wire_bytes(self):
+        """bytes one rank puts on the wire per step: the whole bucket, or with a segmented exchange the segments' buffers
+        (live slices only for the dialect-C weights)"""
+        segs = getattr(self, "_segments", None)
+        if segs is None:
+            return 4 * self.flat.numel()
+        return sum(4 * (sg["pack"].numel() if sg["sliced"] else sg["end"] - sg["start"]) for sg in segs)
+
+    def _direct_written(self, tensors):
+        for t in tensors:
+            p = self._by_ptr.get(t.data_ptr())
+            if p is not None:
+                self._arrived(p)
+
+    def _arrived(self, p):
+        sg = self._seg_of.get(id(p))
+        if sg is None or sg["work"] is not None:
+            return
+        sg["pending"].discard(id(p))
+        if not sg["pending"] and self._collective_needed():
+            self._launch(sg, async_op=True)
+
+    def _live_views(self, sg):
+        """(live slice of the gradient, its place in the pack buffer) for every parameter of a sliced segment"""
+        out, off = [], 0
+        gviews = {id(p): v for p, v in zip(self.params, self.views(self.flat))}
+        for p in sg["params"]:
+            g = gviews[id(p)]
+            g = torch.view_as_real(g) if g.is_complex() else g.unsqueeze(-1)
+            k = self._live[id(p)]
+            live = g[..., :k, :]
+            out.append((live, sg["pack"][off:off + live.numel()].view(live.shape)))
+            off += live.numel()
+        return out
+
+    def _launch(self, sg, async_op):
+        if sg["sliced"]:
+            for live, slot in self._live_views(sg):
+                slot.copy_(live)
+            buf = sg["pack"]
+        else:
+            buf = self.flat[sg["start"]:sg["end"]]
+        self.wire_bytes += 4 * buf.numel()
+        sg["work"] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op) or True
+
+    def _finish_segments(self):
+        for sg in self._segments:
+            if sg["work"] is None:
+                self._launch(sg, async_op=False)
+        for sg in self._segments:
+            if sg["work"] is not True and sg["work"] is not None:
+                sg["work"].wait()
+            if sg["sliced"]:
+                for live, slot in self._live_views(sg):
+                    live.copy_(slot)
+            sg["work"], sg["pending"] = None, set(sg["ids"])
 
     # ---- overlap of the gradient exchange with the backward pass (engine FNO only) -------------------------
     @classmethod
@@ -276,6 +384,31 @@ class FlatGradBucket(object):
         if self._collective_needed():
             self._inflight = dist.all_reduce(self.flat[:self._late_numel], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True)
+
+
+def enable_dp_exchange(bucket, model, sample_inputs=None, min_bytes=16 << 20):
+    """Segmented, overlapped gradient exchange for any model (the fused FNO has its own: FlatGradBucket.for_fno), with the
+    dead last-dim slices of dialect-C weights left off the wire.  The live extents depend on the input's last dimension, so
+    one forward pass under no_grad on `sample_inputs` (any batch size) records them first."""
+    if sample_inputs is not None:
+        was = model.training
+        model.eval()
+        with torch.no_grad():
+            model(*sample_inputs)
+        model.train(was)
+    return bucket.enable_segmented_exchange(min_bytes=min_bytes, live_last=live_last_of(model))
+
+
+def live_last_of(model):
+    """{weight: live last-dim extent} of the dialect-C 3-D spectral convolutions in `model` after a forward pass (the extent
+    depends on the input's last dimension): the argument of FlatGradBucket.enable_segmented_exchange(live_last=...)."""
+    out = {}
+    for m in model.modules():
+        k = m.__dict__.get("_live_last")
+        if k is not None and hasattr(m, "modes3"):
+            for w in (m.weights1, m.weights2, m.weights3, m.weights4):
+                out[w] = int(k)
+    return out
 
 
 class FusedAdam(object):

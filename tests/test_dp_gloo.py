@@ -187,3 +187,111 @@ def test_overlapped_bucket_reduces_every_element_once():
     # projection (256*32 + 256 + 256 + 1) + 3 blocks x (32*32 skip + 2 corners x 32*32*4*4*2)
     assert late == 256 * 32 + 256 + 256 + 1 + 3 * (32 * 32 + 2 * 32 * 32 * 4 * 4 * 2)
     assert all(r[2] for r in res)
+
+
+class OraclePinoFF(nn.Module):
+    """nn.Module facade over oracle.observers_oracle.pinobserver_fullfield_forward (reference parameter names of
+    libs/models/pino_models/pinobserver.py: PINObserverFullField with plane_num 2, width 6, modes 3 x 3 x 4).  With the T = 1
+    inputs of run_pde_observers.py:201-207 only the last-dim slice [..., :1] of the dialect-C weights ever sees data."""
+    LAYERS, MODES = [6] * 5, [(3, 3, 4)] * 4
+
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        C, fc, P = 6, 8, 2
+        shapes = {"fc0.weight": (C, 1), "fc0.bias": (C,)}
+        for k in ("multiplicative_net1", "multiplicative_net2"):
+            shapes.update({f"{k}.A": (C, 1), f"{k}.B": (C, C), f"{k}.bias": (C,)})
+        for i in range(4):
+            for j in (1, 2, 3, 4):
+                shapes[f"observer_head.sp_convs.{i}.weights{j}"] = (C, C, 3, 3, 4)
+            shapes[f"observer_head.ws.{i}.weight"] = (C, C, 1)
+            shapes[f"observer_head.ws.{i}.bias"] = (C,)
+        shapes.update({"observer_head.fc1.weight": (fc, C), "observer_head.fc1.bias": (fc,),
+                       "observer_head.fc2.weight": (P, fc), "observer_head.fc2.bias": (P,)})
+        self.names = list(shapes)
+        ps = []
+        for k, sh in shapes.items():
+            cplx = "weights" in k
+            t = torch.randn(*sh, dtype=torch.cfloat if cplx else torch.float32, generator=g) * (0.3 if not cplx else 0.2)
+            ps.append(nn.Parameter(t))
+        self.ps = nn.ParameterList(ps)
+
+    def spectral_weights(self):
+        return [p for n, p in zip(self.names, self.ps) if "weights" in n]
+
+    def forward(self, x, re):
+        from oracle import observers_oracle as OO
+        return OO.pinobserver_fullfield_forward(dict(zip(self.names, self.ps)), x, re, self.LAYERS, self.MODES, [0.0, 0.0625])
+
+
+def _pino_batch():
+    g = torch.Generator().manual_seed(7)
+    return (torch.randn(4, 8, 8, 1, 1, generator=g), torch.rand(4, 1, generator=g) * 100 + 100,
+            torch.randn(4, 2, 8, 8, 1, generator=g))
+
+
+def _pino_steps(model, bucket, inputs, tgt, steps=3):
+    from pde_policylearning_amd.trainer import LpLoss, train_step
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    loss_fn = lambda y, t: LpLoss(size_average=False)(y.reshape(y.shape[0], -1), t.reshape(t.shape[0], -1))
+    return [float(train_step(model, bucket, opt, inputs, tgt, loss_fn)) for _ in range(steps)]
+
+
+def _pino_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pde_policylearning_amd.trainer import FlatGradBucket, broadcast_parameters, shard_batch
+    model = OraclePinoFF(seed=50 + rank)             # different per rank: broadcast must fix it
+    broadcast_parameters(model)
+    x, re, tgt = _pino_batch()
+    bucket = FlatGradBucket(model.parameters())
+    if mode != "single":
+        live = {w: 1 for w in model.spectral_weights()} if mode == "live" else None      # T = 1: one live last-dim mode
+        bucket.enable_segmented_exchange(min_bytes=2048, live_last=live)
+    losses = _pino_steps(model, bucket, (shard_batch(x, rank, world), shard_batch(re, rank, world)), shard_batch(tgt, rank, world))
+    tot = torch.tensor(losses)
+    dist.all_reduce(tot)
+    flat = torch.cat([torch.view_as_real(p.detach()).reshape(-1) if p.is_complex() else p.detach().reshape(-1)
+                      for p in model.parameters()])
+    q.put((rank, mode, tot.tolist(), flat.numpy(), getattr(bucket, "wire_bytes_last", None), 4 * bucket.flat.numel(),
+           len(getattr(bucket, "_segments", []))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["single", "segmented", "live"])
+def test_pino_observer_dp_exchange_modes_equal_single_process(mode):
+    """World-size-2 data parallelism of an oracle PINObserverFullField: one all-reduce of the bucket, the segmented exchange
+    (segments start as their gradients complete) and the live-slice exchange (dead last-dim modes of the dialect-C weights stay
+    off the wire) all train exactly like ONE process on the whole batch; the live-slice mode moves ~1/4 of the spectral bytes
+    here (1 of 4 last-dim modes), 1/12 at the shipped modes3 = 12."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pino_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model = OraclePinoFF(seed=50)
+    x, re, tgt = _pino_batch()
+    ref_losses = _pino_steps(model, FlatGradBucket(model.parameters()), (x, re), tgt)
+    ref_flat = torch.cat([torch.view_as_real(p.detach()).reshape(-1) if p.is_complex() else p.detach().reshape(-1)
+                          for p in model.parameters()]).numpy()
+    for rank, _, losses, flat, wire, full, nseg in res:
+        assert np.allclose(losses, ref_losses, rtol=1e-5), (losses, ref_losses)
+        assert np.abs(flat - ref_flat).max() < 2e-6 * max(1.0, np.abs(ref_flat).max())
+        if mode == "single":
+            assert wire == full
+        elif mode == "segmented":
+            assert wire == full and nseg > 1
+        else:
+            spec = 16 * 6 * 6 * 3 * 3 * 4 * 2 * 4              # bytes of the spectral weights
+            assert wire == full - spec + spec // 4 and nseg > 1
+    assert np.array_equal(res[0][3], res[1][3])

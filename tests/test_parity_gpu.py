@@ -1668,7 +1668,10 @@ def test_fused_adam_state_round_trips_through_torch_adam(dev):
     rsch2 = torch.optim.lr_scheduler.MultiStepLR(ref2, milestones=[1], gamma=0.1)
     rsch2.load_state_dict(sch.state_dict())
     assert abs(ref2.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12 and rsch2.last_epoch == rsch.last_epoch
-    for a, b in zip(ref.state_dict()["state"].values(), ref2.state_dict()["state"].values()):
+    sa, sb = ref.state_dict()["state"], ref2.state_dict()["state"]
+    assert sorted(sa) == sorted(sb)
+    for k in sorted(sa):
+        a, b = sa[k], sb[k]
         assert float(a["step"]) == float(b["step"])
         ea, eb = (torch.view_as_real(t) if t.is_complex() else t for t in (a["exp_avg"], b["exp_avg"]))
         assert float((ea - eb).norm()) <= 2e-5 * float(ea.norm()) + 1e-12
