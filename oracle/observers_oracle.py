@@ -107,7 +107,7 @@ def _pads(size_z, pad_ratio):
 
 def pinobserver2d_forward(p, x, re, layers, modes, pad_ratio):
     """pinobserver.py:192-233."""
-    re = re.float()
+    re = re if re.dtype == torch.float64 else re.float()      # (float64 passes through: error-budget runs)
     num_pad = _pads(x.shape[-2], pad_ratio)
     x = x @ p["fc0.weight"].t() + p["fc0.bias"]
     x = multiplicative_net(_sub(p, "multiplicative_net1."), x, re).permute(0, 4, 1, 2, 3)
@@ -123,7 +123,7 @@ def pinobserver2d_forward(p, x, re, layers, modes, pad_ratio):
 
 def pinobserver_fullfield_forward(p, x, re, layers, modes, pad_ratio, max_re=1000):
     """pinobserver.py:341-375 + PlanePredHead.forward :257-273."""
-    re = re.float() / max_re
+    re = (re if re.dtype == torch.float64 else re.float()) / max_re
     num_pad = _pads(x.shape[-2], pad_ratio)
     x = x @ p["fc0.weight"].t() + p["fc0.bias"]
     x = multiplicative_net(_sub(p, "multiplicative_net1."), x, re).permute(0, 4, 1, 2, 3)

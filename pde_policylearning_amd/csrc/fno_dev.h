@@ -198,6 +198,21 @@ FNO_DEV float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 FNO_DEV bf16x8 buf_ld8h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// The same step with the hh products and the five cross terms in SEPARATE accumulators.  The bf16 MFMA truncates the
+// aligned addends of its fp32 accumulation: with small and large products in one accumulator every element carries a bias
+// of about -1e-8 of its magnitude (tools/mfma_bias_test.hip) - invisible in a relative-L2 check of the GEMM, but DC-type
+// reductions further down (bias gradients, k = 0 modes, lifting weights: sums over ~1e6 pixels of a zero-mean signal)
+// amplify it by sqrt(#pixels).  Split, the bias drops 50x and the GEMM error halves (5e-8 at K = 64).  Every GEMM whose
+// result feeds activations or the dx chain uses this form; `hi` may be a long-running accumulator (products of one size
+// class), `lo` is summed into the result once.
+FNO_DEV void mfma_x3s(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+}
 FNO_DEV bf16x8 ld8h(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
 FNO_DEV void st8h(unsigned short* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 

@@ -33,15 +33,6 @@ FNO_DEV bf16x8 cat4(s16x4 lo, s16x4 hi) {
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
-// 3-way split GEMM step with the hh products and the cross terms in separate accumulators (see above)
-FNO_DEV void mfma_x3s(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
-  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
-  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
-  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
-  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
-  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
-  hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
-}
 // 4 consecutive pixels of one row -> the three bf16 terms, 8 bytes each, at byte offset `off` of the three term planes
 FNO_DEV void put_split4(unsigned char* img, int term_bytes, int off, const float4& t) {
   const float tv[4] = {t.x, t.y, t.z, t.w};

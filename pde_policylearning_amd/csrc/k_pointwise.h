@@ -307,15 +307,18 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
 #pragma unroll
     for (int q = 0; q < NTW; ++q) {
       const int n0 = (ng * NTW + q) * 32;
+      f32x16 lo;          // cross terms of the split: own accumulator (fno_dev.h: mfma_x3s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { acc[q][r] = 0.0f; lo[r] = 0.0f; }
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         bf16x8 bf[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) bf[t] = ld8h(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
-        acc[q] = mfma_x3(afrag[kb], bf, acc[q]);
+        mfma_x3s(afrag[kb], bf, acc[q], lo);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] += lo[r];
       if constexpr (LOOSE) {
         if (a.z) acc[q] = kext_loose_rows<C>(acc[q], zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
       } else if (a.z) {

@@ -508,17 +508,19 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     for (int ch = 0; ch < NCH; ++ch) {
       if (ch == 1) FNO_STAMP(tslot + 5);
       // ---- A1 ------------------------------------------------------------
-      f32x16 acc;
+      f32x16 acc, lo1;     // hh products / cross terms of the split (fno_dev.h: mfma_x3s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo1[r] = 0.f; }
       {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           bf16x8 bf[3];
 #pragma unroll
           for (int t = 0; t < 3; ++t) bf[t] = ld8h(xbp + t * SP::TERM + kb * 16);
-          acc = mfma_x3(afn[kb], bf, acc);
+          mfma_x3s(afn[kb], bf, acc, lo1);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += lo1[r];
       }
       if (ch == 1) FNO_STAMP(tslot + 6);
       // ---- E ---------------------------------------------------------------
@@ -573,14 +575,19 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
       {
         const unsigned short* wa = a.wa3 + ((size_t)((ch * 2 + hm) * 2 * MT * 3) * 64 + lane) * 8;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int mc = 0; mc < MT; ++mc) {
+          f32x16 lo3;
 #pragma unroll
-          for (int mc = 0; mc < MT; ++mc) {
+          for (int r = 0; r < 16; ++r) lo3[r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
             bf16x8 af[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)((s * MT + mc) * 3 + t) * 64 * 8);
-            acc2[mc] = mfma_x3(af, bd[s], acc2[mc]);
+            mfma_x3s(af, bd[s], acc2[mc], lo3);
           }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[mc][r] += lo3[r];
         }
       }
       // W1 fragments of the NEXT chunk: L2 latency hides behind the barrier and the dW1 phase
@@ -746,23 +753,24 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
     for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-      f32x16 acc;
+      f32x16 acc, lo;      // hh products / cross terms of the split (fno_dev.h: mfma_x3s)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo[r] = 0.f; }
       const unsigned short* wa = w1b + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         bf16x8 af[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
-        acc = mfma_x3(af, bfrag[kb], acc);
+        mfma_x3s(af, bfrag[kb], acc, lo);
       }
       const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
       const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ro = (r & 3) + 8 * (r >> 2);
-        const float gl = RELU ? fmaxf(acc[r] + b1p[ro], 0.f) : gelu_f(acc[r] + b1p[ro]);
+        const float p1 = acc[r] + lo[r] + b1p[ro];
+        const float gl = RELU ? fmaxf(p1, 0.f) : gelu_f(p1);
 #pragma unroll
         for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
       }

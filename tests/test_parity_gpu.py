@@ -222,6 +222,25 @@ def _fno_params(C, L, half_modes, cin=3, cout=1, seed_tag="p"):
     return {k: torch.from_numpy(fill_named(seed_tag + k, s, sc[k])) for k, s in shapes.items()}
 
 
+BUDGET_SLACK = 2.0
+
+
+def _within_budget(err_engine, err_ref32, what):
+    """1e-5 relative L2 against the float64 value - except on tensors where the reference's OWN float32 evaluation is further
+    than that from float64 (ill-conditioned gradients: norms 1000x below their neighbours', see tools/edge_budget.py and
+    profiles/r02_edge_budget.txt); there the engine must stay within BUDGET_SLACK x the reference's float32 error."""
+    assert err_engine < max(TOL_G, BUDGET_SLACK * err_ref32), (what, err_engine, err_ref32)
+
+
+def _oracle_fno_fp64(p, x, tgt, modes, L):
+    """The oracle in float64 on float64 copies of the same float32 inputs / parameters: the value both float32 evaluations
+    (the reference's and the engine's) approximate.  Returns (y, {name: grad}) as float64 numpy arrays."""
+    pc = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    yc = O.fno_forward(pc, x.double(), modes, n_layers=L)
+    O.lp_loss_rel_sum(yc, tgt.double()).backward()
+    return yc.detach().numpy(), {k: v.grad.numpy() for k, v in pc.items()}
+
+
 @pytest.mark.parametrize("C,S,modes,B,L", [(32, 32, (8, 8), 3, 4), (64, 64, (12, 10), 2, 2),
                                            (32, 128, (16, 16), 1, 3), (64, 256, (12, 12), 1, 1),
                                            (64, 32, (16, 16), 2, 2),      # 4 rows per tile x 8 modes: more Z rows than threads
@@ -234,14 +253,14 @@ def test_fno2d_vs_oracle(dev, C, S, modes, B, L, gemm_mode):
     p = _fno_params(C, L, half)
     x = torch.from_numpy(fill_named("x", (B, 3, S, S), 1.0))
     tgt = torch.from_numpy(fill_named("t", (B, 1, S, S), 1.0))
+    y64, g64 = _oracle_fno_fp64(p, x, tgt, modes, L)
     pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    yc = O.fno_forward(pc, x, modes, n_layers=L)
-    O.lp_loss_rel_sum(yc, tgt).backward()
+    O.lp_loss_rel_sum(O.fno_forward(pc, x, modes, n_layers=L), tgt).backward()
     y, pg = _run_fused(p, x, modes, dev, n_layers=L)
-    assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    assert rel_l2(_cpu(y), y64) < TOL_Y
     O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
     for k in p:
-        assert rel_l2(_cpu(pg[k].grad), pc[k].grad.numpy()) < TOL_G, k
+        _within_budget(rel_l2(_cpu(pg[k].grad), g64[k]), rel_l2(pc[k].grad.numpy(), g64[k]), k)
 
 
 def test_fno2d_fullsize_properties(dev):
@@ -385,15 +404,23 @@ def test_pino_finetune_config5_as_named_vs_oracle(dev):
         return y
     y, names = _profiled_kernels(run)
     assert CFG5_KERNELS <= names, CFG5_KERNELS - names
-    pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    yc = OO.pinobserver2d_forward(pc, x.cpu(), re.cpu(), [64] * 5, [(20, 20, 20)] * 4, [0.0625, 0.0625])
-    O.lp_loss_rel_sum(yc, tgt.cpu()).backward()
+    # the oracle in float64 on float64 copies of the same parameters / inputs (the value the reference's float32 run approximates)
+    pc = {k: v.detach().cpu().to(torch.complex128 if v.is_complex() else torch.float64).requires_grad_(True)
+          for k, v in model.state_dict().items()}
+    yc = OO.pinobserver2d_forward(pc, x.cpu().double(), re.cpu().double(), [64] * 5, [(20, 20, 20)] * 4, [0.0625, 0.0625])
+    O.lp_loss_rel_sum(yc, tgt.cpu().double()).backward()
     assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    del yc
+    # ... and in float32, for the tensors whose float32 evaluation is itself further than 1e-5 from float64
+    p32 = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    O.lp_loss_rel_sum(OO.pinobserver2d_forward(p32, x.cpu(), re.cpu(), [64] * 5, [(20, 20, 20)] * 4, [0.0625, 0.0625]),
+                      tgt.cpu()).backward()
+    rr = lambda t: torch.view_as_real(t) if t.is_complex() else t
     for name, prm in model.named_parameters():
-        got, want = prm.grad, pc[name].grad
-        if got.is_complex():
-            got, want = torch.view_as_real(got), torch.view_as_real(want)
-        assert rel_l2(_cpu(got), want.numpy()) < TOL_G, name
+        want = rr(pc[name].grad).numpy()
+        _within_budget(rel_l2(_cpu(rr(prm.grad)), want), rel_l2(rr(p32[name].grad).numpy(), want), name)
+        pc[name].grad = None
+        p32[name].grad = None
 
 
 def test_pino_finetune_config5_as_named_fullsize(dev):
@@ -1022,7 +1049,7 @@ def test_graphed_train_step_equals_eager(dev):
         l2 = step2()
         assert float(l1) == float(l2), i
     assert torch.equal(o1.flat_param, o2.flat_param)
-    assert o2.state_dict()["step"] == 4
+    assert all(int(st["step"]) == 4 for st in o2.state_dict()["state"].values())      # device-side step counter
 
 
 def test_rno_gates_match_torch_formulas(dev):
@@ -1068,15 +1095,15 @@ def test_fno2d_channel_and_layer_edges_vs_oracle(dev, C, cin, cout, L, S, B):
     p = _fno_params(C, L, half, cin=cin, cout=cout, seed_tag="e")
     x = torch.from_numpy(fill_named("xe", (B, cin, S, S), 1.0))
     tgt = torch.from_numpy(fill_named("te", (B, cout, S, S), 1.0))
+    y64, g64 = _oracle_fno_fp64(p, x, tgt, modes, L)
     pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    yc = O.fno_forward(pc, x, modes, n_layers=L)
-    O.lp_loss_rel_sum(yc, tgt).backward()
+    O.lp_loss_rel_sum(O.fno_forward(pc, x, modes, n_layers=L), tgt).backward()
     y, pg = _run_fused(p, x, modes, dev, n_layers=L)
     assert y.shape == (B, cout, S, S)
-    assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    assert rel_l2(_cpu(y), y64) < TOL_Y
     O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
     for k in p:
-        assert rel_l2(_cpu(pg[k].grad), pc[k].grad.numpy()) < TOL_G, k
+        _within_budget(rel_l2(_cpu(pg[k].grad), g64[k]), rel_l2(pc[k].grad.numpy(), g64[k]), k)
 
 
 def test_block_stack_3d_vs_oracle(dev):
