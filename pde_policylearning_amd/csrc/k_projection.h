@@ -740,6 +740,12 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
       if (nt2 < a.ntiles)
         pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
     }
+#ifndef FNO_PFWD_STAGGER
+#define FNO_PFWD_STAGGER 0
+#endif
+    // the chunk loop below has no barrier: both waves of a SIMD would run their matrix phases and their GELU phases together;
+    // holding one partner back by about half a chunk puts one's GELU beside the other's MFMAs
+    if (FNO_PFWD_STAGGER > 0 && hm == 1) __builtin_amdgcn_s_sleep(FNO_PFWD_STAGGER);
     // this wave's activation fragments: B[k = c][n = px], 8 consecutive channels per lane
     bf16x8 bfrag[KB][3];
 #pragma unroll
