@@ -421,12 +421,18 @@ def main():
                 if el > budget or n_it >= max_it:
                     return bs * n_it / el, n_it, el
         best = None
-        for nthr in [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]:
+        probe = min(16, ncores)
+        torch.set_num_threads(probe)
+        t_p = time.perf_counter()
+        cpu_step()
+        t_p = time.perf_counter() - t_p
+        heavy = t_p > 4.0                  # (weight-dominated observers: seconds per step) - one more step at this count, no sweep
+        for nthr in ([probe] if heavy else [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]):
             rate, n_it, el = timed(nthr, 3.0, 12)
             if best is None or rate > best[0]:
                 best = (rate, nthr, n_it, el)
         allc = None
-        if ncores > 32:
+        if ncores > 32 and not heavy:
             try:
                 import signal
 

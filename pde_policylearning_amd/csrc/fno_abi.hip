@@ -1273,7 +1273,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
                                        const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
                                        size_t ws_bytes, void* stream, int l_hi, int l_lo) {
   if (!p || !prm || !x || !dy || !saved || !gr || B < 1) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
-  if (dx && p->d.Cin > 0) return fail(FNO_EUNSUPPORTED, "input gradient is produced for block stacks (Cin == 0) only");
+  if (dx && p->d.Cin > 4) return fail(FNO_EUNSUPPORTED, "input gradient through the lifting layer: at most 4 input channels");
   if (l_lo < 0 || l_hi >= p->d.n_layers || l_lo > l_hi) return fail(FNO_EINVAL, "fno_model_backward_part: layers %d..%d", l_hi, l_lo);
   hipStream_t st = (hipStream_t)stream;
   const Geom& g = p->g;
@@ -1355,7 +1355,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     memset(&a, 0, sizeof(a));
     a.g = gcur; a.uin = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act; a.w = prm->skip_w[l];
     a.zg = w.z; a.tinv = p->t.tinv_b;
-    a.gout = (l > 0) ? gnext : (has_lift ? nullptr : dx);
+    a.gout = (l > 0) ? gnext : (has_lift ? (dx ? gnext : nullptr) : dx);     // dx through a lifting layer: dL/du_0 is needed
     a.x1g = (l > 0 && !p->loose) ? w.x1 : nullptr;
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_l; a.db_part = db_part_l;
@@ -1375,6 +1375,11 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     }
     gcur = gnext;
     { float* t = gnext; gnext = gspare; gspare = t; }
+  }
+  if (dx && has_lift && l_lo == 0) {      // dL/dx = W_l^T dL/du_0 (gcur is block 0's output gradient after the rotation)
+    const size_t n4 = (size_t)B * g.PW / 4;
+    LAUNCHCHK(launch("k_lift_dx", k_lift_dx, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 8192)), dim3(256), 0, st, gcur,
+                     prm->lift_w, dx, C, d.Cin, (size_t)g.PW, n4));
   }
   if (batch_dw)
     LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l_lo * s.n_hat, w.ohat + (size_t)l_lo * s.n_hat, w.dwp + (size_t)l_lo * s.n_wp, B,

@@ -397,14 +397,26 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
     // MFMAs from ONE b128 read per operand (two independent accumulation chains)
     const float* tf = tfwd + (size_t)(jt * 16 + l15) * tpitch + 4 * quad;
     const float* xr = tile + (nt * 16 + l15) * PITCH + rr * W + 4 * quad;
-#pragma unroll 4
-    for (int q = 0; q < W / 16; ++q) {
-      const float4 av = ld4(tf + 16 * q);
-      const float4 bv = ld4(xr + 16 * q);
-      d0 = mfma16(av.x, bv.x, d0);
-      d1 = mfma16(av.y, bv.y, d1);
-      d0 = mfma16(av.z, bv.z, d0);
-      d1 = mfma16(av.w, bv.w, d1);
+    // operands of FOUR k steps are in flight together (left to itself the compiler reuses one register set: read, wait,
+    // four MFMAs, read ... - the phase then runs at LDS latency, 2.9 k instead of 1 k cycles per 128-pixel row)
+    for (int q0 = 0; q0 < W / 16; q0 += 4) {
+      float4 av[4], bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = q0 + j < W / 16;          // rows of 32 pixels: two k steps
+        av[j] = in ? ld4(tf + 16 * (q0 + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[j] = in ? ld4(xr + 16 * (q0 + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#ifndef FNO_DFT_NOPIPE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d0 = mfma16(av[j].x, bv[j].x, d0);
+        d1 = mfma16(av[j].y, bv[j].y, d1);
+        d0 = mfma16(av[j].z, bv[j].z, d0);
+        d1 = mfma16(av[j].w, bv[j].w, d1);
+      }
     }
     const int prow = px0 / W + rr;
     const int c = nt * 16 + l15;

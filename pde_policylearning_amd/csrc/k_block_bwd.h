@@ -719,3 +719,30 @@ __global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
     __syncthreads();
   }
 }
+
+// Input gradient of a lifting layer (y = W x + b, W (C, CL <= 4)): dx[k][px] = sum_c W[c][k] g[c][px]
+// (run_control.py:186-224 differentiates the observer down to its input field).  One thread = 4 pixels of one sample.
+__global__ void __launch_bounds__(256) k_lift_dx(const float* __restrict__ g, const float* __restrict__ lw, float* __restrict__ dx,
+                                                 int C, int CL, size_t PW, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t b = (4 * i) / PW, px = 4 * i - b * PW;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* gp = g + b * C * PW + px;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+      const float4 gv = ld4(gp + (size_t)c * PW);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < CL) {
+          const float w = lw[c * CL + k];
+          acc[k].x = fmaf(w, gv.x, acc[k].x); acc[k].y = fmaf(w, gv.y, acc[k].y);
+          acc[k].z = fmaf(w, gv.z, acc[k].z); acc[k].w = fmaf(w, gv.w, acc[k].w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < CL) st4(dx + (b * CL + k) * PW + px, acc[k]);
+  }
+}

@@ -637,14 +637,18 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
               if (h == 0) { dft0[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; dft1[jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
               const float* tf = tfwd_s + (size_t)(jt * 16 + l15) * (a.W + 4) + 4 * quad + 64 * h;
               const float* xr = r3 + (n16 * 16 + l15) * PITCH + 4 * quad;
+              float4 av[4], bv[4];        // all four k steps' operands in flight before the first MFMA (fno_dev.h: row_dft_epilogue)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { av[q] = ld4(tf + 16 * q); bv[q] = ld4(xr + 16 * q); }
+#ifndef FNO_DFT_NOPIPE
+              __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float4 av = ld4(tf + 16 * q);
-                const float4 bv = ld4(xr + 16 * q);
-                dft0[jj] = mfma16(av.x, bv.x, dft0[jj]);
-                dft1[jj] = mfma16(av.y, bv.y, dft1[jj]);
-                dft0[jj] = mfma16(av.z, bv.z, dft0[jj]);
-                dft1[jj] = mfma16(av.w, bv.w, dft1[jj]);
+                dft0[jj] = mfma16(av[q].x, bv[q].x, dft0[jj]);
+                dft1[jj] = mfma16(av[q].y, bv[q].y, dft1[jj]);
+                dft0[jj] = mfma16(av[q].z, bv[q].z, dft0[jj]);
+                dft1[jj] = mfma16(av[q].w, bv[q].w, dft1[jj]);
               }
               if (h == 1) {
                 const int prow = pxt / a.W;

@@ -196,9 +196,6 @@ class _FNOModelFn(torch.autograd.Function):
         ctx.direct = direct
         ctx.overlap = overlap
         _require_cuda(x, "x")
-        if x.requires_grad:
-            raise RuntimeError("fnoengine fused FNO: gradient w.r.t. the input field is not produced "
-                               "(parameter gradients only); detach the input")
         x = x.contiguous()
         dims = tuple(x.shape[2:])
         ndim = len(dims)
@@ -258,8 +255,13 @@ class _FNOModelFn(torch.autograd.Function):
         nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
         ws = _bytes(nws, dy.device)
         ov = ctx.overlap
+        # dL/dx through the lifting layer (run_control.py:186-224 differentiates the observer down to its input field)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(dy.device):
-            if ov is not None and ctx.direct is not None and 0 < ov.split_layer < nl:
+            if dx is not None:
+                _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                   C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "model_backward_dx")
+            elif ov is not None and ctx.direct is not None and 0 < ov.split_layer < nl:
                 # late layers first; their finished gradients go on the wire while the early layers are differentiated
                 k = ov.split_layer
                 _lib.check(L.fno_model_backward_part(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
@@ -273,8 +275,8 @@ class _FNOModelFn(torch.autograd.Function):
                 _lib.check(L.fno_model_backward(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
                                                 C.byref(grd), _ptr(ws), nws, _stream()), "model_backward")
         if ctx.direct is not None:
-            return (None,) * (9 + len(skip_ws) + len(spec_ws))
-        return (None, None, g[0], g[1], g_sb, g[2], g[3], g[4], g[5]) + tuple(g_skip) + tuple(g_spec)
+            return (None, dx) + (None,) * (7 + len(skip_ws) + len(spec_ws))
+        return (None, dx, g[0], g[1], g_sb, g[2], g[3], g[4], g[5]) + tuple(g_skip) + tuple(g_spec)
 
 
 def fno_model(x, lift_w, lift_b, skip_ws, spec_ws, spec_bias, w1, b1, w2, b2, modes, norm="forward",

@@ -91,7 +91,8 @@ class FNO(nn.Module):
         tiled = w % 32 == 0 and w <= 256 and npx % w == 0 and plane % npx == 0
         loose = (not tiled) and 32 <= w <= 320 and plane % 128 == 0 and F._lib.lib().fno_get_gemm_mode() == 1
         if not (self.hidden_channels in (32, 64) and self.in_channels <= 4 and self.out_channels <= 4
-                and self.projection_channels == 256 and (tiled or loose) and not x.requires_grad and x.is_cuda):
+                and self.projection_channels == 256 and (tiled or loose) and x.is_cuda
+                and (not x.requires_grad or self.in_channels <= 4)):
             return False
         # the engine has the last word (e.g. 256-pixel tiles with many kept modes do not fit LDS)
         gelu_mask = 0

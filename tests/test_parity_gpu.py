@@ -1718,3 +1718,29 @@ def test_fused_adam_state_round_trips_through_torch_adam(dev):
     for (n, a), b in zip(m3.named_parameters(), m2.parameters()):
         a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a.detach(), b.detach()))
         assert float((a - b).norm()) <= 1e-4 * float(b.norm()), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,S,B,L", [(64, 128, 2, 4), (32, 64, 3, 2), (64, 96, 2, 2)])
+def test_fno2d_input_gradient_vs_oracle(dev, C, S, B, L):
+    """dL/dx of the fused FNO (run_control.py:186-224 differentiates the observer down to its input field): block 0 hands
+    dL/du_0 to the lifting layer's adjoint (k_lift_dx).  Against the float64 oracle; parameter gradients unchanged."""
+    from pde_policylearning_amd import functional as F
+    modes = (12, 10)
+    half = [m // 2 for m in modes]
+    p = _fno_params(C, L, half, seed_tag="dx")
+    x = torch.from_numpy(fill_named("xdx", (B, 3, S, S), 1.0))
+    tgt = torch.from_numpy(fill_named("tdx", (B, 1, S, S), 1.0))
+    pc = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    xc = x.double().clone().requires_grad_(True)
+    O.lp_loss_rel_sum(O.fno_forward(pc, xc, modes, n_layers=L), tgt.double()).backward()
+    pg = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    xg = x.to(dev).requires_grad_(True)
+    y = F.fno_model(xg, pg["lifting.fc.weight"], pg["lifting.fc.bias"], [pg[f"fno_blocks.fno_skips.{l}.weight"] for l in range(L)],
+                    [pg[f"fno_blocks.convs.weight.{i}.tensor"] for i in range(2 * L)], pg["fno_blocks.convs.bias"],
+                    pg["projection.fc1.weight"], pg["projection.fc1.bias"], pg["projection.fc2.weight"],
+                    pg["projection.fc2.bias"], modes=half)
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    assert rel_l2(_cpu(xg.grad), xc.grad.numpy()) < TOL_G
+    for k in ("lifting.fc.weight", "fno_blocks.fno_skips.0.weight", "projection.fc1.weight"):
+        assert rel_l2(_cpu(pg[k].grad), pc[k].grad.numpy()) < TOL_G, k
