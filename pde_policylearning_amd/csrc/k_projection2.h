@@ -113,6 +113,13 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
   load_wa1(0);
 
+#ifndef PBT_BASE_PRIO
+#define PBT_BASE_PRIO 1
+#endif
+  // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4): waves 4-7 lose every
+  // VALU arbitration to their older partners otherwise (GELU phase 4 k vs 1.9 k cycles in the phase trace)
+  const int base_prio = (PBT_BASE_PRIO && wave >= 4) ? 1 : 0;
+  if (base_prio) __builtin_amdgcn_s_setprio(1);
   int tslot = 0;
   FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         }
         dw1acc[k] = dacc;
           }
-        __builtin_amdgcn_s_setprio(0);
+        if (base_prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       }
       if (ch == 1) FNO_STAMP(tslot + 8);
     }
