@@ -1141,12 +1141,12 @@ static size_t pbwd_x3_lds(int C, int npx, int nco) {
          ((size_t)nco * npx + kHID + (size_t)nco * kHID) * 4;
 }
 // second-generation projection backward (k_projection2.h): C = 64, one output channel, 128-pixel tiles, split-precision mode
-static size_t pbwd_t_lds(const ProjBwdArgs& a) {
-  return (size_t)3 * 64 * 256 + (size_t)2 * 3 * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
+static size_t pbwd_t_lds(int C, const ProjBwdArgs& a) {
+  return (size_t)3 * C * 256 + (size_t)2 * 3 * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
 }
 static bool use_pbwd_t(int C, int CO, int npx) {
   static const int v1 = getenv("FNO_PBWD_V1") ? 1 : 0;        // A/B switch: the first-generation kernel
-  return !v1 && g_gemm_x3 && C == 64 && CO == 1 && npx == 128;
+  return !v1 && g_gemm_x3 && (C == 64 || C == 32) && CO == 1 && npx == 128;
 }
 // W1 -> bf16x3 fragments in the order the selected projection-backward kernel reads them
 static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsigned short* wa3, int HID, int C, bool t_order) {
@@ -1157,7 +1157,7 @@ static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsi
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
   if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
-    return launch("k_proj_bwd", k_proj_bwd_t<kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(a), st, a);
+    return launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
   if (a.wa1 && a.CO == 1 && p->NPX == 128 && pbwd_x3_lds(C, 128, 1) <= 160 * 1024)
     return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
@@ -2018,10 +2018,8 @@ static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
 }
 template <int C, int HID, bool RELU>
 static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
-  if constexpr (C == 64) {
-    if (use_pbwd_t(C, 1, 128))
-      return launch("k_proj_bwd", k_proj_bwd_t<HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(a), st, a);
-  }
+  if (use_pbwd_t(C, 1, 128))
+    return launch("k_proj_bwd", k_proj_bwd_t<C, HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
   return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }

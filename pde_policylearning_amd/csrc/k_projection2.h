@@ -41,14 +41,18 @@ __global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __rest
   }
 }
 
-template <int HID, bool RELU = false>
+// C = 32: the dx product's K (hidden rows) is split between the two wave groups (wave (hm, nt) contracts over rows
+// 32 hm .. 32 hm + 31 of every chunk: one channel block, two partial tiles per pixel block, added through LDS once per tile) and
+// a chunk's dW1 (two 32 x 32 tiles) is split over the owner group's four waves by pixel halves (added through LDS at the end).
+template <int C, int HID, bool RELU = false>
 __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
-  constexpr int C = 64, NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32;
+  constexpr int NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32, XI = C / 16;
+  static_assert(C == 32 || C == 64, "32 or 64 channels");
   constexpr int NCH = HID / 64, CPW = NCH / 2;
   constexpr int PITCH = NPX + 4;
   constexpr int ATERM = C * 256, DTERM = 64 * 256;          // bytes per term plane of the a image / one dP1 buffer
   static_assert(NCH % 2 == 0, "two owner groups");
-  static_assert((size_t)C * PITCH * 4 <= (size_t)3 * DTERM, "the gout tile aliases dP1 buffer 0");
+  static_assert((size_t)64 * PITCH * 4 <= (size_t)3 * DTERM, "the gout tile / the partial-sum exchange alias a dP1 buffer");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* aimg = reinterpret_cast<unsigned char*>(smem);             // a = act(u_L): [3][C][128] bf16, swizzled
   unsigned char* dr0 = aimg + 3 * ATERM;                                     // dP1 chunk, two buffers [3][64][128] bf16, swizzled
@@ -61,7 +65,8 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   const int l15 = lane & 15, quad = lane >> 4;
   const int hm = wave >> 2, nt = wave & 3;
   const int n0 = nt * 32;
-  const int dmt = nt >> 1, dnt = nt & 1;          // dW1 tile of an owner wave: hidden 32-block, channel 32-block
+  const int dmt = nt >> 1, dnt = MT == 2 ? (nt & 1) : 0;   // dW1 tile of an owner wave: hidden 32-block, channel 32-block
+  const int dkh = MT == 2 ? 0 : (nt & 1);                   // C = 32: pixel half of the tile's K range
   // transposed-read lane roles (k_block_bwd2.h): lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p + 3
   const int tq = l15 >> 2, tp = l15 & 3;
   const int tpx = n0 + 16 * (quad & 1) + 4 * tp;
@@ -80,21 +85,24 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   // descriptor + fragment offset in SGPRs, one 32-bit lane offset
   const __amdgpu_buffer_rsrc_t rs_wa1 = make_rsrc(a.wa1, (unsigned)((HID / 32) * KB * 3 * 64 * 16));
   const __amdgpu_buffer_rsrc_t rs_wb3 = make_rsrc(a.wa3, (unsigned)((HID / 16) * MT * 3 * 64 * 16));
-  bf16x8 wf[KB][3];
+  bf16x8 wf[4][3];        // (KB used by the recompute, 4 / 2 by the dx product)
   auto load_wa1 = [&](int ch) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int t = 0; t < 3; ++t) wf[kb][t] = buf_ld8h(rs_wa1, lane * 16, (((ch * 2 + hm) * KB + kb) * 3 + t) * 1024);
   };
+  constexpr int NK3 = MT == 2 ? 4 : 2;            // 16-row k blocks of the dx product per wave and chunk
   auto load_wb3 = [&](int ch) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kk = 0; kk < NK3; ++kk) {
+      const int kb = MT == 2 ? kk : 2 * hm + kk, cb = MT == 2 ? hm : 0;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) wf[kb][t] = buf_ld8h(rs_wb3, lane * 16, ((((ch * 4 + kb) * MT + hm) * 3) + t) * 1024);
+      for (int t = 0; t < 3; ++t) wf[kk][t] = buf_ld8h(rs_wb3, lane * 16, ((((ch * 4 + kb) * MT + cb) * 3) + t) * 1024);
+    }
   };
   // the tile's rows of u_L: thread (c = tid / 32 + 16 i, q = tid % 32) loads 16 bytes; per-sample descriptor
-  float4 xq[4];
+  float4 xq[XI];
   const int xvoff = ((tid >> 5) * a.PW + 4 * (tid & 31)) * 4;
   auto issue_x = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
@@ -102,10 +110,10 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
 #ifdef PBT_GLOBAL_X
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xq[i] = ld4(a.x + ((size_t)b * C + (tid >> 5) + 16 * i) * a.PW + px0 + 4 * (tid & 31));
+    for (int i = 0; i < XI; ++i) xq[i] = ld4(a.x + ((size_t)b * C + (tid >> 5) + 16 * i) * a.PW + px0 + 4 * (tid & 31));
 #else
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xq[i] = buf_ld4(rs, xvoff, (16 * i * a.PW + px0) * 4);
+    for (int i = 0; i < XI; ++i) xq[i] = buf_ld4(rs, xvoff, (16 * i * a.PW + px0) * 4);
 #endif
   };
   if ((int)blockIdx.x < a.ntiles) issue_x(blockIdx.x);
@@ -128,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     FNO_STAMP(tslot + 0);
     // ---- commit: a = act(u) -> swizzled [c][px] image (one split) -----------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XI; ++i) {
       const int c = (tid >> 5) + 16 * i, q = tid & 31;
       float4 t = xq[i];
       if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
@@ -205,13 +213,14 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       // ---- A3: dx^T[px][c] += sum_hid dP1[hid][px] W1[hid][c]: A = transposed reads of the dP1 image ----------------------
       {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kk = 0; kk < NK3; ++kk) {
           bf16x8 af[3];
+          const int kb = MT == 2 ? kk : 2 * hm + kk;       // C = 32: this wave group's half of the chunk's hidden rows
           const int o0 = swz_off(kb * 16 + trow, tpx >> 3) + 2 * (tpx & 7);
           const int o1 = swz_off(kb * 16 + trow + 4, tpx >> 3) + 2 * (tpx & 7);
 #pragma unroll
           for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(dr + t * DTERM + o0), lds_tr16(dr + t * DTERM + o1));
-          mfma_x3s(af, wf[kb], dxh, dxl);
+          mfma_x3s(af, wf[kk], dxh, dxl);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -227,8 +236,8 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
           if (k == (ch >> 1)) {
         f32x16 dacc = dw1acc[k];
 #pragma unroll 1
-        for (int kq = 0; kq < NPX / 16; ++kq) {
-          const int chn = 2 * kq + half;
+        for (int kq = 0; kq < (MT == 2 ? NPX / 16 : NPX / 32); ++kq) {
+          const int chn = 2 * (kq + dkh * (NPX / 32)) + half;
           const int od = swz_off(ro, chn), oa = swz_off(rc, chn);
           bf16x8 af[3], bf[3];
 #pragma unroll
@@ -247,7 +256,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     FNO_STAMP(tslot + 9);
     // ---- epilogue: x act'(u), gout store (before the barrier: the last chunk's dW1 owners are still on the matrix pipe),
     //      then the gout tile for the row DFT ----------------------------------------------------------------------------
-    {
+    if constexpr (MT == 2) {
       const int crow = hm * 32 + l31;
       const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
       float4 v[4];
@@ -275,28 +284,89 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st4(r3p + 8 * i, v[i]);
       }
+    } else {
+      // C = 32: the two wave groups hold partial sums over their hidden halves of the SAME tile.  Wave (hm, nt) finishes the
+      // pixel groups i = 2 hm, 2 hm + 1 of its 32 pixels and hands the other two to its partner through dP1 buffer 0 (free
+      // since the last chunk's barrier); the gout tile goes to buffer 1 (free behind the barrier below).
+      const size_t ro = ((size_t)b * C + l31) * a.PW + px0 + n0 + 4 * half;
+      float* part = reinterpret_cast<float*>(dr0);                       // [hm][32][PITCH]
+      float* r3b = reinterpret_cast<float*>(dr0 + 3 * DTERM);
+      {
+        float* pp = part + (hm * 32 + l31) * PITCH + n0 + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = 2 * (1 - hm) + j;
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+            if (ii == i) st4(pp + 8 * ii, make_float4(dxh[4 * ii] + dxl[4 * ii], dxh[4 * ii + 1] + dxl[4 * ii + 1],
+                                                       dxh[4 * ii + 2] + dxl[4 * ii + 2], dxh[4 * ii + 3] + dxl[4 * ii + 3]));
+        }
+      }
+      float4 uq[2];
+      if (a.act_in) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) uq[j] = buf_ld4(rs, (l31 * a.PW + n0 + 4 * half) * 4, (px0 + 8 * (2 * hm + j)) * 4);
+      }
+      FNO_STAMP(tslot + 10);
+      __syncthreads();
+      const float* pq = part + ((1 - hm) * 32 + l31) * PITCH + n0 + 4 * half;
+      float* r3p = r3b + l31 * PITCH + n0 + 4 * half;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int i = 2 * hm + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+          if (ii == i) v = make_float4(dxh[4 * ii] + dxl[4 * ii], dxh[4 * ii + 1] + dxl[4 * ii + 1],
+                                       dxh[4 * ii + 2] + dxl[4 * ii + 2], dxh[4 * ii + 3] + dxl[4 * ii + 3]);
+        const float4 o = ld4(pq + 8 * i);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        if (a.act_in) {
+          v.x *= gelu_grad_f(uq[j].x); v.y *= gelu_grad_f(uq[j].y); v.z *= gelu_grad_f(uq[j].z); v.w *= gelu_grad_f(uq[j].w);
+        }
+        st4(a.gout + ro + 8 * i, v);
+        if (a.x1g) st4(r3p + 8 * i, v);
+      }
     }
     if (a.x1g) {
       __syncthreads();
-      row_dft_epilogue<C, NPX, 8>(r3, tfwd_s, a.W + 4, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      row_dft_epilogue<C, NPX, 8>(MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + 3 * DTERM), tfwd_s, a.W + 4, a.x1g, b, px0, a.P,
+                                  a.W, a.K2out, a.NJ, wave, lane);
       FNO_STAMP(tslot + 11);
-#ifdef PBT_TRAIL_BARRIER
-      __syncthreads();
-#endif
-      // no barrier here: r3 (dP1 buffer 0) is rewritten by the next tile's first chunk, behind the commit barrier, which a
-      // wave only reaches after it has left the row DFT; the commit itself writes the a image, which nobody reads any more
+      // no barrier here: the gout tile (a dP1 buffer) is rewritten by the next tile's chunks, behind the commit barrier, which
+      // a wave only reaches after it has left the row DFT; the commit itself writes the a image, which nobody reads any more
     }
     tslot += 12;
   }
 
   // ---- partial slabs ---------------------------------------------------------------------------------------------------------
+  if constexpr (MT == 1) {      // C = 32: add the two pixel halves of every dW1 tile (waves nt, nt ^ 1 of the owner group)
+    __syncthreads();
+    float* sc = smem;           // [hm][k][dmt][16][64]
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+      if (dkh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[(((hm * CPW + k) * 2 + dmt) * 16 + r) * 64 + lane] = dw1acc[k][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+      if (dkh == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw1acc[k][r] += sc[(((hm * CPW + k) * 2 + dmt) * 16 + r) * 64 + lane];
+      }
+  }
 #pragma unroll
   for (int k = 0; k < CPW; ++k) {
     const int ch = 2 * k + hm;
     float* dst = a.dw1_part + (size_t)blockIdx.x * HID * C;
+    if (MT == 2 || dkh == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
+      for (int r = 0; r < 16; ++r)
+        dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
+    }
   }
   {
     const size_t slab = (size_t)blockIdx.x * NTN + nt;
