@@ -909,6 +909,7 @@ extern "C" void fno_model_plan_destroy(FnoModelPlan* p) {
 
 struct ModelSizes {
   size_t n_act, n_x1, n_tmp, n_hat, n_wp;
+  int grid_bb;      // workgroups of the block-backward launches (its partial slabs are sized by it)
   int ntiles, tiles_per_plane, grid;
 };
 static ModelSizes model_sizes(const FnoModelPlan* p, int B) {
@@ -923,6 +924,8 @@ static ModelSizes model_sizes(const FnoModelPlan* p, int B) {
   s.tiles_per_plane = g.PW / p->NPX;
   s.ntiles = B * s.tiles_per_plane;
   s.grid = std::min(s.ntiles, FNO_GRID_BWD * p->ncu);
+  // block backward at 32 channels: 4-wave workgroups of ~75 KB LDS, two fit a CU (k_block_bwd_t)
+  s.grid_bb = (p->d.C == 32 && g_gemm_x3 && p->NPX == 128) ? std::min(s.ntiles, 2 * p->ncu) : s.grid;
   return s;
 }
 
@@ -953,9 +956,9 @@ static ModelWs carve_model(const FnoModelPlan* p, int B, void* ws, size_t cap, b
     w.ga = c.take<float>(s.n_act);
     w.gb = c.take<float>(s.n_act);
     w.dwp = c.take<float>((size_t)p->d.n_layers * s.n_wp);
-    w.dw_part = c.take<float>((size_t)p->d.n_layers * s.grid * ((p->NPX / 32) / (C / 32)) * C * C);
-    w.db_part = c.take<float>((size_t)p->d.n_layers * s.grid * C);
-    w.dwl_part = c.take<float>((size_t)s.grid * C * 16);
+    w.dw_part = c.take<float>((size_t)p->d.n_layers * s.grid_bb * ((p->NPX / 32) / (C / 32)) * C * C);
+    w.db_part = c.take<float>((size_t)p->d.n_layers * s.grid_bb * C);
+    w.dwl_part = c.take<float>((size_t)s.grid_bb * C * 16);
     w.dw1_part = c.take<float>((size_t)s.grid * kHID * C);
     w.db1_part = c.take<float>((size_t)s.grid * 8 * kHID);
     w.dw2_part = c.take<float>((size_t)s.grid * 8 * PROJ_MAXCO * kHID);
@@ -1340,8 +1343,8 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   for (int l = l_hi; l >= l_lo; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
     float* dwp_l = w.dwp + (size_t)l * s.n_wp;
-    float* dw_part_l = w.dw_part + (size_t)l * s.grid * ks * C * C;
-    float* db_part_l = w.db_part + (size_t)l * s.grid * C;
+    float* dw_part_l = w.dw_part + (size_t)l * s.grid_bb * ks * C * C;
+    float* db_part_l = w.db_part + (size_t)l * s.grid_bb * C;
     // G_l is kept per layer: dW_l = conj(Xhat_l) G_l does not feed the dx chain, so all layers of this part share ONE
     // contraction launch behind the loop (layer index on the grid) instead of one 72-workgroup launch each
     float* ohat_l = w.ohat + (size_t)(batch_dw ? l : 0) * s.n_hat;
@@ -1364,14 +1367,14 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
+    LAUNCHCHK(launch_bbwd(p, st, s.grid_bb, a));
     if (p->loose && l > 0)     // the running gradient's row spectrum for the next (lower) block, in its own pass
       LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, gnext, w.x1));
-    jobs.add(dw_part_l, gr->skip_w[l], s.grid * ks, C, C, C, C);
-    if (gr->spec_bias) jobs.add(db_part_l, gr->spec_bias + (size_t)l * C, s.grid, 1, C, C, C);
+    jobs.add(dw_part_l, gr->skip_w[l], s.grid_bb * ks, C, C, C, C);
+    if (gr->spec_bias) jobs.add(db_part_l, gr->spec_bias + (size_t)l * C, s.grid_bb, 1, C, C, C);
     if (l == 0 && has_lift) {
-      jobs.add(w.dwl_part, gr->lift_w, s.grid, C, d.Cin, 16, d.Cin);
-      jobs.add(w.dwl_part + d.Cin, gr->lift_b, s.grid, C, 1, 16, 1);
+      jobs.add(w.dwl_part, gr->lift_w, s.grid_bb, C, d.Cin, 16, d.Cin);
+      jobs.add(w.dwl_part + d.Cin, gr->lift_b, s.grid_bb, C, 1, 16, 1);
     }
     gcur = gnext;
     { float* t = gnext; gnext = gspare; gspare = t; }
@@ -1535,8 +1538,8 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   JobList jobs;
   for (int j = 0; j < n_out; ++j) {
     float* dwp_j = w.dwp + (size_t)j * s.n_wp;
-    float* dw_part_j = w.dw_part + (size_t)j * s.grid * ks * C * C;
-    float* db_part_j = w.db_part + (size_t)j * s.grid * C;
+    float* dw_part_j = w.dw_part + (size_t)j * s.grid_bb * ks * C * C;
+    float* db_part_j = w.db_part + (size_t)j * s.grid_bb * C;
     const float* zj = w.z;
     if (batched) zj = f.z + (size_t)j * s.n_x1;
     else {
@@ -1556,9 +1559,9 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
     a.dw_part = dw_part_j; a.db_part = db_part_j;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    LAUNCHCHK(launch_bbwd(p, st, s.grid, a));
-    jobs.add(dw_part_j, gr->skip_w[j], s.grid * ks, C, C, C, C);
-    if (dbias && dbias[j]) jobs.add(db_part_j, dbias[j], s.grid, 1, C, C, C);
+    LAUNCHCHK(launch_bbwd(p, st, s.grid_bb, a));
+    jobs.add(dw_part_j, gr->skip_w[j], s.grid_bb * ks, C, C, C, C);
+    if (dbias && dbias[j]) jobs.add(db_part_j, dbias[j], s.grid_bb, 1, C, C, C);
   }
   LAUNCHCHK(jobs.run(st));
   CornerPtrsMutL cp;
