@@ -426,7 +426,9 @@ def main():
         t_p = time.perf_counter()
         cpu_step()
         t_p = time.perf_counter() - t_p
-        heavy = t_p > 4.0                  # (weight-dominated observers: seconds per step) - one more step at this count, no sweep
+        # weight-dominated observers (seconds per step; torch's complex einsum also degrades unboundedly at some thread
+        # counts on the 256-core boxes, and a running C++ op cannot be interrupted): one more step at this count, no sweep
+        heavy = t_p > 2.0 or cfg.get("n_params", 0) > 50_000_000
         for nthr in ([probe] if heavy else [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]):
             rate, n_it, el = timed(nthr, 3.0, 12)
             if best is None or rate > best[0]:
