@@ -43,6 +43,13 @@ int fno_get_gemm_mode(void);
 void fno_set_mode_gemm(int mfma);
 int fno_get_mode_gemm(void);
 
+/* The spectral middle of a fused 2-D block (leading-axis DFT -> mode contraction -> leading-axis inverse DFT,
+ * spectral_convolution.py:324-345): 1 (default) = one launch (k_spec_mid; 32 / 64 channels, 4 / 8 / 12 / 16 kept leading
+ * modes), 0 = the three-launch sequence.  Same results to fp32 rounding.  Environment FNO_NO_FUSED_MID=1 selects 0 at
+ * load time. */
+void fno_set_fused_mid(int on);
+int fno_get_fused_mid(void);
+
 /* ------------------------------------------------------------------------
  * Standalone spectral convolution  y = irfftn(pad(W_c . rfftn(x)[corner_c])) (+ bias)
  * Covers the reference's three dialects:

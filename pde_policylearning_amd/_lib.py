@@ -66,6 +66,9 @@ def lib():
     L.fno_set_mode_gemm.argtypes = [ci]
     L.fno_set_mode_gemm.restype = None
     L.fno_get_mode_gemm.restype = ci
+    L.fno_set_fused_mid.argtypes = [ci]
+    L.fno_set_fused_mid.restype = None
+    L.fno_get_fused_mid.restype = ci
     L.fno_spec_plan_create.argtypes = [C.POINTER(FnoSpecDesc), C.POINTER(vp)]
     L.fno_spec_plan_destroy.argtypes = [vp]
     L.fno_spec_plan_destroy.restype = None
@@ -152,6 +155,7 @@ def check(rc, what=""):
 
 EXPORTED_SYMBOLS = [
     "fno_version", "fno_last_error", "fno_set_gemm_mode", "fno_get_gemm_mode", "fno_set_mode_gemm", "fno_get_mode_gemm",
+    "fno_set_fused_mid", "fno_get_fused_mid",
     "fno_spec_plan_create", "fno_spec_plan_destroy", "fno_spec_workspace_bytes", "fno_spec_xhat_bytes",
     "fno_spec_forward", "fno_spec_backward",
     "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",

@@ -116,6 +116,7 @@ extern "C" int fno_profile_get(int i, const char** name, float* total_ms, int* l
   return FNO_OK;
 }
 
+static const int g_print_occ = getenv("FNO_PRINT_OCC") ? 1 : 0;
 template <typename... KArgs, typename... Args>
 static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
                   Args... args) {
@@ -127,6 +128,19 @@ static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 bloc
     if (e != hipSuccess) {
       (void)hipGetLastError();      // do not leave a sticky error for the next launch
       return fail(FNO_EHIP, "%s: set LDS %zu: %s", name, lds, hipGetErrorString(e));
+    }
+  }
+  if (g_print_occ) {        // FNO_PRINT_OCC=1: resident workgroups per CU the runtime reports, once per kernel instantiation
+    static std::map<const void*, int> seen;
+    const void* key = reinterpret_cast<const void*>(kern);
+    if (!seen.count(key)) {
+      int nb = -1;
+      hipFuncAttributes fa;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, (int)(block.x * block.y * block.z), lds);
+      (void)hipFuncGetAttributes(&fa, key);
+      seen[key] = nb;
+      fprintf(stderr, "[occ] %-22s threads=%4u grid=%6u lds=%6zu+%zu regs=%3d -> %d workgroups/CU\n", name,
+              block.x * block.y * block.z, grid.x * grid.y * grid.z, lds, (size_t)fa.sharedSizeBytes, fa.numRegs, nb);
     }
   }
   ProfRec rec;
@@ -296,6 +310,7 @@ static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
 }
 
 
+static int g_pack_flat_early() { static const int v = getenv("FNO_PACK_FLAT") ? 1 : 0; return v; }
 // many -> few (twT transposed (n_in, n_out)) or few -> many (tw (n_out, n_in)); the small (kept) extent
 // is a template parameter of the fast kernels (2*m for the usual m = 2..20), anything else is generic.
 template <int NS>
@@ -359,6 +374,47 @@ static int lead_inverse(hipStream_t st, const Geom& g, const Tables& t, int B, i
   if (g.nlead == 1) return axis_pass(st, false, hat, z, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klast * C);
   LAUNCHCHK(axis_pass(st, false, hat, tmp, t.tw_inv[0], B, g.Klead[0], g.dims[0], g.Klead[1] * g.Klast * C));
   return axis_pass(st, false, tmp, z, t.tw_inv[1], B * g.dims[0], g.Klead[1], g.dims[1], g.Klast * C);
+}
+
+// The fused middle (k_spec_mid): one leading dim, 32 / 64 channels, whole last-dim bins per 64-column workgroup, a kept
+// leading extent with an instantiation.  FNO_NO_FUSED_MID=1 keeps the three-launch sequence (A/B switch).
+static int g_fused_mid = getenv("FNO_NO_FUSED_MID") ? 0 : 1;
+extern "C" void fno_set_fused_mid(int on) { g_fused_mid = on ? 1 : 0; }
+extern "C" int fno_get_fused_mid(void) { return g_fused_mid; }
+static bool fused_mid_shape_ok(const Geom& g, int C) {      // decides what the forward packs (the switch may flip before the backward)
+  if (g_pack_flat_early() || g.nlead != 1 || (C != 32 && C != 64) || (g.Klast * C) % 64 != 0) return false;
+  if (g.dims[0] > 512) return false;             // the (n, Klead) tables are staged in the partial-sum region
+  const int nk = g.Klead[0];
+  // 24 kept modes: one workgroup per CU (123 KB of LDS), measured no faster than the three launches (RNO2d 128^2: 6.30 vs 6.26 ms)
+  return nk == 4 || nk == 8 || nk == 12 || nk == 16;
+}
+static bool fused_mid_ok(const Geom& g, int C) { return g_fused_mid && fused_mid_shape_ok(g, C); }
+template <int NK>
+static int spec_mid_t(hipStream_t st, int C, const float2* x1, float2* hat, const float2* wm, float2* z, const float2* twT,
+                      const float2* twi, int n, int inner, int K2, int conj_w, int samples, int Bm, size_t w_ms) {
+  const size_t lds = (size_t)10 * NK * 64 * 8;
+  const dim3 grid(inner / 64, samples), blk(64, 8);
+  if (C == 32) return launch("k_spec_mid", k_spec_mid<NK, 32>, grid, blk, lds, st, x1, hat, wm, z, twT, twi, n, inner, K2, conj_w, Bm, w_ms);
+  return launch("k_spec_mid", k_spec_mid<NK, 64>, grid, blk, lds, st, x1, hat, wm, z, twT, twi, n, inner, K2, conj_w, Bm, w_ms);
+}
+// x1 [samples][n][Klast][C] -> hat [samples][Klead][Klast][C] (kept for the weight gradient) and z [samples][n][Klast][C];
+// wm: packed weights [k][i][o] (conj_w = 0) or their transposed copy [k][o][i] (conj_w = 1: the adjoint); sample s uses
+// the weights of member s / Bm (w_ms floats apart)
+static int spectral_mid_fused(hipStream_t st, const Geom& g, const Tables& t, bool grad_dir, int samples, int C,
+                              const float* x1, float* hat, const float* wm, float* z, int conj_w, int Bm = 1 << 30,
+                              size_t w_ms = 0) {
+  if (samples > 65535) return fail(FNO_EUNSUPPORTED, "spectral middle grid too large (%d)", samples);
+  const float2* twT = grad_dir ? t.tw_fwd_si[0] : t.tw_fwd_sf[0];
+  const float2 *xx = (const float2*)x1, *ww = (const float2*)wm;
+  float2 *hh = (float2*)hat, *zz = (float2*)z;
+  const int n = g.dims[0], inner = g.Klast * C;
+  switch (g.Klead[0]) {
+    case 4: return spec_mid_t<4>(st, C, xx, hh, ww, zz, twT, t.tw_inv[0], n, inner, g.Klast, conj_w, samples, Bm, w_ms / 2);
+    case 8: return spec_mid_t<8>(st, C, xx, hh, ww, zz, twT, t.tw_inv[0], n, inner, g.Klast, conj_w, samples, Bm, w_ms / 2);
+    case 12: return spec_mid_t<12>(st, C, xx, hh, ww, zz, twT, t.tw_inv[0], n, inner, g.Klast, conj_w, samples, Bm, w_ms / 2);
+    case 16: return spec_mid_t<16>(st, C, xx, hh, ww, zz, twT, t.tw_inv[0], n, inner, g.Klast, conj_w, samples, Bm, w_ms / 2);
+  }
+  return fail(FNO_EUNSUPPORTED, "fused spectral middle: %d kept leading modes", g.Klead[0]);
 }
 
 // nm > 1: nm independent contractions in one launch (fan-out members); *_ms = member strides in floats (0 = shared operand).
@@ -1172,6 +1228,7 @@ static int spectral_mid_fwd(const FnoModelPlan* p, hipStream_t st, int B, const 
                             float* hat) {
   const Geom& g = p->g;
   const int C = p->d.C;
+  if (fused_mid_ok(g, C)) return spectral_mid_fused(st, g, p->t, false, B, C, w.x1, hat, wp, w.z, 0);
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));
   LAUNCHCHK(mode_gemm(st, hat, wp, w.ohat, B, g.Ktot, C, C, 0));
   return lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z);
@@ -1200,7 +1257,9 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (const float2*)prm->spec_w[l][c];
     const ModeMap mm = make_modemap(g, C, C);
     const size_t n = (size_t)g.Ktot * C * C;
-    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) ? nullptr : wpts, s.n_wp));   // the matrix-core adjoint reads wps
+    // the matrix-core adjoint reads wps; the fused middle's adjoint streams the transposed copy
+    if (!g_pack_flat)
+      LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) && !fused_mid_shape_ok(g, C) ? nullptr : wpts, s.n_wp));
     else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
@@ -1290,8 +1349,9 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   const float* hats = u + (size_t)(L + 1) * s.n_act;
   const float* wps = hats + (size_t)L * s.n_hat;                          // [k][i][o] packed weights from forward
   float* wpts = const_cast<float*>(wps) + (size_t)L * s.n_wp;            // [k][o][i]: only the VALU adjoint needs them
+  const bool fused_mid = fused_mid_ok(g, C);           // the forward packed the transposed copy as well
   const bool adj_mfma = mode_gemm_members_ok(C, C) && !g_pack_flat;
-  if (!adj_mfma && !g_pack_flat) {       // VALU contraction (A/B switch): the forward may have skipped the transposed copy
+  if (!adj_mfma && !g_pack_flat && !fused_mid_shape_ok(g, C)) {       // VALU contraction (A/B switch): the forward may have skipped the transposed copy
     CornerPtrsL cpw;
     memset(&cpw, 0, sizeof(cpw));
     for (int l = l_lo; l <= l_hi; ++l)
@@ -1348,11 +1408,16 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     // G_l is kept per layer: dW_l = conj(Xhat_l) G_l does not feed the dx chain, so all layers of this part share ONE
     // contraction launch behind the loop (layer index on the grid) instead of one 72-workgroup launch each
     float* ohat_l = w.ohat + (size_t)(batch_dw ? l : 0) * s.n_hat;
+    if (fused_mid) {
+      LAUNCHCHK(spectral_mid_fused(st, g, p->t, true, B, C, w.x1, ohat_l, wpts + (size_t)l * s.n_wp, w.z, 1));
+      if (!batch_dw) LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, ohat_l, dwp_l, B, g.Ktot, C, C));
+    } else {
     LAUNCHCHK(lead_forward(st, g, p->t, true, B, C, w.x1, w.tmp, ohat_l));
     if (!batch_dw) LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l * s.n_hat, ohat_l, dwp_l, B, g.Ktot, C, C));
     if (adj_mfma) LAUNCHCHK(mode_gemm(st, ohat_l, wps + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1, 1, 0, 0, 0, 1));
     else LAUNCHCHK(mode_gemm(st, ohat_l, wpts + (size_t)l * s.n_wp, w.hat, B, g.Ktot, C, C, 1));
     LAUNCHCHK(lead_inverse(st, g, p->t, B, C, w.hat, w.tmp, w.z));
+    }
 
     BlkBwdArgs a;
     memset(&a, 0, sizeof(a));

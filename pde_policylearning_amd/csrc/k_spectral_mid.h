@@ -1183,3 +1183,173 @@ __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) part[(size_t)blockIdx.x * C + c] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+
+// ---------------------------------------------------------------------------
+// The whole middle of a block with ONE leading dim (2-D grids) in one launch: leading-axis truncating DFT -> per-mode
+// channel contraction -> leading-axis inverse DFT (k_axis_fwd -> k_mode_gemm* -> k_axis_inv above).
+// A workgroup owns one sample and 64 consecutive (last-dim bin, channel) columns = whole bins of all C channels, so the
+// contraction over channels stays inside the workgroup; the spectrum of the kept modes never leaves LDS except for the
+// copy `hat` the weight-gradient contraction reads later.
+//   phase 1  Y[r][q]   = sum_n twT[n][r] X1[b][n][q]              the n range split over the 8 waves, combined through LDS
+//   phase 2  O[r][k2,o] = sum_j Y[r][k2,j] (conj) M[(r,k2)][j][o]  M = packed weights [k][i][o] (forward) or their
+//                                                                  transposed copy [k][o][i] with conj (adjoint): the lane
+//                                                                  runs along the contiguous index, the j range is split
+//                                                                  over the waves; the weights stream through L2 (they are
+//                                                                  shared by all samples), two modes' rows in flight
+//                                                                  while the previous two are used
+//   phase 3  Z[b][n][q] = sum_r twi[n][r] O[r][q]                  rows n split over the waves
+// Measured (BASELINE config 2, 384 workgroups, two per CU; in-kernel stamps, tools/trace_mid.py): every workgroup starts
+// together, so the three phases run in lock step over the whole chip - 25 MB of HBM reads, then 151 MB of weight rows out
+// of L2, then 25 MB of HBM writes, ~9 + 6 + 4 us with nothing overlapping: 29 us per launch against 32 us for the three
+// separate launches (rocprofv3; ~4.5 us of each launch is the fixed cost of a launch on this stack).  What it buys is
+// launches: BASELINE config 1 (launch-bound, hipGraph) runs 0.217 instead of 0.255 ms per step.
+//   block (64, 8), grid (inner / 64, samples), LDS (8 + 2) * NK * 64 float2
+#ifndef FNO_MID_SKIP
+#define FNO_MID_SKIP 0        // timing experiments: 1 = no contraction, 2 = no phase 1 loads, 4 = no phase 3
+#endif
+#ifdef FNO_TRACE
+#define MID_STAMP(slot) do { if (blockIdx.x == 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0) \
+    g_trace[threadIdx.y * 256 + (slot)] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0 && ((slot) == 0 || (slot) == 7)) \
+    g_trace[8 * 256 + blockIdx.y * 2 + ((slot) == 7)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MID_STAMP(slot) do { } while (0)
+#endif
+template <int NK, int C>
+__global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ x1, float2* __restrict__ hat,
+                                                     const float2* __restrict__ wm, float2* __restrict__ z,
+                                                     const float2* __restrict__ twT, const float2* __restrict__ twi, int n,
+                                                     int inner, int K2, int conj_w, int Bm, size_t w_ms) {
+  static_assert(C == 32 || C == 64, "whole bins per workgroup");
+  constexpr int SEGS = 8, JW = C / SEGS, NTH = 64 * SEGS;
+  constexpr int RB = 2, NG = NK / RB;               // RB modes' weight rows per load group, double-buffered
+  static_assert(NK % RB == 0, "mode groups");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* sh = reinterpret_cast<float2*>(smem);     // [SEGS][NK][64] partial sums (phases 1 and 2); the (n, NK) tables
+                                                    // of phases 1 and 3 are staged here while the sums are not live
+  float2* ys = sh + SEGS * NK * 64;                 // [NK][64] truncated spectrum of the input
+  float2* os = ys + NK * 64;                        // [NK][64] contracted spectrum
+  const int ql = threadIdx.x;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tid = seg * 64 + ql;
+  const int q = blockIdx.x * 64 + ql;
+  const int o = blockIdx.y;
+  const int k2 = q / C, ch = q - k2 * C, lb = (ql / C) * C;     // lb: first lane of this lane's bin
+  const float2* wb = wm + (size_t)(o / Bm) * w_ms + ((size_t)k2 * C + seg * JW) * C + ch;
+  MID_STAMP(0);
+  // Table rows are the same for every lane.  Through the scalar cache a wave waits ~1000 cycles per row (measured with
+  // the stamps: 16 rows = 16 k cycles, the register budget leaves no room to run ahead); as broadcast LDS reads they pipeline.
+  for (int i = tid; i < n * NK; i += NTH) sh[i] = twT[i];
+  // the first weight group does not depend on phase 1: in flight from here on
+  float2 wv[2][RB][JW];
+  auto load_w = [&](int g, int buf) {
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+      for (int j = 0; j < JW; ++j) wv[buf][rr][j] = wb[((size_t)(g * RB + rr) * K2 * C + j) * C];
+  };
+  if (!(FNO_MID_SKIP & 1)) load_w(0, 0);
+  // ---- phase 1 ----
+  {
+    float2 acc[NK];
+#pragma unroll
+    for (int r = 0; r < NK; ++r) acc[r] = make_float2(0.f, 0.f);
+    const float2* src = x1 + (size_t)o * n * inner + q;
+    bool first = true;
+#pragma unroll 2
+    for (int nb = seg; nb < n; nb += 8 * SEGS) {
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int nn = nb + SEGS * j;
+        v[j] = (nn < n && !(FNO_MID_SKIP & 2)) ? src[(size_t)nn * inner] : make_float2(0.f, 0.f);
+      }
+      if (first) { __syncthreads(); first = false; }      // the table is staged (n >= 1: every wave passes here once)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int nn = nb + SEGS * j;
+        if (nn < n) {
+          const float2* t = sh + nn * NK;
+#pragma unroll
+          for (int r = 0; r < NK; ++r) {
+            const float2 w = t[r];
+            acc[r].x = fmaf(w.x, v[j].x, acc[r].x); acc[r].x = fmaf(-w.y, v[j].y, acc[r].x);
+            acc[r].y = fmaf(w.x, v[j].y, acc[r].y); acc[r].y = fmaf(w.y, v[j].x, acc[r].y);
+          }
+        }
+      }
+    }
+    if (first) __syncthreads();
+    MID_STAMP(1);
+    __syncthreads();                                    // every wave is done reading the table
+#pragma unroll
+    for (int r = 0; r < NK; ++r) sh[(seg * NK + r) * 64 + ql] = acc[r];
+  }
+  __syncthreads();
+  MID_STAMP(2);
+  for (int r = seg; r < NK; r += SEGS) {
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEGS; ++k) { sx += sh[(k * NK + r) * 64 + ql].x; sy += sh[(k * NK + r) * 64 + ql].y; }
+    ys[r * 64 + ql] = make_float2(sx, sy);
+    if (hat) hat[((size_t)o * NK + r) * inner + q] = make_float2(sx, sy);
+  }
+  __syncthreads();
+  MID_STAMP(3);
+  // ---- phase 2 ----
+  if (!(FNO_MID_SKIP & 1))
+  {
+    const float sg = conj_w ? -1.f : 1.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) load_w(g + 1, (g + 1) & 1);
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        float ax = 0.f, ay = 0.f;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+          const float2 y = ys[(g * RB + rr) * 64 + lb + seg * JW + j];
+          const float2 w = wv[g & 1][rr][j];
+          const float wy = sg * w.y;
+          ax = fmaf(y.x, w.x, ax); ax = fmaf(-y.y, wy, ax);
+          ay = fmaf(y.x, wy, ay); ay = fmaf(y.y, w.x, ay);
+        }
+        sh[(seg * NK + g * RB + rr) * 64 + ql] = make_float2(ax, ay);
+      }
+    }
+  }
+  MID_STAMP(4);
+  __syncthreads();
+  MID_STAMP(5);
+  for (int r = seg; r < NK; r += SEGS) {
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEGS; ++k) { sx += sh[(k * NK + r) * 64 + ql].x; sy += sh[(k * NK + r) * 64 + ql].y; }
+    os[r * 64 + ql] = make_float2(sx, sy);
+  }
+  __syncthreads();
+  for (int i = tid; i < n * NK; i += NTH) sh[i] = twi[i];
+  __syncthreads();
+  MID_STAMP(6);
+  // ---- phase 3 ----
+  if (!(FNO_MID_SKIP & 4))
+  {
+    float2 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = os[k * 64 + ql];
+    float2* dst = z + (size_t)o * n * inner + q;
+#pragma unroll 2
+    for (int r = seg; r < n; r += SEGS) {
+      const float2* t = sh + r * NK;
+      float sr = 0.f, si = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float2 w = t[k];
+        sr = fmaf(w.x, v[k].x, sr); sr = fmaf(-w.y, v[k].y, sr);
+        si = fmaf(w.x, v[k].y, si); si = fmaf(w.y, v[k].x, si);
+      }
+      dst[(size_t)r * inner] = make_float2(sr, si);
+    }
+  }
+  MID_STAMP(7);
+}

@@ -732,6 +732,42 @@ def test_mode_contraction_matrix_cores_equal_valu_kernels(dev, shape, modes, cou
                 assert rel_l2(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("shape,modes", [((5, 64, 32, 64), (6, 6)), ((3, 32, 64, 32), (4, 8)), ((2, 64, 128, 128), (8, 5)),
+                                         ((4, 64, 32, 32), (2, 2))])
+def test_fused_spectral_middle_equals_three_launches(dev, shape, modes):
+    """k_spec_mid (leading-axis DFT -> mode contraction -> leading-axis inverse DFT of a fused 2-D block in ONE launch,
+    the default) vs the k_axis_fwd -> k_mode_gemm -> k_axis_inv sequence it replaces (fno_set_fused_mid(0)): y, dx, dW,
+    also when the switch flips between a forward and its backward (the forward packs the transposed weights either way).
+    32 / 64 channels, 4 / 8 / 12 / 16 kept leading modes, two-layer stacks."""
+    from pde_policylearning_amd import _lib
+    from pde_policylearning_amd import functional as F
+    C = shape[1]
+    x = torch.from_numpy(fill_named("fm.x", shape, 1.0)).to(dev)
+    dy = torch.from_numpy(fill_named("fm.dy", shape, 1.0)).to(dev)
+    ws = [torch.from_numpy(fill_named(f"fm.w{i}", (C, C) + tuple(modes) + (2,), 0.05)).to(dev) for i in range(4)]
+    skip = [torch.from_numpy(fill_named(f"fm.s{i}", (C, C, 1), 0.1)).to(dev) for i in range(2)]
+    bias = torch.from_numpy(fill_named("fm.b", (2, C), 0.1)).to(dev)
+    L = _lib.lib()
+    assert L.fno_get_fused_mid() == 1
+    res = []
+    for fwd_on, bwd_on in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        xe = x.clone().requires_grad_(True)
+        we = [w.clone().requires_grad_(True) for w in ws]
+        try:
+            L.fno_set_fused_mid(fwd_on)
+            y, names = _profiled_kernels(lambda: F.fno_blocks(xe, skip, we, bias, modes, "ortho"))
+            assert ("k_spec_mid" in names) == bool(fwd_on), names
+            L.fno_set_fused_mid(bwd_on)
+            y.backward(dy)
+            torch.cuda.synchronize()
+        finally:
+            L.fno_set_fused_mid(1)
+        res.append([_cpu(y), _cpu(xe.grad)] + [_cpu(w.grad) for w in we])
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert rel_l2(a, b) < 1e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # standalone spectral convolution at the shapes that take the MFMA last-dim tile kernels
 # (k_rowdft_tile / k_rowidft_tile: 32 or 64 channels, rows of 32 / 64 / 128 floats) vs the oracle
