@@ -1255,18 +1255,19 @@ __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ 
 #pragma unroll
     for (int r = 0; r < NK; ++r) acc[r] = make_float2(0.f, 0.f);
     const float2* src = x1 + (size_t)o * n * inner + q;
+    // 16 rows per lane in flight (two batches of 8) before the first use: one HBM round trip for n <= 128
+    constexpr int NBR = 16;
     bool first = true;
-#pragma unroll 2
-    for (int nb = seg; nb < n; nb += 8 * SEGS) {
-      float2 v[8];
+    for (int nb = seg; nb < n; nb += NBR * SEGS) {
+      float2 v[NBR];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NBR; ++j) {
         const int nn = nb + SEGS * j;
         v[j] = (nn < n && !(FNO_MID_SKIP & 2)) ? src[(size_t)nn * inner] : make_float2(0.f, 0.f);
       }
       if (first) { __syncthreads(); first = false; }      // the table is staged (n >= 1: every wave passes here once)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NBR; ++j) {
         const int nn = nb + SEGS * j;
         if (nn < n) {
           const float2* t = sh + nn * NK;

@@ -1,0 +1,37 @@
+"""Which torch (non-engine) GPU kernels an observer training step still launches, by aten op and input shape.
+usage (GPU box): python tools/torch_ops.py [rno2d|rno2d_shipped]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from pde_policylearning_amd import trainer
+from pde_policylearning_amd.libs.models.fno_models import RNO2dObserver
+kind = sys.argv[1] if len(sys.argv) > 1 else "rno2d"
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+width, (X, Y), B = (64, (128, 128), 32) if kind == "rno2d" else (34, (32, 32), 32)
+model = RNO2dObserver(12, 12, width, recurrent_index=0, layer_num=3).to(dev)
+x = torch.randn(B, X, Y, 1, device=dev)
+tgt = torch.randn(B, X, Y, device=dev)
+bucket = trainer.FlatGradBucket.for_model(model)
+opt = trainer.FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
+step = lambda: trainer.observer_train_step(model, None, opt, x, tgt)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    t = getattr(e, "self_device_time_total", None)
+    if t is None:
+        t = getattr(e, "self_cuda_time_total", 0)
+    if t > 0 and not e.key.startswith("k_"):
+        rows.append((t / 3, e.count / 3, e.key, str(e.input_shapes)[:110]))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"non-engine GPU time per step: {tot:.0f} us")
+for t, n, k, sh in rows[:40]:
+    print(f"{t:8.1f} us {n:6.1f}x {k:45s} {sh}")
