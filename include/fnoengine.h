@@ -160,6 +160,29 @@ int fno_model_backward(const FnoModelPlan* plan, int batch, const FnoModelParams
 int fno_model_backward_dx(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
                           const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
                           size_t ws_bytes, void* stream);
+/* One-layer block stacks with a tail: the layers of the RNO regressor, neuralop/models/rno.py:92-106
+ * SpectralConvWithFC.forward = act(spec_conv(dropout(x)) + Linear(x)) with act = ReLU (rno.py:214-215), channels-first.
+ *   forward   y = max(u, 0) if relu_out else u,   u = specconv(drop(x)) + skip_w x + bias
+ *   backward  g = dy * (y > 0) (the mask is read off the forward's output `y`), dx = skip_w^T g + drop-scale * (spectral
+ *             adjoint of g); parameter gradients as fno_model_backward_dx
+ * drop(x)[e] = x[e] * s[e], s[e] = 0 with probability drop_p and 1 / (1 - drop_p) otherwise, decided by a hash of the
+ * element index and the two 32-bit words at `drop_seed` (device memory; the caller draws them per call and passes the same
+ * pointer to the backward, which regenerates s instead of reading a mask; fno_dropout_scale writes s out for tests).
+ * drop_p = 0 disables the dropout (evaluation mode).  Plans: Cin = Cout = 0, n_layers = 1, 32 / 64 channels, rows of
+ * 32 / 64 / 128 floats, split-precision GEMM mode; anything else returns FNO_EUNSUPPORTED. */
+typedef struct FnoBlockTail {
+  int relu_out;
+  float drop_p;
+  const unsigned* drop_seed;   /* device pointer to 2 x uint32, or NULL when drop_p == 0 */
+  const float* y;              /* backward only: the forward's output (B, C, ...) */
+} FnoBlockTail;
+int fno_model_forward_tail(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x, float* y,
+                           void* saved, void* ws, size_t ws_bytes, void* stream, const FnoBlockTail* tail);
+int fno_model_backward_tail(const FnoModelPlan* plan, int batch, const FnoModelParams* p, const float* x,
+                            const float* dy, const void* saved, const FnoModelGrads* g, float* dx, void* ws,
+                            size_t ws_bytes, void* stream, const FnoBlockTail* tail);
+int fno_dropout_scale(size_t n, float drop_p, const unsigned* seed /*device, 2 words*/, float* out /*device, n*/, void* stream);
+
 /* The same pass in parts: layers l_hi .. l_lo (descending; l_hi = n_layers-1 includes the projection, l_lo = 0 the
  * lifting).  Calls over a partition of the layers with the SAME workspace reproduce the full pass bit for bit, and each
  * call finishes the gradients of its own layers - a data-parallel caller starts the all-reduce of the late layers'

@@ -29,6 +29,10 @@ class FnoModelDesc(C.Structure):
                 ("norm", C.c_int), ("gelu_mask", C.c_uint)]
 
 
+class FnoBlockTail(C.Structure):        # include/fnoengine.h: one-layer block stacks with a tail (RNO regressor layers)
+    _fields_ = [("relu_out", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_void_p), ("y", C.c_void_p)]
+
+
 class FnoModelParams(C.Structure):
     _fields_ = [("lift_w", C.c_void_p), ("lift_b", C.c_void_p),
                 ("skip_w", C.c_void_p * FNO_MAX_LAYERS),
@@ -138,6 +142,10 @@ def lib():
                                         C.POINTER(FnoModelGrads), vp, vp, sz, vp]
     L.fno_model_backward_part.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp,
                                           C.POINTER(FnoModelGrads), vp, vp, sz, vp, ci, ci]
+    L.fno_model_forward_tail.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp, vp, sz, vp, C.POINTER(FnoBlockTail)]
+    L.fno_model_backward_tail.argtypes = [vp, ci, C.POINTER(FnoModelParams), vp, vp, vp,
+                                          C.POINTER(FnoModelGrads), vp, vp, sz, vp, C.POINTER(FnoBlockTail)]
+    L.fno_dropout_scale.argtypes = [sz, C.c_float, vp, vp, vp]
     L.fno_profile_enable.argtypes = [ci]
     L.fno_profile_enable.restype = None
     L.fno_profile_reset.restype = None
@@ -160,6 +168,7 @@ EXPORTED_SYMBOLS = [
     "fno_spec_forward", "fno_spec_backward",
     "fno_model_plan_create", "fno_model_plan_destroy", "fno_model_workspace_bytes", "fno_model_saved_bytes",
     "fno_model_forward", "fno_model_backward", "fno_model_backward_dx", "fno_model_backward_part",
+    "fno_model_forward_tail", "fno_model_backward_tail", "fno_dropout_scale",
     "fno_fanout_saved_bytes", "fno_fanout_workspace_bytes", "fno_fanout_forward", "fno_fanout_backward",
     "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
     "fno_pointwise_workspace_bytes", "fno_pointwise_forward", "fno_pointwise_backward",

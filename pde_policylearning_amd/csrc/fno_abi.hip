@@ -667,15 +667,30 @@ static int dev_ncu() {
   }
   return ncu;
 }
+// what the tile kernel does to the rows while it stages them (k_rowdft_tile's MOD): dropout of the input, or the ReLU
+// derivative read off a forward output (the masked tensor is written out as well)
+struct RowMod { const unsigned* drop_seed = nullptr; float drop_p = 0.f; const float* ymask = nullptr; float* gmasked = nullptr; };
 static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const float* tT, int K2P, int B, int C,
-                       const float* x, float* x1, int act_in = 0) {
+                       const float* x, float* x1, int act_in = 0, const RowMod* mod = nullptr) {
   if (act_in && !row_chan_ok(g, K2P, C)) return fail(FNO_EUNSUPPORTED, "input_gelu needs <= 64 channels, rows <= 320, <= 32 kept bins");
+  if (mod && (act_in || !row_fast_ok(g, C))) return fail(FNO_EUNSUPPORTED, "dropout / ReLU-mask row passes need the tile kernel's shapes");
   if (!act_in && row_fast_ok(g, C)) {
     RowDftArgs a;
+    memset(&a, 0, sizeof(a));
     a.x = x; a.x1 = x1; a.tfwd = tfwd; a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2out = g.Klast; a.NJ = g.NJ;
     a.tiles_per_plane = g.PW / 128; a.ntiles = B * a.tiles_per_plane;
     const size_t lds = ((size_t)C * 132 + (size_t)16 * g.NJ * (g.W + 4)) * 4;
     const int grid = std::min(a.ntiles, 3 * dev_ncu());
+    if (mod && mod->ymask) {
+      a.ymask = mod->ymask; a.gmasked = mod->gmasked;
+      if (C == 32) return launch("k_rowdft_tile_relu", k_rowdft_tile<32, 128, 2>, dim3(grid), dim3(256), lds, st, a);
+      return launch("k_rowdft_tile_relu", k_rowdft_tile<64, 128, 2>, dim3(grid), dim3(256), lds, st, a);
+    }
+    if (mod && mod->drop_seed) {
+      a.drop_seed = mod->drop_seed; a.drop_p = mod->drop_p;
+      if (C == 32) return launch("k_rowdft_tile_drop", k_rowdft_tile<32, 128, 1>, dim3(grid), dim3(256), lds, st, a);
+      return launch("k_rowdft_tile_drop", k_rowdft_tile<64, 128, 1>, dim3(grid), dim3(256), lds, st, a);
+    }
     if (C == 32) return launch("k_rowdft_tile", k_rowdft_tile<32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowdft_tile", k_rowdft_tile<64, 128>, dim3(grid), dim3(256), lds, st, a);
   }
@@ -1064,12 +1079,17 @@ template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
                      (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
-  if (p->loose)
+  if (p->loose && !a.relu_out)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
-  if (a.lw)
+  if (a.lw && !a.relu_out)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
+  if (a.relu_out) {
+    if (p->NPX != 128 || p->loose || a.lw) return fail(FNO_EUNSUPPORTED, "ReLU output: 128-pixel tiles of whole rows, no fused lifting");
+    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, false, true>, dim3(grid),
+                  dim3((C / 32) * (4 / FNO_NTW_PWX) * 64), lds, st, a);
+  }
   if (p->NPX == 128)
     return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
@@ -1105,6 +1125,12 @@ template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a) {
   const size_t pitch = p->NPX + 4;
   static const int v1 = getenv("FNO_BBWD_V1") ? 1 : 0;        // A/B switch: the first-generation split-precision kernel
+  if (a.drop_seed) {      // dropout of the spectral branch (one-layer stacks with a tail, fno_model_*_tail)
+    if (p->loose || a.lw || a.xin || !g_gemm_x3 || p->NPX != 128 || bbwd_t_lds(C, a) > 160 * 1024)
+      return fail(FNO_EUNSUPPORTED, "spectral-branch dropout: split-precision GEMM mode, 128-pixel tiles of whole rows, no lifting");
+    return launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+                  bbwd_t_lds(C, a), st, a);
+  }
   if (p->loose) {
     if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
     BlkBwdArgs al = a;
@@ -1234,10 +1260,34 @@ static int spectral_mid_fwd(const FnoModelPlan* p, hipStream_t st, int B, const 
   return lead_inverse(st, g, p->t, B, C, w.ohat, w.tmp, w.z);
 }
 
+// one-layer block stacks with a tail (FnoBlockTail, include/fnoengine.h): what the plan must look like
+static int tail_check(const FnoModelPlan* p, const FnoBlockTail* t, bool backward) {
+  if (!t) return FNO_OK;
+  const FnoModelDesc& d = p->d;
+  if (d.Cin != 0 || d.Cout != 0 || d.n_layers != 1) return fail(FNO_EUNSUPPORTED, "block tail: one-layer block stacks only");
+  if (!g_gemm_x3 || p->NPX != 128 || p->loose || !row_fast_ok(p->g, d.C))
+    return fail(FNO_EUNSUPPORTED, "block tail: split-precision GEMM mode, 32 / 64 channels, rows of 32 / 64 / 128 floats");
+  if (t->drop_p < 0.f || t->drop_p >= 1.f) return fail(FNO_EINVAL, "block tail: dropout rate %g outside [0, 1)", (double)t->drop_p);
+  if (t->drop_p > 0.f && !t->drop_seed) return fail(FNO_EINVAL, "block tail: dropout needs the two seed words (device pointer)");
+  if (backward && t->relu_out && !t->y) return fail(FNO_EINVAL, "block tail: the backward of a ReLU tail needs the forward's output");
+  return FNO_OK;
+}
+static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x, float* y,
+                              void* saved, void* ws, size_t ws_bytes, void* stream, const FnoBlockTail* tail);
 extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x, float* y,
                                  void* saved, void* ws, size_t ws_bytes, void* stream) {
+  return model_forward_impl(p, B, prm, x, y, saved, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int fno_model_forward_tail(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x, float* y,
+                                      void* saved, void* ws, size_t ws_bytes, void* stream, const FnoBlockTail* tail) {
+  if (!tail) return fail(FNO_EINVAL, "fno_model_forward_tail: null tail");
+  return model_forward_impl(p, B, prm, x, y, saved, ws, ws_bytes, stream, tail);
+}
+static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x, float* y,
+                              void* saved, void* ws, size_t ws_bytes, void* stream, const FnoBlockTail* tail) {
   if (!p || !prm || !x || !y || B < 1) return fail(FNO_EINVAL, "fno_model_forward: bad argument");
   if (!saved) return fail(FNO_EINVAL, "fno_model_forward: `saved` buffer required (fno_model_saved_bytes)");
+  LAUNCHCHK(tail_check(p, tail, false));
   hipStream_t st = (hipStream_t)stream;
   const Geom& g = p->g;
   const FnoModelDesc& d = p->d;
@@ -1278,6 +1328,10 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
     if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, u, w.x1));   // no epilogue on loose rows
+  } else if (tail && tail->drop_p > 0.f) {
+    RowMod mod;                          // the spectral branch sees drop(x) (rno.py:98); the skip branch below reads x itself
+    mod.drop_seed = tail->drop_seed; mod.drop_p = tail->drop_p;
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1, 0, &mod));
   } else {
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));     // block stack: x is u_0
   }
@@ -1299,6 +1353,7 @@ extern "C" int fno_model_forward(const FnoModelPlan* p, int B, const FnoModelPar
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.act_out = (d.gelu_mask >> l) & 1u;
+    a.relu_out = tail && tail->relu_out;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
@@ -1331,10 +1386,25 @@ extern "C" int fno_model_backward_dx(const FnoModelPlan* p, int B, const FnoMode
 // lifting.  Consecutive calls over a partition of the layers with the SAME workspace reproduce the full pass bit for
 // bit (the running gradient and its row spectrum live in the workspace); every call finishes the gradients of its own
 // layers (slab reduction + weight unpack), so a data-parallel caller can start exchanging them while the rest runs.
+static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                               const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
+                               size_t ws_bytes, void* stream, int l_hi, int l_lo, const FnoBlockTail* tail);
 extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
                                        const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
                                        size_t ws_bytes, void* stream, int l_hi, int l_lo) {
+  return model_backward_impl(p, B, prm, x, dy, saved, gr, dx, ws, ws_bytes, stream, l_hi, l_lo, nullptr);
+}
+extern "C" int fno_model_backward_tail(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                                       const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
+                                       size_t ws_bytes, void* stream, const FnoBlockTail* tail) {
+  if (!p || !tail) return fail(FNO_EINVAL, "fno_model_backward_tail: null argument");
+  return model_backward_impl(p, B, prm, x, dy, saved, gr, dx, ws, ws_bytes, stream, p->d.n_layers - 1, 0, tail);
+}
+static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParams* prm, const float* x,
+                               const float* dy, const void* saved, const FnoModelGrads* gr, float* dx, void* ws,
+                               size_t ws_bytes, void* stream, int l_hi, int l_lo, const FnoBlockTail* tail) {
   if (!p || !prm || !x || !dy || !saved || !gr || B < 1) return fail(FNO_EINVAL, "fno_model_backward: bad argument");
+  LAUNCHCHK(tail_check(p, tail, true));
   if (dx && p->d.Cin > 4) return fail(FNO_EUNSUPPORTED, "input gradient through the lifting layer: at most 4 input channels");
   if (l_lo < 0 || l_hi >= p->d.n_layers || l_lo > l_hi) return fail(FNO_EINVAL, "fno_model_backward_part: layers %d..%d", l_hi, l_lo);
   hipStream_t st = (hipStream_t)stream;
@@ -1366,6 +1436,12 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   memset(&pb, 0, sizeof(pb));
   if (l_hi < L - 1) {
     // a later part: the running gradient and its row spectrum were left in the workspace by the previous call
+  } else if (!has_proj && tail && tail->relu_out) {
+    // dy is dL/d relu(u_L): the row pass applies the derivative (mask read off the forward's output) and leaves
+    // g = dL/du_L in the workspace for the block kernel
+    RowMod mod;
+    mod.ymask = tail->y; mod.gmasked = w.ga;
+    LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1, 0, &mod));
   } else if (!has_proj) {
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
@@ -1389,7 +1465,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
   if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, w.ga, w.x1));   // dL/du_L's row spectrum
   }
 
-  const float* gcur = has_proj ? w.ga : dy;   // dL/du_{l+1}
+  const float* gcur = (has_proj || (tail && tail->relu_out)) ? w.ga : dy;   // dL/du_{l+1}
   float* gnext = has_proj ? w.gb : w.ga;
   float* gspare = has_proj ? w.ga : w.gb;
   for (int l = L - 1; l > l_hi; --l) {        // replay the buffer rotation of the layers done by earlier parts
@@ -1432,6 +1508,7 @@ extern "C" int fno_model_backward_part(const FnoModelPlan* p, int B, const FnoMo
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    if (tail && tail->drop_p > 0.f) { a.drop_seed = tail->drop_seed; a.drop_p = tail->drop_p; }
     LAUNCHCHK(launch_bbwd(p, st, s.grid_bb, a));
     if (p->loose && l > 0)     // the running gradient's row spectrum for the next (lower) block, in its own pass
       LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, gnext, w.x1));
@@ -1979,6 +2056,18 @@ extern "C" int fno_rno_output_gate_backward(size_t n, const float* g, const floa
   a.ds1 = (float4*)d_s1; a.ds7 = (float4*)d_s7; a.ds3 = (float4*)d_s3; a.dh = (float4*)d_h; a.db_part = db_partials;
   a.n4 = n / 4;
   return launch("k_rno_out_bwd", k_rno_out_bwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, a);
+}
+
+// the dropout scale field the kernels regenerate (tests / oracles): out[e] = 0 or 1 / (1 - p)
+__global__ void __launch_bounds__(256) k_drop_scale(float* __restrict__ out, size_t n, const unsigned* __restrict__ seed, float p) {
+  const DropCfg dc = drop_cfg(seed, p);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) out[e] = drop_scale(dc, e);
+}
+extern "C" int fno_dropout_scale(size_t n, float drop_p, const unsigned* seed, float* out, void* stream) {
+  if (!seed || !out || drop_p < 0.f || drop_p >= 1.f) return fail(FNO_EINVAL, "fno_dropout_scale: bad argument");
+  if (n == 0) return FNO_OK;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)8 * dev_ncu());
+  return launch("k_drop_scale", k_drop_scale, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, n, seed, drop_p);
 }
 
 // ===========================================================================

@@ -430,6 +430,26 @@ FNO_DEV void row_dft_epilogue(const float* tile, const float* __restrict__ tfwd,
   }
 }
 
+// Counter-based dropout (rno.py:89,98: nn.Dropout on the spectral branch's input): the keep / drop decision of element e
+// is a hash of (e, two 32-bit words the caller draws per call and keeps in device memory), so the backward kernels
+// regenerate the mask instead of reading one.  drop_scale = 0 with probability p, 1 / (1 - p) otherwise.
+FNO_DEV unsigned mix32(unsigned x) {      // (lowbias32: full-avalanche 32-bit mixer)
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCfg { unsigned key, thr; float inv_keep; };        // thr = p * 2^32: dropped iff hash < thr
+FNO_DEV DropCfg drop_cfg(const unsigned* seed, float p) {
+  DropCfg d;
+  d.key = seed[0] ^ (seed[1] * 0x85ebca6bU);
+  d.thr = (unsigned)fminf(p * 4294967296.f, 4294967040.f);
+  d.inv_keep = 1.f / (1.f - p);
+  return d;
+}
+FNO_DEV float drop_scale(const DropCfg& d, size_t e) {
+  const unsigned x = ((unsigned)e ^ d.key) * 0x9E3779B1U + (unsigned)(e >> 32);
+  return mix32(x) < d.thr ? 0.f : d.inv_keep;
+}
+
 // Register-staged prefetch of a tile's rows: issue() starts the HBM loads for the NEXT tile,
 // commit() (one iteration later) applies the optional GELU and writes them to LDS.
 template <int NPX, int NT, int NROWS, int NROWS_PAD>
@@ -454,6 +474,17 @@ struct TilePrefetch {
       float4 t = v[i];
       if (act) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
       if (idx < TOTAL) st4(dst + c * PITCH + 4 * q, t);
+    }
+  }
+  // commit with a per-piece transform f(t, row c, float4 index q within the row)
+  template <typename F>
+  FNO_DEV void commit_with(float* dst, int tid, F f) {
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int idx = tid + i * NT;
+      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
+      float4 t = v[i];
+      if (idx < TOTAL) { f(t, c, q, i); st4(dst + c * PITCH + 4 * q, t); }
     }
   }
 };

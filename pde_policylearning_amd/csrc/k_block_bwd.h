@@ -45,6 +45,8 @@ struct BlkBwdArgs {
   int kch;             // loose rows: kept last-dim modes per K-extension chunk (0 = all at once); the spectral rows and
                        // the table of a chunk are staged right before it is applied, so many kept modes still fit LDS
   int tiles_per_plane, ntiles;
+  const unsigned* drop_seed;   // k_block_bwd_t<.., DROPK = true>: the forward's dropout words and rate (fno_dev.h: drop_cfg)
+  float drop_p;
 };
 
 template <int C, int NPX>

@@ -69,10 +69,13 @@ FNO_DEV f32x16 kext_loose_rows_t(f32x16 acc, const float* zs, const float* tinv_
   return acc;
 }
 
-template <int C, int NPX, bool LOOSE = false, bool LIFT = false>
+// DROPK: the spectral branch saw drop(x) in the forward pass (rno.py:98): its gradient, the K-extension part of dx, is
+// multiplied by the regenerated dropout scale before the skip branch's W^T g is accumulated on top of it.
+template <int C, int NPX, bool LOOSE = false, bool LIFT = false, bool DROPK = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(BlkBwdArgs a) {
   using Cfg = BlkBwdCfg<C, NPX>;
   static_assert(NPX == 128, "images are 128 pixels wide");
+  static_assert(!DROPK || (!LOOSE && !LIFT), "dropout of the spectral branch: whole rows, no lifting");
   constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
   constexpr int NT = NW * 64;
   constexpr int KB = C / 16;
@@ -236,6 +239,18 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
       f32x16 hi, lo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
+      if constexpr (DROPK) {
+        if (a.zg) {
+          const float* zr = zs + (((n0 / a.W) * a.K2in) * C + crow) * 2 + half;
+          const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
+#pragma unroll 2
+          for (int s = 0; s < a.K2in; ++s) hi = mfma32(tv[2 * s * a.W], zr[s * C * 2], hi);
+          const DropCfg dc = drop_cfg(a.drop_seed, a.drop_p);
+          const size_t e0 = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;      // hi[4 i + j] <-> element e0 + 8 i + j
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hi[r] *= drop_scale(dc, e0 + 8 * (r >> 2) + (r & 3));
+        }
+      }
       // lane 4q + p of a 16-lane group supplies row q, pixels 4p .. 4p + 3 of its 4 x 16 block; groups 0 / 1 = pixels
       // 0-15 / 16-31 of k half 0, groups 2 / 3 the same pixels of k half 1
       const int tq = l15 >> 2, tp = l15 & 3;
@@ -270,7 +285,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
           acc = kext_loose_rows_t<C>(acc, zs, tinv_s, kc, a.W, px0 + n0, r_lo, mt, l31, half);
         }
       }
-    } else if (a.zg) {
+    } else if (a.zg && !DROPK) {
       const float* zr = zs + (((n0 / a.W) * a.K2in) * C + crow) * 2 + half;
       const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
 #pragma unroll 2

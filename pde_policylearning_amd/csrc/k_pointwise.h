@@ -43,6 +43,7 @@ struct PwFwdArgs {
   const float* add;   // (B, COUT, PW) tensor added to the output before it is stored, or null
   int PW, W, P, K2in, K2out, NJ;
   int act_in, act_out;
+  int relu_out;       // k_pw_fwd_x3<.., RELU = true>: store max(u, 0)
   int loose;          // rows do not tile the pixel tile (W >= 32, any remainder): spectral rows per tile vary, no x1 epilogue
   const float* lw;    // LIFT variant of k_pw_fwd_x3 (block 0 computes u_0 = lw x + lb itself): lifting weight (C, CL) ...
   const float* lb;    // ... and bias (C); x is then the (B, CL, PW) model input
@@ -180,8 +181,14 @@ struct RowDftArgs {
   const float* tfwd;   // (16*NJ, W)
   int PW, W, P, K2out, NJ;
   int tiles_per_plane, ntiles;
+  // MOD = 1: the rows of drop(x) (counter-based dropout, fno_dev.h; rno.py:98 spec_conv(dropout(x)))
+  const unsigned* drop_seed;
+  float drop_p;
+  // MOD = 2: the rows of g = x * (ymask > 0) (ReLU derivative read off the forward's output); g itself is also written
+  const float* ymask;  // (B, C, PW)
+  float* gmasked;      // (B, C, PW)
 };
-template <int C, int NPX>
+template <int C, int NPX, int MOD = 0>
 __global__ void __launch_bounds__(256) k_rowdft_tile(RowDftArgs a) {
   constexpr int NW = 4, NT = NW * 64, PITCH = NPX + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -190,14 +197,34 @@ __global__ void __launch_bounds__(256) k_rowdft_tile(RowDftArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
   TilePrefetch<NPX, NT, C, C> pf;
+  TilePrefetch<NPX, NT, MOD == 2 ? C : 1, MOD == 2 ? C : 1> pfy;
+  DropCfg dc = {0u, 0u, 1.f};
+  if constexpr (MOD == 1) dc = drop_cfg(a.drop_seed, a.drop_p);
   auto issue = [&](int tile) {
-    pf.issue(a.x + (size_t)(tile / a.tiles_per_plane) * C * a.PW + (tile % a.tiles_per_plane) * NPX, a.PW, tid);
+    const size_t off = (size_t)(tile / a.tiles_per_plane) * C * a.PW + (tile % a.tiles_per_plane) * NPX;
+    pf.issue(a.x + off, a.PW, tid);
+    if constexpr (MOD == 2) pfy.issue(a.ymask + off, a.PW, tid);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pf.commit(xs, false, tid);
+    if constexpr (MOD == 1) {
+      const size_t e0 = (size_t)b * C * a.PW + px0;
+      pf.commit_with(xs, tid, [&](float4& t, int c, int q, int) {
+        const size_t e = e0 + (size_t)c * a.PW + 4 * q;
+        t.x *= drop_scale(dc, e); t.y *= drop_scale(dc, e + 1); t.z *= drop_scale(dc, e + 2); t.w *= drop_scale(dc, e + 3);
+      });
+    } else if constexpr (MOD == 2) {
+      float* gdst = a.gmasked + (size_t)b * C * a.PW + px0;
+      pf.commit_with(xs, tid, [&](float4& t, int c, int q, int i) {
+        const float4 y = pfy.v[i];
+        t.x = y.x <= 0.f ? 0.f : t.x; t.y = y.y <= 0.f ? 0.f : t.y; t.z = y.z <= 0.f ? 0.f : t.z; t.w = y.w <= 0.f ? 0.f : t.w;   // threshold_backward
+        st4(gdst + (size_t)c * a.PW + 4 * q, t);
+      });
+    } else {
+      pf.commit(xs, false, tid);
+    }
     __syncthreads();
     if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
     row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
@@ -226,7 +253,9 @@ static inline size_t pw_fwd_x3_lds_bytes(int c, int npx, int W, int K2in, int NJ
 // NTW = 32-pixel column tiles per wave.  NTW = 2 halves the workgroup (4 waves at C = 64, NPX = 128)
 // so that TWO workgroups share a CU at the same 256-VGPR budget per wave: their phases (split /
 // MFMA / epilogue / row DFT) drift apart and the matrix pipe of one overlaps the VALU work of the other.
-template <int C, int NPX, int NTW, bool LOOSE = false, bool LIFT = false>
+// RELU: the stored tensor is max(u, 0) (the one-layer stacks of the RNO regressor, rno.py:92-106, whose backward reads the
+// ReLU mask off this output)
+template <int C, int NPX, int NTW, bool LOOSE = false, bool LIFT = false, bool RELU = false>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX) k_pw_fwd_x3(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;
   constexpr int NTG = NTN / NTW;          // wave groups along the pixel dimension
@@ -349,6 +378,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
           const float* ap = a.add + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[q][r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
+        }
+        if constexpr (RELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] = acc[q][r] < 0.f ? 0.f : acc[q][r];      // (NaN stays NaN, as torch's relu)
         }
         if (up) {
 #pragma unroll

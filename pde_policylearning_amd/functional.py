@@ -379,7 +379,8 @@ class _FNOBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, bias, *rest):
-        n_layers, modes, norm, gelu_mask, direct = cfg
+        n_layers, modes, norm, gelu_mask, direct = cfg[:5]
+        tail = cfg[5] if len(cfg) > 5 else None      # (relu_out, drop_p, seed tensor or None): fno_model_*_tail
         ctx.direct = direct
         _require_cuda(x, "x")
         x = x.contiguous()
@@ -406,10 +407,20 @@ class _FNOBlocksFn(torch.autograd.Function):
         nws = L.fno_model_workspace_bytes(plan, B)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.fno_model_forward(plan, B, C.byref(prm), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), nws,
-                                           _stream()), "blocks_forward")
+            if tail is None:
+                _lib.check(L.fno_model_forward(plan, B, C.byref(prm), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), nws,
+                                               _stream()), "blocks_forward")
+            else:
+                relu_out, drop_p, seed = tail
+                t = _lib.FnoBlockTail(int(relu_out), float(drop_p), _ptr(seed), None)
+                _lib.check(L.fno_model_forward_tail(plan, B, C.byref(prm), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), nws,
+                                                    _stream(), C.byref(t)), "blocks_forward_tail")
         ctx.plan, ctx.B, ctx.n_layers, ctx.ncorner, ctx.has_sb = plan, B, n_layers, ncorner, sb is not None
-        ctx.save_for_backward(x, saved, *skip_ws, *spec_ws, *([sb] if sb is not None else []))
+        ctx.tail = None if tail is None else (bool(tail[0]), float(tail[1]))
+        extra = []
+        if tail is not None:
+            extra = [y if tail[0] else x.new_empty(0), tail[2] if tail[2] is not None else x.new_empty(0)]
+        ctx.save_for_backward(x, saved, *skip_ws, *spec_ws, *([sb] if sb is not None else []), *extra)
         return y
 
     @staticmethod
@@ -436,8 +447,16 @@ class _FNOBlocksFn(torch.autograd.Function):
         nws = L.fno_model_workspace_bytes(ctx.plan, ctx.B)
         ws = _bytes(nws, dy.device)
         with torch.cuda.device(dy.device):
-            _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
-                                               C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "blocks_backward")
+            if ctx.tail is None:
+                _lib.check(L.fno_model_backward_dx(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                   C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream()), "blocks_backward")
+            else:
+                y_out, seed = sv[-2], sv[-1]
+                t = _lib.FnoBlockTail(int(ctx.tail[0]), ctx.tail[1], _ptr(seed) if seed.numel() else None,
+                                      _ptr(y_out) if y_out.numel() else None)
+                _lib.check(L.fno_model_backward_tail(ctx.plan, ctx.B, C.byref(prm), _ptr(x), _ptr(dy), _ptr(saved),
+                                                     C.byref(grd), _ptr(dx), _ptr(ws), nws, _stream(), C.byref(t)),
+                           "blocks_backward_tail")
         if ctx.direct is not None:
             _notify_direct(ctx.direct)
         return (None, dx, g_sb) + tuple(g_skip) + ((None,) * len(g_spec) if ctx.direct is not None else tuple(g_spec))
@@ -464,6 +483,46 @@ def blocks_supported(x, n_layers=1, modes=None, norm="backward", gelu_mask=0):
         return True
     return model_plan_available(x.dim() - 2, 0, c, 0, 0, n_layers, tuple(x.shape[2:]), tuple(int(m) for m in modes), norm,
                                 int(gelu_mask), x.device)
+
+
+def block_tail_supported(x, modes, norm):
+    """Shapes fno_block_tail covers: what one fused block covers on whole rows (32 / 64 channels, rows of 32 / 64 / 128
+    floats tiling 128-pixel tiles), split-precision GEMM mode."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _lib.lib().fno_get_gemm_mode() == 1):
+        return False
+    w, pw = x.shape[-1], x.shape[-1] * x.shape[-2]
+    if not (x.shape[1] in (32, 64) and w in (32, 64, 128) and pw % 128 == 0):
+        return False
+    return blocks_supported(x, 1, modes, norm)
+
+
+def draw_dropout_seed(device):
+    """Two 32-bit words for the engine's counter-based dropout, drawn on the device by torch's generator: follows
+    torch.manual_seed, and is safe under hipGraph capture (the generator's offset advances per replay)."""
+    return torch.randint(-2 ** 31, 2 ** 31 - 1, (2,), device=device, dtype=torch.int32)
+
+
+def dropout_scale(n, drop_p, seed, device):
+    """The 0 / 1/(1-p) field the kernels regenerate from `seed` for a tensor of n elements (tests, oracles)."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().fno_dropout_scale(n, float(drop_p), _ptr(seed), _ptr(out), _stream()), "dropout_scale")
+    return out
+
+
+def fno_block_tail(x, skip_w, spec_ws, bias, modes, norm, relu_out=True, drop_p=0.0, seed=None, direct_grads=False):
+    """One fused Fourier layer with the tail of the RNO regressor's layers (rno.py:92-106, channels-first):
+    y = relu(specconv(drop(x)) + skip_w x + bias).  `seed`: draw_dropout_seed() (required when drop_p > 0).  The ReLU, its
+    derivative, the dropout mask (regenerated in the backward) and the accumulation of the two branches' input gradients
+    all happen inside the engine kernels (fno_model_forward_tail / fno_model_backward_tail)."""
+    sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_ws]
+    direct = None
+    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws):
+        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
+    if drop_p > 0 and seed is None:
+        raise ValueError("fno_block_tail: drop_p > 0 needs a seed (draw_dropout_seed)")
+    cfg = (1, tuple(int(m) for m in modes), norm, 0, direct, (bool(relu_out), float(drop_p), seed if drop_p > 0 else None))
+    return _FNOBlocksFn.apply(cfg, x, bias, skip_w, *sw)
 
 
 def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0, direct_grads=False):

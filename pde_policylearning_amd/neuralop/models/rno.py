@@ -61,6 +61,17 @@ class SpectralConvWithFC(nn.Module):
         `linear(a) + bias + spec_conv(dropout(a))` is ONE fno_pointwise_* launch with the spectral branch as its
         addend (the dropout mask is drawn on the channels-first tensor: same distribution, different element order
         than the reference's channels-last draw)."""
+        sc = self.spec_conv
+        relu, ident = isinstance(self.activation, nn.ReLU), isinstance(self.activation, nn.Identity)
+        if ((relu or ident) and not getattr(self, "no_engine_tail", False) and a.shape[-1] == a.shape[-2]
+                and F.block_tail_supported(a, (sc.modes1, sc.modes2), sc.norm)):
+            # ONE fused engine layer incl. the dropout of the spectral branch (counter-based mask, regenerated in the
+            # backward), the ReLU and its derivative (fno_model_forward_tail / _backward_tail); the mask comes from the
+            # engine's hash of torch-drawn seed words: same distribution as nn.Dropout, a different stream
+            p = self.dropout.p if self.training else 0.0
+            seed = F.draw_dropout_seed(a.device) if p > 0 else None
+            return F.fno_block_tail(a.contiguous(), self.linear.weight, list(sc.fourier_weight), self.linear.bias.view(1, -1),
+                                    (sc.modes1, sc.modes2), sc.norm, relu_out=relu, drop_p=p, seed=seed)
         s = self.spec_conv(self.dropout(a))
         return self.activation(F.pointwise_conv_add(a, self.linear.weight, self.linear.bias, addend=s))
 

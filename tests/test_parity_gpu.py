@@ -939,48 +939,89 @@ def test_rno2d_width64_engine_regressor_vs_oracle(dev):
     yc = OO.rno2d_forward(pc, x, 6, 6, 64, 1, 1)
     O.lp_loss_rel_sum(yc, tgt).backward()
     model = model.to(dev)
-    calls = {"proj": 0, "pw": 0, "lift": 0}
-    orig = (F.projection_head, F.pointwise_conv_add, F.lifting)
+    calls = {"proj": 0, "pw": 0, "lift": 0, "tail": 0}
+    orig = (F.projection_head, F.pointwise_conv_add, F.lifting, F.fno_block_tail)
     def spy(name, fn):
         def w(*a, **k):
             calls[name] += 1
             return fn(*a, **k)
         return w
-    F.projection_head, F.pointwise_conv_add, F.lifting = spy("proj", orig[0]), spy("pw", orig[1]), spy("lift", orig[2])
+    F.projection_head, F.pointwise_conv_add, F.lifting, F.fno_block_tail = (spy("proj", orig[0]), spy("pw", orig[1]),
+                                                                            spy("lift", orig[2]), spy("tail", orig[3]))
     try:
         y = model(x.to(dev))
     finally:
-        F.projection_head, F.pointwise_conv_add, F.lifting = orig
-    assert calls == {"proj": 2, "pw": 4, "lift": 1}, calls
+        F.projection_head, F.pointwise_conv_add, F.lifting, F.fno_block_tail = orig
+    # the regressor's two layers run as fused one-layer stacks with a ReLU tail (fno_model_forward_tail), per predicted step
+    assert calls == {"proj": 2, "pw": 0, "lift": 1, "tail": 4}, calls
     assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
     O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
     for name, prm in model.named_parameters():
         assert rel_l2(_cpu(prm.grad), pc[name].grad.numpy()) < TOL_G, name
 
 
-def test_rno2d_regressor_train_mode_dropout(dev):
-    """train mode: the regressor's dropout (p = 0.3, rno.py:319-320) acts on the spectral branch only (rno.py:96-99); with the
-    mask drawn channels-first the layer must equal the torch composition under the SAME mask (same generator state)."""
+@pytest.mark.parametrize("engine_tail", [True, False])
+@pytest.mark.parametrize("shape,modes", [((2, 64, 32, 32), 6), ((3, 32, 64, 64), 8), ((2, 64, 128, 128), 12)])
+def test_rno2d_regressor_train_mode_dropout(dev, engine_tail, shape, modes):
+    """train mode: the regressor's dropout (p = 0.3, rno.py:319-320) acts on the spectral branch only (rno.py:96-99).
+    engine_tail: the layer is ONE fused engine layer (fno_model_forward_tail / _backward_tail: counter-based dropout regenerated
+    in the backward, ReLU + derivative in the kernels) and must equal the torch composition under the SAME scale field
+    (fno_dropout_scale of the same seed words); otherwise (no_engine_tail) torch draws the mask and the layer must equal the
+    torch composition under the same generator state."""
+    from pde_policylearning_amd import functional as F
     from pde_policylearning_amd.neuralop.models.rno import SpectralConvWithFC
+    C = shape[1]
     torch.manual_seed(3)
-    layer = SpectralConvWithFC(64, 64, 6, 6, dropout=0.3, activation='relu').to(dev).train()
-    a = torch.randn(2, 64, 32, 32, device=dev, requires_grad=True)
+    layer = SpectralConvWithFC(C, C, modes, modes, dropout=0.3, activation='relu').to(dev).train()
+    layer.no_engine_tail = not engine_tail
+    a = torch.randn(*shape, device=dev, requires_grad=True)
+    dy = torch.randn(*shape, device=dev)
     torch.manual_seed(5)
-    y1 = layer.forward_channels_first(a)
-    y1.square().sum().backward()
+    y1, names = _profiled_kernels(lambda: layer.forward_channels_first(a))
+    assert ("k_rowdft_tile_drop" in names) == engine_tail, names
+    _, names = _profiled_kernels(lambda: y1.backward(dy))
+    assert ("k_rowdft_tile_relu" in names) == engine_tail, names
     g1 = [a.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
     a.grad = None
     layer.zero_grad()
     torch.manual_seed(5)
-    s = layer.spec_conv(layer.dropout(a))
-    y2 = torch.relu(s + torch.nn.functional.conv2d(a, layer.linear.weight.view(64, 64, 1, 1), layer.linear.bias))
-    y2.square().sum().backward()
+    if engine_tail:
+        scale = F.dropout_scale(a.numel(), 0.3, F.draw_dropout_seed(dev), dev).view_as(a)
+        kept = float((scale > 0).float().mean())
+        assert abs(kept - 0.7) < 0.01 and abs(float(scale.max()) - 1 / 0.7) < 1e-6, kept
+        s = layer.spec_conv(a * scale)
+    else:
+        s = layer.spec_conv(layer.dropout(a))
+    y2 = torch.relu(s + torch.nn.functional.conv2d(a, layer.linear.weight.view(C, C, 1, 1), layer.linear.bias))
+    y2.backward(dy)
     assert rel_l2(_cpu(y1), _cpu(y2)) < TOL_COMP
     for u, v in zip(g1, [a.grad] + [p.grad for p in layer.parameters()]):
         assert rel_l2(_cpu(u), _cpu(v)) < 2e-5
     assert float((y1 == 0).float().mean()) > 0.05          # ReLU active; and the mask really dropped inputs:
     layer.eval()
-    assert rel_l2(_cpu(layer.forward_channels_first(a)), _cpu(y1)) > 5e-5
+    assert rel_l2(_cpu(layer.forward_channels_first(a)), _cpu(y1)) > 1e-5       # (the xavier-initialised spectral branch is small)
+    # evaluation mode: no dropout, same layer
+    ye = layer.forward_channels_first(a)
+    yr = torch.relu(layer.spec_conv(a) + torch.nn.functional.conv2d(a, layer.linear.weight.view(C, C, 1, 1), layer.linear.bias))
+    assert rel_l2(_cpu(ye), _cpu(yr)) < TOL_COMP
+
+
+def test_engine_dropout_scale_statistics(dev):
+    """The counter-based dropout field (fno_dev.h: drop_scale): keep rate, independence of neighbouring elements and of the
+    two seed words, reproducibility."""
+    from pde_policylearning_amd import functional as F
+    n = 1 << 22
+    torch.manual_seed(11)
+    s1, s2 = F.draw_dropout_seed(dev), F.draw_dropout_seed(dev)
+    for p in (0.1, 0.3, 0.5):
+        m1 = (F.dropout_scale(n, p, s1, dev) > 0).float()
+        m2 = (F.dropout_scale(n, p, s2, dev) > 0).float()
+        assert torch.equal(m1, (F.dropout_scale(n, p, s1, dev) > 0).float())
+        for m in (m1, m2):
+            assert abs(float(m.mean()) - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4
+        for x, y in ((m1[:-1], m1[1:]), (m1[:-128], m1[128:]), (m1, m2)):       # neighbours, rows, seeds
+            cov = float(((x - x.mean()) * (y - y.mean())).mean()) / (p * (1 - p))
+            assert abs(cov) < 5 / n ** 0.5, cov
 
 
 # ---------------------------------------------------------------------------------------------

@@ -5,17 +5,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from pde_policylearning_amd import trainer
-from pde_policylearning_amd.libs.models.fno_models import RNO2dObserver
+from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
 kind = sys.argv[1] if len(sys.argv) > 1 else "rno2d"
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 width, (X, Y), B = (64, (128, 128), 32) if kind == "rno2d" else (34, (32, 32), 32)
-model = RNO2dObserver(12, 12, width, recurrent_index=0, layer_num=3).to(dev)
-x = torch.randn(B, X, Y, 1, device=dev)
-tgt = torch.randn(B, X, Y, device=dev)
-bucket = trainer.FlatGradBucket.for_model(model)
+model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82 (bench.py's workload)
+x = torch.randn(B, 1, X, Y, 1, device=dev)
+tgt = torch.randn(B, X, Y, 1, device=dev)
+bucket = trainer.FlatGradBucket(model.parameters())
 opt = trainer.FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
-step = lambda: trainer.observer_train_step(model, None, opt, x, tgt)
+loss_fn = trainer.FusedLpLoss(size_average=False)
+step = lambda: trainer.train_step(model, bucket, opt, (x,), tgt, loss_fn)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
