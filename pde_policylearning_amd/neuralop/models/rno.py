@@ -185,13 +185,18 @@ class RNO_layer(nn.Module):
     def forward(self, x, h=None):
         b, steps, _, n1, n2 = x.shape
         if h is None:
-            h = torch.zeros((b, self.width, n1, n2), device=x.device) + self.bias_h
+            # zeros + bias_h (rno.py:279) in one pass: the broadcast scalar materialised once (same values, same gradient)
+            h = self.bias_h.expand(b, self.width, n1, n2).contiguous()
         seq = []
         for t in range(steps):
-            h = self.cell(x[:, t], h)
+            # one time step (the shipped configuration): a view, so the backward needs no zero-filled (B, T, ...) scatter
+            xt = x.reshape(b, x.shape[2], n1, n2) if steps == 1 else x[:, t]
+            h = self.cell(xt, h)
             if self.return_sequences:
                 seq.append(h)
-        return torch.stack(seq, dim=1) if self.return_sequences else h
+        if not self.return_sequences:
+            return h
+        return torch.stack(seq, dim=1) if steps > 1 else seq[0].unsqueeze(1)
 
 
 # width-64 twins of narrow models (see RNO2d._wide_twin): keyed by the configuration, parameters on the meta device

@@ -29,10 +29,12 @@ for e in prof.key_averages(group_by_input_shape=True):
     t = getattr(e, "self_device_time_total", None)
     if t is None:
         t = getattr(e, "self_cuda_time_total", 0)
-    if t > 0 and not e.key.startswith("k_"):
+    k = e.key
+    if t > 0 and not (k.startswith("k_") or k.startswith("void k_") or k.startswith("_") or k.startswith("void at::") or k.startswith("__amd")
+                      or k.startswith("Memcpy") or k.startswith("Memset") or k.startswith("void (anonymous")):
         rows.append((t / 3, e.count / 3, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"non-engine GPU time per step: {tot:.0f} us")
-for t, n, k, sh in rows[:40]:
+for t, n, k, sh in rows[:60]:
     print(f"{t:8.1f} us {n:6.1f}x {k:45s} {sh}")
