@@ -2151,8 +2151,8 @@ static ProjWs carve_proj(int C, int HID, void* ws, size_t ws_bytes) {
   w.wa3 = c.take<unsigned short>((size_t)(HID / 32) * 2 * (C / 32) * 3 * 64 * 8);
   w.dw1_part = c.take<float>((size_t)grid * HID * C);
   w.db1_part = c.take<float>((size_t)grid * 4 * HID);
-  w.dw2_part = c.take<float>((size_t)grid * 4 * HID);
-  w.db2_part = c.take<float>(64);
+  w.dw2_part = c.take<float>((size_t)grid * 4 * PROJ_MAXCO * HID);
+  w.db2_part = c.take<float>((size_t)64 * PROJ_MAXCO);
   w.total = c.off;
   w.ok = c.ok;
   return w;
@@ -2160,7 +2160,7 @@ static ProjWs carve_proj(int C, int HID, void* ws, size_t ws_bytes) {
 static int proj_check(int B, int C, int HID, int CO, size_t PW) {
   LAUNCHCHK(pw_check(B, C, PW));
   if (HID != 128 && HID != 256) return fail(FNO_EUNSUPPORTED, "projection: hidden width 128 or 256 (got %d)", HID);
-  if (CO != 1) return fail(FNO_EUNSUPPORTED, "projection: one output channel (got %d)", CO);
+  if (CO < 1 || CO > PROJ_MAXCO) return fail(FNO_EUNSUPPORTED, "projection: 1..%d output channels (got %d)", PROJ_MAXCO, CO);
   if (!g_gemm_x3) return fail(FNO_EUNSUPPORTED, "projection entry points need the split-precision GEMM mode");
   return FNO_OK;
 }
@@ -2180,6 +2180,24 @@ static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
   const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
   return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
+// 2..PROJ_MAXCO output channels (PlanePredHead, pinobserver.py:257-273: fc2 -> out_dim * plane_num): the forward kernel with
+// PROJ_MAXCO output rows, the backward on the exact-fp32 first-generation kernel (the split-precision ones are built for one)
+template <int C, int HID>
+static int proj_fwd_launch_mo(hipStream_t st, int grid, const ProjFwdArgs& a) {
+  constexpr int NCO = PROJ_MAXCO;
+  const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(HID / 32) * (C / 16) * 3 * 64 * 16 + (size_t)(HID + NCO * HID + NCO * 128) * 4;
+  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, NCO, false>, dim3(grid), dim3(512), lds, st, a);
+}
+template <int C, int HID>
+static int proj_bwd_launch_mo(hipStream_t st, int grid, const ProjBwdArgs& a) {
+  constexpr int NCO = PROJ_MAXCO, pitch = 132;          // mirrors the constexpr W1LDS / DBUF choices of k_proj_bwd
+  const size_t small = ((size_t)NCO * 128 + HID + NCO * HID) * 4;
+  const size_t w1b = (size_t)HID * (C + 1) * 4;
+  const bool w1lds = (size_t)(C + 64) * pitch * 4 + small + w1b <= 160 * 1024;
+  const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + (w1lds ? w1b : 0) <= 160 * 1024;
+  const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + (w1lds ? w1b : 0);
+  return launch("k_proj_bwd", k_proj_bwd<C, HID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+}
 static int proj_act_check(int hidden, int act) {
   if (act != FNO_ACT_GELU && act != FNO_ACT_RELU) return fail(FNO_EINVAL, "projection: hidden_act %d (FNO_ACT_GELU or FNO_ACT_RELU)", act);
   if (act == FNO_ACT_RELU && hidden != 256) return fail(FNO_EUNSUPPORTED, "projection: the ReLU head is built for hidden width 256 (got %d)", hidden);
@@ -2193,10 +2211,15 @@ extern "C" int fno_projection_forward_act(int B, int C, int hidden, int Cout, si
   if (!x || !w1 || !b1 || !w2 || !b2 || !y) return fail(FNO_EINVAL, "fno_projection_forward: null argument");
   ProjFwdArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.x = x; pa.w1 = w1; pa.b1 = b1; pa.w2 = w2; pa.b2 = b2; pa.y = y; pa.PW = (int)PW; pa.CO = 1;
+  pa.x = x; pa.w1 = w1; pa.b1 = b1; pa.w2 = w2; pa.b2 = b2; pa.y = y; pa.PW = (int)PW; pa.CO = Cout;
   pa.tiles_per_plane = (int)(PW / 128); pa.ntiles = B * pa.tiles_per_plane;
   const int grid = std::min(pa.ntiles, FNO_GRID_PF * dev_ncu());
   hipStream_t st = (hipStream_t)stream;
+  if (Cout > 1) {
+    if (hidden_act != FNO_ACT_GELU) return fail(FNO_EUNSUPPORTED, "projection: several output channels with the GELU head only");
+    if (C == 32) return hidden == 128 ? proj_fwd_launch_mo<32, 128>(st, grid, pa) : proj_fwd_launch_mo<32, 256>(st, grid, pa);
+    return hidden == 128 ? proj_fwd_launch_mo<64, 128>(st, grid, pa) : proj_fwd_launch_mo<64, 256>(st, grid, pa);
+  }
   if (hidden_act == FNO_ACT_RELU) return C == 32 ? proj_fwd_launch<32, 256, true>(st, grid, pa) : proj_fwd_launch<64, 256, true>(st, grid, pa);
   if (C == 32) return hidden == 128 ? proj_fwd_launch<32, 128, false>(st, grid, pa) : proj_fwd_launch<32, 256, false>(st, grid, pa);
   return hidden == 128 ? proj_fwd_launch<64, 128, false>(st, grid, pa) : proj_fwd_launch<64, 256, false>(st, grid, pa);
@@ -2216,23 +2239,29 @@ extern "C" int fno_projection_backward_act(int B, int C, int hidden, int Cout, s
   ProjWs w = carve_proj(C, hidden, ws, ws_bytes);
   if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  LAUNCHCHK(pack_w1_x3(st, w1, w.wa1, w.wa3, hidden, C, use_pbwd_t(C, 1, 128)));
+  if (Cout == 1) LAUNCHCHK(pack_w1_x3(st, w1, w.wa1, w.wa3, hidden, C, use_pbwd_t(C, 1, 128)));
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
-  pb.x = x; pb.dy = dy; pb.w1 = w1; pb.b1 = b1; pb.w2 = w2; pb.gout = dx; pb.wa1 = w.wa1; pb.wa3 = w.wa3;
+  pb.x = x; pb.dy = dy; pb.w1 = w1; pb.b1 = b1; pb.w2 = w2; pb.gout = dx;
+  if (Cout == 1) { pb.wa1 = w.wa1; pb.wa3 = w.wa3; }
   pb.dw1_part = w.dw1_part; pb.db1_part = w.db1_part; pb.dw2_part = w.dw2_part;
-  pb.PW = (int)PW; pb.W = 128; pb.P = (int)(PW / 128); pb.CO = 1;
+  pb.PW = (int)PW; pb.W = 128; pb.P = (int)(PW / 128); pb.CO = Cout;
   pb.tiles_per_plane = (int)(PW / 128); pb.ntiles = B * pb.tiles_per_plane;
   const int grid = std::min(pb.ntiles, FNO_GRID_BWD * dev_ncu());
+  if (Cout > 1) {
+    if (hidden_act != FNO_ACT_GELU) return fail(FNO_EUNSUPPORTED, "projection: several output channels with the GELU head only");
+    if (C == 32) LAUNCHCHK((hidden == 128 ? proj_bwd_launch_mo<32, 128>(st, grid, pb) : proj_bwd_launch_mo<32, 256>(st, grid, pb)));
+    else LAUNCHCHK((hidden == 128 ? proj_bwd_launch_mo<64, 128>(st, grid, pb) : proj_bwd_launch_mo<64, 256>(st, grid, pb)));
+  } else
   if (hidden_act == FNO_ACT_RELU) LAUNCHCHK((C == 32 ? proj_bwd_launch<32, 256, true>(st, grid, pb) : proj_bwd_launch<64, 256, true>(st, grid, pb)));
   else if (C == 32) LAUNCHCHK((hidden == 128 ? proj_bwd_launch<32, 128, false>(st, grid, pb) : proj_bwd_launch<32, 256, false>(st, grid, pb)));
   else LAUNCHCHK((hidden == 128 ? proj_bwd_launch<64, 128, false>(st, grid, pb) : proj_bwd_launch<64, 256, false>(st, grid, pb)));
-  LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, 1), dim3(256), 0, st, dy, w.db2_part, B, 1, (int)PW));
+  LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, Cout), dim3(256), 0, st, dy, w.db2_part, B, Cout, (int)PW));
   JobList jobs;
   jobs.add(w.dw1_part, dw1, grid, hidden, C, C, C);
   jobs.add(w.db1_part, db1, grid * 4, 1, hidden, hidden, hidden);
-  jobs.add(w.dw2_part, dw2, grid * 4, 1, hidden, hidden, hidden);
-  jobs.add(w.db2_part, db2, 64, 1, 1, 1, 1);
+  jobs.add(w.dw2_part, dw2, grid * 4, Cout, hidden, hidden, hidden);
+  jobs.add(w.db2_part, db2, 64, 1, Cout, Cout, Cout);
   return jobs.run(st);
 }
 extern "C" int fno_projection_backward(int B, int C, int hidden, int Cout, size_t PW, const float* x, const float* w1,

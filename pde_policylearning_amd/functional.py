@@ -1134,8 +1134,12 @@ def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=F
 # ----------------------------------------------------------------------------
 # projection head  y = W2 gelu(W1 x + b1) + b2  on (B, C, ...) tensors
 # ----------------------------------------------------------------------------
+PROJ_MAXCO = 4        # k_projection.h
+
+
 def projection_supported(x, hidden, cout, act="gelu"):
-    return (pointwise_supported(x) and hidden in ((128, 256) if act == "gelu" else (256,)) and cout == 1
+    return (pointwise_supported(x) and hidden in ((128, 256) if act == "gelu" else (256,))
+            and (cout == 1 or (act == "gelu" and 1 <= cout <= PROJ_MAXCO))
             and act in _ACT_CODES and _lib.lib().fno_get_gemm_mode() == 1)
 
 
@@ -1149,38 +1153,39 @@ class _ProjectionHeadFn(torch.autograd.Function):
         x = x.contiguous()
         B, Cc = x.shape[0], x.shape[1]
         pw = x.numel() // (B * Cc)
-        hid = w1.shape[0]
+        hid, co = w1.shape[0], w2.shape[0]
         w1c, b1c = w1.reshape(hid, Cc).contiguous(), b1.contiguous()
-        w2c, b2c = w2.reshape(1, hid).contiguous(), b2.contiguous()
-        y = torch.empty((B, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        w2c, b2c = w2.reshape(co, hid).contiguous(), b2.contiguous()
+        y = torch.empty((B, co) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().fno_projection_forward_act(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c),
+            _lib.check(_lib.lib().fno_projection_forward_act(B, Cc, hid, co, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c),
                                                              _ptr(b2c), act, _ptr(y), _stream()), "projection_forward")
         ctx.save_for_backward(x, w1c, b1c, w2c)
-        ctx.meta = (B, Cc, hid, pw, w1.shape, w2.shape, act)
+        ctx.meta = (B, Cc, hid, pw, w1.shape, w2.shape, act, co)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1c, b1c, w2c = ctx.saved_tensors
-        B, Cc, hid, pw, w1shape, w2shape, act = ctx.meta
+        B, Cc, hid, pw, w1shape, w2shape, act, co = ctx.meta
         L = _lib.lib()
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dw1, db1, dw2 = torch.empty_like(w1c), torch.empty_like(b1c), torch.empty_like(w2c)
-        db2 = torch.empty(1, dtype=torch.float32, device=x.device)
+        db2 = torch.empty(co, dtype=torch.float32, device=x.device)
         nws = L.fno_projection_workspace_bytes(Cc, hid)
         ws = _bytes(nws, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.fno_projection_backward_act(B, Cc, hid, 1, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(dy), act,
+            _lib.check(L.fno_projection_backward_act(B, Cc, hid, co, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(dy), act,
                                                      _ptr(dx), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nws,
                                                      _stream()), "projection_backward")
         return dx, dw1.view(w1shape), db1, dw2.view(w2shape), db2, None
 
 
 def projection_head(x, w1, b1, w2, b2, act="gelu"):
-    """(B, C, ...) -> (B, 1, ...): fc2(act(fc1(x))) with fc1.weight (hidden, C), fc2.weight (1, hidden); act 'gelu'
-    (FNO projection, PINO observer tails) or 'relu' (RNO2d's regressor head, rno.py:171-175; hidden 256)."""
+    """(B, C, ...) -> (B, Cout, ...): fc2(act(fc1(x))) with fc1.weight (hidden, C), fc2.weight (Cout, hidden); act 'gelu'
+    (FNO projection, PINO observer tails; Cout <= 4: PlanePredHead's out_dim * plane_num, pinobserver.py:257-273) or 'relu'
+    (RNO2d's regressor head, rno.py:171-175; hidden 256, Cout 1)."""
     return _ProjectionHeadFn.apply(x, w1, b1, w2, b2, _ACT_CODES[act])
 
 

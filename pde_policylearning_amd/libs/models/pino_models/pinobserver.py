@@ -217,8 +217,18 @@ class PlanePredHead(_SpectralStack):
         self.act = _activation(act)
 
     def forward(self, x, num_pad, re, multiplicative_net2):
-        x = _unpad_last(self._run_stack(x), num_pad).permute(0, 2, 3, 4, 1)
-        x = multiplicative_net2(x, re)
+        x = _unpad_last(self._run_stack(x), num_pad)
+        if (self.act is TF.gelu and self.layers[-1] in (32, 64) and not getattr(self, "no_engine_tail", False)
+                and F.projection_supported(x, self.fc1.out_features, self.fc2.out_features)):
+            # channels-first tail on the engine (as PINObserver2d's): the Re-conditioning affine as a pointwise mix with the
+            # per-sample code added, then fc1 -> GELU -> fc2 for all planes in the projection kernels (hidden tensor never
+            # materialised; pinobserver.py:257-273)
+            mn = multiplicative_net2
+            code = (re if re.dim() >= 2 else re.unsqueeze(-1)) @ mn.A.t()                     # (B, C)
+            h = F.pointwise_conv_add(x.contiguous(), mn.B, mn.bias, None) + code[:, :, None, None, None]
+            y = F.projection_head(h, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+            return y.permute(0, 2, 3, 4, 1)
+        x = multiplicative_net2(x.permute(0, 2, 3, 4, 1), re)
         return self.fc2(self.act(self.fc1(x)))
 
 

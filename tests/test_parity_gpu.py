@@ -539,6 +539,45 @@ def test_pinobserver_fullfield_module_golden(dev):
     _check_module_grads(model, g)
 
 
+@pytest.mark.parametrize("planes,fc_dim", [(3, 128), (2, 256), (4, 128)])
+def test_pinobserver_fullfield_engine_head_vs_oracle(dev, planes, fc_dim):
+    """PINObserverFullField at the widths of the shipped configuration (64 channels, fc_dim 128, three planes): the multi-plane
+    head (pinobserver.py:257-273: Re-conditioning affine, fc1 -> GELU -> fc2 for all planes) runs on the engine's pointwise and
+    projection kernels (2..4 output channels); output and every parameter gradient against the CPU oracle (pinned by the
+    reference-generated pino_fullfield_small golden)."""
+    from oracle import observers_oracle as OO
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.libs.models.pino_models import PINObserverFullField
+    torch.manual_seed(7)
+    model = PINObserverFullField(plane_num=planes, modes1=[4] * 4, modes2=[4] * 4, modes3=[4] * 4, fc_dim=fc_dim,
+                                 layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625])
+    x = torch.from_numpy(fill_named("ffh.x", (4, 32, 32, 1, 1), 1.0))
+    re = torch.tensor([[120.0], [180.0], [150.0], [199.0]])
+    pc = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    yc = OO.pinobserver_fullfield_forward(pc, x, re, [64] * 5, [(4, 4, 4)] * 4, [0.0, 0.0625])
+    tgt = torch.from_numpy(fill_named("ffh.t", tuple(yc.shape), 1.0))
+    O.lp_loss_rel_sum(yc, tgt).backward()
+    model = model.to(dev)
+    calls = {"proj": 0}
+    orig = F.projection_head
+    def spy(*a, **k):
+        calls["proj"] += 1
+        return orig(*a, **k)
+    F.projection_head = spy
+    try:
+        y = model(x.to(dev), re.to(dev))
+    finally:
+        F.projection_head = orig
+    assert calls["proj"] == 1
+    assert tuple(y.shape) == tuple(yc.shape)
+    assert rel_l2(_cpu(y), yc.detach().numpy()) < TOL_Y
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    for name, prm in model.named_parameters():
+        ref = pc[name].grad
+        assert rel_l2(_cpu(torch.view_as_real(prm.grad) if prm.grad.is_complex() else prm.grad),
+                      (torch.view_as_real(ref) if ref.is_complex() else ref).numpy()) < TOL_G, name
+
+
 def test_pinobserver2d_module_golden(dev):
     from pde_policylearning_amd.libs.models.pino_models import PINObserver2d
     g = load_golden("pino2d_small")

@@ -1,5 +1,5 @@
 """Which torch (non-engine) GPU kernels an observer training step still launches, by aten op and input shape.
-usage (GPU box): python tools/torch_ops.py [rno2d|rno2d_shipped]"""
+usage (GPU box): python tools/torch_ops.py [rno2d|rno2d_shipped|pino_ff|pino2d]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,14 +9,32 @@ from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
 kind = sys.argv[1] if len(sys.argv) > 1 else "rno2d"
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-width, (X, Y), B = (64, (128, 128), 32) if kind == "rno2d" else (34, (32, 32), 32)
-model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82 (bench.py's workload)
-x = torch.randn(B, 1, X, Y, 1, device=dev)
-tgt = torch.randn(B, X, Y, 1, device=dev)
-bucket = trainer.FlatGradBucket(model.parameters())
+gen = torch.Generator().manual_seed(0)
+if kind.startswith("rno2d"):
+    width, (X, Y), B = (64, (128, 128), 32) if kind == "rno2d" else (34, (32, 32), 32)
+    model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82 (bench.py's workload)
+    inputs = (torch.randn(B, 1, X, Y, 1, device=dev),)
+    tgt = torch.randn(B, X, Y, 1, device=dev)
+else:
+    from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
+    if kind == "pino_ff":                                                  # bench.py: pino_fullfield_32x32_w64_m12_b32
+        B = 32
+        model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
+                                     layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+        x = torch.randn(B, 32, 32, 1, 1, device=dev)
+    else:                                                                  # bench.py: pinobserver2d_128x128x65_w64_m8_b2
+        B = 2
+        model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+                              out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)
+        x = torch.randn(B, 128, 128, 65, 4, device=dev)
+    re = (torch.rand(B, 1) * 100 + 100).to(dev)
+    inputs = (x, re)
+    with torch.no_grad():
+        tgt = torch.randn(model(*inputs).shape, device=dev)
+bucket = trainer.FlatGradBucket(model.parameters(), direct_module=None if kind.startswith("rno2d") else model)
 opt = trainer.FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
 loss_fn = trainer.FusedLpLoss(size_average=False)
-step = lambda: trainer.train_step(model, bucket, opt, (x,), tgt, loss_fn)
+step = lambda: trainer.train_step(model, bucket, opt, inputs, tgt, loss_fn)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
