@@ -453,7 +453,7 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
     const dim3 grid(Ktot, (B + 63) / 64, nm), blk(2 * (2 * Cout / 32) * 64);
-    const size_t lds = ((size_t)64 * (2 * Cin + 1) + (size_t)2 * Cin * (2 * Cout + 32)) * 4 + (trans_w ? (size_t)Cout * (Cin + 1) * 8 : 0);
+    const size_t lds = (size_t)64 * (2 * Cin + 1) * 4 + (size_t)std::max(Cin * (Cout + 1), Cout * (Cin + 1)) * 8;      // spectra + the complex weight block
     const float2 *xx = (const float2*)x, *ww = (const float2*)w;
     float2* oo = (float2*)out;
     if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(512) k_mode_gemm_dw_lds(const float2* __restri
 // 64 batch rows; the expanded real weight block and the spectra are staged once in LDS (weight rows padded by 32 floats so
 // that the two lane halves, which read adjacent k rows, fall on disjoint banks; spectrum rows by 1 float for the
 // row-per-lane A reads).  Wave (mt, nt): batch rows [32 mt, +32), real output columns [32 nt, +32).
-//   grid (Ktot, ceil(B / 64)), block 2 * (2 CO / 32) waves, LDS 64 (2 CI + 1) + 2 CI (2 CO + 32) floats
+//   grid (Ktot, ceil(B / 64)), block 2 * (2 CO / 32) waves, LDS 64 (2 CI + 1) floats + max(CI (CO + 1), CO (CI + 1)) float2
 template <int CI, int CO>
 __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
                                                                            const float2* __restrict__ w,
@@ -459,10 +459,14 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
   // (out[b][n] = sum_m x[b][m] w[n][m]): the adjoint reads the forward's packed weights, no transposed copy exists
   // blockIdx.z = member of a batch of independent contractions (fan-outs); *_ms = member strides in float2 (0: shared)
   x += blockIdx.z * x_ms; w += blockIdx.z * w_ms; out += blockIdx.z * o_ms;
-  constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1, PB = 2 * CO + 32;
+  // The weight block stays COMPLEX in LDS (rows padded by one float2) and the real operand [[wr wi], [-wi wr]] is formed
+  // per lane while it is read: 33 KB instead of the 80 KB expanded block, so two workgroups share a CU (the launch is
+  // bound by staging latency, not arithmetic: 28 -> 16 us for the RNO cell's batched contractions).
+  constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1;
+  constexpr int PW_N = CO + 1, PW_T = CI + 1;         // row pitch (float2) of the stored block: (CI, CO) or, trans_w, (CO, CI)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                 // [64][PA]
-  float* ws = smem + 64 * PA;       // [2 CI][PB]
+  float* xs = smem;                                              // [64][PA]
+  float2* wc = reinterpret_cast<float2*>(smem + 64 * PA);        // (64 * PA floats: 8-byte aligned)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int mt = wave / NTN, nt = wave % NTN;
@@ -471,28 +475,9 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
   const float sg = conj_w ? -1.f : 1.f;
   const float2* wk = w + (size_t)k * CI * CO;
   if (trans_w) {
-    // the stored matrix is (CO, CI): a coalesced copy into a padded LDS tile first, then the expanding transpose with
-    // consecutive lanes on consecutive output columns (a direct scatter would put a whole wave on one LDS bank)
-    float2* raw = reinterpret_cast<float2*>(ws + 2 * CI * PB);      // [CO][CI + 1]
-    for (int i = tid; i < CI * CO; i += NT) raw[(i / CI) * (CI + 1) + i % CI] = wk[i];
-    __syncthreads();
-    for (int i = tid; i < CI * CO; i += NT) {
-      const int o = i % CO, ci = i / CO;
-      float2 v = raw[o * (CI + 1) + ci];
-      v.y *= sg;
-      float* r0 = ws + (2 * ci) * PB + 2 * o;
-      r0[0] = v.x; r0[1] = v.y;
-      r0[PB] = -v.y; r0[PB + 1] = v.x;
-    }
+    for (int i = tid; i < CI * CO; i += NT) wc[(i / CI) * PW_T + i % CI] = wk[i];      // stored (CO, CI): row = output channel
   } else {
-    for (int i = tid; i < CI * CO; i += NT) {
-      const int ci = i / CO, o = i % CO;
-      float2 v = wk[i];
-      v.y *= sg;
-      float* r0 = ws + (2 * ci) * PB + 2 * o;
-      r0[0] = v.x; r0[1] = v.y;
-      r0[PB] = -v.y; r0[PB + 1] = v.x;
-    }
+    for (int i = tid; i < CI * CO; i += NT) wc[(i / CO) * PW_N + i % CO] = wk[i];      // stored (CI, CO): row = input channel
   }
   for (int i = tid; i < 64 * CI; i += NT) {
     const int bb = i / CI, ci = i % CI;
@@ -505,9 +490,17 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* ap = xs + (mt * 32 + l31) * PA + half;
-  const float* bp = ws + half * PB + nt * 32 + l31;
+  // this lane's real output column n = 2 o + c and k row 2 s + half:  half 0: (wr, wi)_c,  half 1: (-wi, wr)_c
+  const int n = nt * 32 + l31, o = n >> 1, c = n & 1;
+  const float2* wp = trans_w ? wc + o * PW_T : wc + o;
+  const int wstep = trans_w ? 1 : PW_N;
+  const bool pick_y = (c ^ half) != 0;                  // the imaginary part feeds (half 0, c 1) and (half 1, c 0)
+  const float sgn = pick_y ? (half ? -sg : sg) : 1.f;
 #pragma unroll 8
-  for (int s = 0; s < CI; ++s) acc = mfma32(ap[2 * s], bp[(2 * s) * PB], acc);
+  for (int s = 0; s < CI; ++s) {
+    const float2 wv = wp[s * wstep];
+    acc = mfma32(ap[2 * s], (pick_y ? wv.y : wv.x) * sgn, acc);
+  }
   float* op = reinterpret_cast<float*>(out);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
