@@ -1326,6 +1326,14 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    static const int lift_dft_lin = getenv("FNO_NO_LIFT_ROWDFT") ? 0 : 1;      // A/B switch
+    const size_t lds_lr = ((size_t)2 * g.Klast * (g.W + 1) + (size_t)LR_ROWS * d.Cin * (g.W + 1) + 2) * 4 + (size_t)LR_ROWS * g.Klast * (d.Cin + 1) * 8;
+    if (lift_dft_lin && p->u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
+      // u_0 is never stored: only its row spectra are needed, and those are linear in the <= 4 input channels
+      const int nrows = B * g.P;
+      LAUNCHCHK(launch("k_lift_rowdft", k_lift_rowdft, dim3((nrows + LR_ROWS - 1) / LR_ROWS), dim3(256), lds_lr, st, x,
+                       prm->lift_w, prm->lift_b, p->t.tfwd_f, (float2*)w.x1, d.Cin, C, g.PW, g.W, g.P, g.Klast, nrows));
+    } else
     LAUNCHCHK(launch_lift(p, st, std::min(s.ntiles, FNO_GRID_LIFT * p->ncu), a));
     if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, u, w.x1));   // no epilogue on loose rows
   } else if (tail && tail->drop_p > 0.f) {

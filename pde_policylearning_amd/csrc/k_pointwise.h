@@ -409,3 +409,73 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     tslot += 8;
   }
 }
+
+// ---------------------------------------------------------------------------
+// Row spectra of the lifting output WITHOUT the lifting output: x1 = rowDFT(W_l x + b_l) is linear in x, so
+//   x1[b, row, k2, c] = sum_k W_l[c][k] * rowDFT(x_k)[row, k2] + b_l[c] * sum_w T[k2][w]
+// needs the truncated DFT of the <= 4 input channels only (the fused block 0 recomputes u_0 itself and never reads it:
+// k_pw_fwd_x3<.., LIFT>).  The tile kernel it replaces transformed all C channels on the fp32 matrix pipe: 52 us at BASELINE
+// config 2 for 12.6 MB in and 25 MB out; this one is a streaming pass.
+//   block 256, one workgroup per LR_ROWS rows of W pixels; LDS: table 2 K2 x W, LR_ROWS x CL x W inputs, spectra
+constexpr int LR_ROWS = 8;
+__global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x, const float* __restrict__ lw,
+                                                     const float* __restrict__ lb, const float* __restrict__ tfwd,
+                                                     float2* __restrict__ x1, int CL, int C, int PW, int W, int P, int K2,
+                                                     int nrows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int WP = W + 1;                               // row pitch: threads of a wave read different rows at the same w
+  float* ts = smem;                                   // [2 K2][WP]
+  float* xs = ts + 2 * K2 * WP;                       // [LR_ROWS][CL][WP]
+  float2* xh = reinterpret_cast<float2*>(xs + ((LR_ROWS * CL * WP + 1) & ~1));     // [LR_ROWS][K2][CL + 1]: spectra; entry CL = sum of the table row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * LR_ROWS;              // rows are (b, prow) pairs, b-major
+  const int nr = min(LR_ROWS, nrows - row0);
+  // (loops over whole rows per wave: no per-element index divisions)
+  for (int j = wave; j < 2 * K2; j += 4)
+    for (int w = lane; w < W; w += 64) ts[j * WP + w] = tfwd[j * W + w];
+  for (int rk = wave; rk < LR_ROWS * CL; rk += 4) {
+    const int r = rk / CL, k = rk - r * CL;
+    const int row = row0 + r;
+    const int b = row / P, prow = row - b * P;
+    const float* src = x + ((size_t)b * CL + k) * PW + (size_t)prow * W;
+    for (int w = lane; w < W; w += 64) xs[rk * WP + w] = r < nr ? src[w] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < LR_ROWS * K2 * (CL + 1); i += 256) {
+    const int r = i / (K2 * (CL + 1)), k2 = (i / (CL + 1)) % K2, k = i % (CL + 1);
+    const float* tr = ts + (2 * k2) * WP;
+    const float* ti = tr + WP;
+    float sr = 0.f, si = 0.f;
+    if (k < CL) {
+      const float* xr = xs + (r * CL + k) * WP;
+      float sr2 = 0.f, si2 = 0.f;                       // two chains: the sums are latency-bound otherwise
+#pragma unroll 8
+      for (int w = 0; w < W; w += 2) {
+        sr = fmaf(xr[w], tr[w], sr); si = fmaf(xr[w], ti[w], si);
+        if (w + 1 < W) { sr2 = fmaf(xr[w + 1], tr[w + 1], sr2); si2 = fmaf(xr[w + 1], ti[w + 1], si2); }
+      }
+      sr += sr2; si += si2;
+    } else {
+      for (int w = 0; w < W; ++w) { sr += tr[w]; si += ti[w]; }
+    }
+    xh[i] = make_float2(sr, si);
+  }
+  __syncthreads();
+  // lane <-> channel (two channels per lane pair of passes when C > 64 never happens: C is 32 or 64); a wave per (row, bin)
+  const int c = lane;
+  if (c < C) {
+    float wv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[k] = k < CL ? lw[c * CL + k] : 0.f;
+    const float bc = lb ? lb[c] : 0.f;
+    float2* dst = x1 + (size_t)row0 * K2 * C + c;
+    for (int p = wave; p < nr * K2; p += 4) {           // p = r * K2 + k2
+      const float2* h = xh + p * (CL + 1);
+      float sr = bc * h[CL].x, si = bc * h[CL].y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < CL) { sr = fmaf(wv[k], h[k].x, sr); si = fmaf(wv[k], h[k].y, si); }
+      dst[(size_t)p * C] = make_float2(sr, si);
+    }
+  }
+}
