@@ -559,8 +559,16 @@ class GraphedTrainStep(object):
         with torch.cuda.graph(self.graph):
             self.loss = train_step(model_fn, bucket, opt, self.inputs, self.target, loss_fn, decoder)
         opt.step_count = host_step            # capture enqueued nothing
+        # lr / betas / eps / weight decay are launch arguments of the captured Adam kernel: a scheduler that changes them
+        # afterwards would be ignored silently on replay
+        self._opt = opt
+        self._hyper = (opt.lr, tuple(opt.betas), opt.eps, opt.weight_decay)
 
     def __call__(self, inputs=None, target=None):
+        if (self._opt.lr, tuple(self._opt.betas), self._opt.eps, self._opt.weight_decay) != self._hyper:
+            raise RuntimeError("GraphedTrainStep: the optimizer's lr / betas / eps / weight_decay changed after capture "
+                               f"({self._hyper} -> {(self._opt.lr, tuple(self._opt.betas), self._opt.eps, self._opt.weight_decay)}); "
+                               "they are baked into the captured launches - build a new GraphedTrainStep")
         if inputs is not None:
             for dst, src in zip(self.inputs, inputs):
                 if dst.data_ptr() != src.data_ptr():

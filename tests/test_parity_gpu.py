@@ -1166,6 +1166,9 @@ def test_graphed_train_step_equals_eager(dev):
         assert float(l1) == float(l2), i
     assert torch.equal(o1.flat_param, o2.flat_param)
     assert all(int(st["step"]) == 4 for st in o2.state_dict()["state"].values())      # device-side step counter
+    o2.lr = 5e-4            # a scheduler step after capture: the captured launches carry the old rate - refused, not ignored
+    with pytest.raises(RuntimeError, match="changed after capture"):
+        step2()
 
 
 def test_rno_gates_match_torch_formulas(dev):
