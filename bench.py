@@ -226,7 +226,9 @@ def main():
         bucket = FlatGradBucket.for_fno(model, split_layer=1)
     else:
         # fused FNO: every gradient is written in place; PINO observers: their spectral weights (> 99 % of the bytes) are
-        bucket = FlatGradBucket(model.parameters(), direct_module=model if fused_model or cfg["kind"].startswith("pino") else None)
+        # RNO2d: its spectral weights too, while the sequence is one time step long (functional.single_use decides per call;
+        # the bucket is cleared in full so that the accumulating fallback starts from zeros)
+        bucket = FlatGradBucket(model.parameters(), direct_module=model, zero_all=cfg["kind"].startswith("rno2d"))
     bucket.force_collective = force_dist
     if not fused_model:
         # layer-ordered segments go on the wire as their gradients complete; dead last-dim slices of the dialect-C weights

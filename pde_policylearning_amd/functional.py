@@ -61,6 +61,32 @@ def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, in
 DIRECT_WRITE_HOOKS = []
 
 
+# Direct gradient writes are valid only when a parameter is used by exactly ONE engine call per step.  Models whose
+# parameters may be reused (RNO2d over several time steps / predicted steps) run their forward under single_use(flag): with
+# the flag off, `direct_grads` requests inside are ignored and autograd accumulates as usual (the bucket is zeroed in full
+# for such models: FlatGradBucket(direct_module=..., zero_all=True)).
+_SINGLE_USE = [True]
+
+
+class single_use(object):
+    def __init__(self, ok):
+        self.ok = bool(ok)
+
+    def __enter__(self):
+        _SINGLE_USE.append(self.ok)
+
+    def __exit__(self, *exc):
+        _SINGLE_USE.pop()
+
+
+def _direct_views(direct_grads, spec_ws):
+    """the weights' own .grad storage as real views, or None when direct writes are off / not possible"""
+    if not (direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled()
+            and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws)):
+        return None
+    return [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
+
+
 def _notify_direct(tensors):
     for h in DIRECT_WRITE_HOOKS:
         h(tensors)
@@ -133,7 +159,7 @@ def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=N
     wle = int(weight_last_extent) if weight_last_extent is not None else int(ws[0].shape[-2])
     b = bias.reshape(-1) if bias is not None else None
     direct = None
-    if direct_grads and torch.is_grad_enabled() and all(w.grad is not None and w.grad.is_contiguous() for w in weights):
+    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(w.grad is not None and w.grad.is_contiguous() for w in weights):
         direct = [torch.view_as_real(w.grad) if w.grad.is_complex() else w.grad for w in weights]
     return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, direct, *ws)
 
@@ -516,9 +542,7 @@ def fno_block_tail(x, skip_w, spec_ws, bias, modes, norm, relu_out=True, drop_p=
     derivative, the dropout mask (regenerated in the backward) and the accumulation of the two branches' input gradients
     all happen inside the engine kernels (fno_model_forward_tail / fno_model_backward_tail)."""
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_ws]
-    direct = None
-    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws):
-        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
+    direct = _direct_views(direct_grads, spec_ws)
     if drop_p > 0 and seed is None:
         raise ValueError("fno_block_tail: drop_p > 0 needs a seed (draw_dropout_seed)")
     cfg = (1, tuple(int(m) for m in modes), norm, 0, direct, (bool(relu_out), float(drop_p), seed if drop_p > 0 else None))
@@ -531,9 +555,7 @@ def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0, direct_grads
     (`skip_ws[l]`, (C, C) or (C, C, 1..)) and one bias row of `bias` (L, C); GELU after layer l iff bit l
     of `gelu_mask`.  Returns (B, C, ...); differentiable w.r.t. x and every parameter."""
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_ws]
-    direct = None       # direct_grads: backward WRITES dL/dW of the spectral weights into their existing .grad storage
-    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws):
-        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
+    direct = _direct_views(direct_grads, spec_ws)       # backward WRITES dL/dW of the spectral weights into their existing .grad storage
     cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
     return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *sw)
 
@@ -549,7 +571,8 @@ class _FourierFanoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, *rest):
-        n, modes, norm = cfg
+        n, modes, norm = cfg[:3]
+        ctx.direct = cfg[3] if len(cfg) > 3 else None
         _require_cuda(x, "x")
         x = x.contiguous()
         dims = tuple(x.shape[2:])
@@ -593,7 +616,7 @@ class _FourierFanoutFn(torch.autograd.Function):
         L = _lib.lib()
         prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
         g_skip = [torch.empty_like(t) for t in skip_ws]
-        g_spec = [torch.empty_like(t) for t in spec_ws]
+        g_spec = ctx.direct if ctx.direct is not None else [torch.empty_like(t) for t in spec_ws]     # direct: the weights' own .grad storage
         g_bias = [torch.empty(x.shape[1], dtype=torch.float32, device=x.device) for _ in range(n)]
         for j in range(n):
             prm.skip_w[j], grd.skip_w[j] = skip_ws[j].data_ptr(), g_skip[j].data_ptr()
@@ -608,7 +631,10 @@ class _FourierFanoutFn(torch.autograd.Function):
             _lib.check(L.fno_fanout_backward(ctx.plan, ctx.B, n, C.byref(prm), _ptr(x), dyptr, _ptr(saved), C.byref(grd), dbptr,
                                              _ptr(dx), _ptr(ws), nws, _stream()), "fanout_backward")
         g_bias = [g.view(sh) for g, sh in zip(g_bias, ctx.bias_shapes)]
-        return (None, dx if ctx.needs_input_grad[1] else None) + tuple(g_skip) + tuple(g_bias) + tuple(g_spec)
+        if ctx.direct is not None:
+            _notify_direct(ctx.direct)
+        return ((None, dx if ctx.needs_input_grad[1] else None) + tuple(g_skip) + tuple(g_bias)
+                + ((None,) * len(g_spec) if ctx.direct is not None else tuple(g_spec)))
 
 
 def fanout_supported(x, n, modes, norm):
@@ -618,12 +644,12 @@ def fanout_supported(x, n, modes, norm):
                                 norm, 0, x.device)
 
 
-def fourier_fanout(x, skip_ws, biases, spec_ws, modes, norm):
+def fourier_fanout(x, skip_ws, biases, spec_ws, modes, norm, direct_grads=False):
     """[SpecConv_j(x) + conv1x1(x; skip_ws[j]) + biases[j] for j < n]: n <= 4 Fourier layers (rno.py:215-228) on ONE input,
     whose forward transforms run once and whose input gradients are summed inside the backward kernels
     (include/fnoengine.h, fno_fanout_*).  spec_ws is member-major: member j's corner weights at [j * ncorner, (j+1) * ncorner)."""
     n = len(skip_ws)
-    cfg = (n, tuple(int(m) for m in modes), norm)
+    cfg = (n, tuple(int(m) for m in modes), norm, _direct_views(direct_grads, spec_ws))
     return _FourierFanoutFn.apply(cfg, x, *skip_ws, *biases, *spec_ws)
 
 
@@ -1126,7 +1152,7 @@ def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=F
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_weights]
     wle = int(weight_last_extent) if weight_last_extent is not None else int(sw[0].shape[-2])
     direct = None
-    if direct_grads and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_weights):
+    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_weights):
         direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_weights]
     return _SpectralLayerFn.apply(u, w, bias, tuple(int(m) for m in modes), norm, wle, bool(input_gelu), direct, *sw)
 

@@ -26,11 +26,17 @@ class SpectralConv2d(nn.Module):
         for w in self.fourier_weight:
             nn.init.xavier_normal_(w, gain=gain)
 
+    def direct_grad_params(self):
+        """parameters whose gradient the engine may write straight into a trainer.FlatGradBucket - honoured only while the
+        enclosing model declares one use per step (functional.single_use; RNO2d.forward: one time step)"""
+        return list(self.fourier_weight)
+
     def forward(self, x):
         if x.shape[-1] != x.shape[-2]:
             raise RuntimeError("rno.SpectralConv2d transforms with s=(n, n), n = x.shape[-1] (rno.py:66-67): "
                                "square grids only")
-        return F.spectral_conv(x, list(self.fourier_weight), None, (self.modes1, self.modes2), self.norm)
+        return F.spectral_conv(x, list(self.fourier_weight), None, (self.modes1, self.modes2), self.norm,
+                               direct_grads=getattr(self, "_direct_grads", False))
 
 
 class SpectralConvWithFC(nn.Module):
@@ -71,7 +77,8 @@ class SpectralConvWithFC(nn.Module):
             p = self.dropout.p if self.training else 0.0
             seed = F.draw_dropout_seed(a.device) if p > 0 else None
             return F.fno_block_tail(a.contiguous(), self.linear.weight, list(sc.fourier_weight), self.linear.bias.view(1, -1),
-                                    (sc.modes1, sc.modes2), sc.norm, relu_out=relu, drop_p=p, seed=seed)
+                                    (sc.modes1, sc.modes2), sc.norm, relu_out=relu, drop_p=p, seed=seed,
+                                    direct_grads=getattr(sc, "_direct_grads", False))
         s = self.spec_conv(self.dropout(a))
         return self.activation(F.pointwise_conv_add(a, self.linear.weight, self.linear.bias, addend=s))
 
@@ -130,7 +137,7 @@ class FourierLayer2d(nn.Module):
             # one fused engine layer: spectral conv + Conv1d(k=1) + bias (fno_model_* block stack, L = 1)
             sc = self.spec_conv
             return F.fno_blocks(x, [self.norm_conv1d.weight], list(sc.fourier_weight), self.norm_conv1d.bias.view(1, c),
-                                (sc.modes1, sc.modes2), sc.norm)
+                                (sc.modes1, sc.modes2), sc.norm, direct_grads=getattr(sc, "_direct_grads", False))
         return self.spec_conv(x) + self.norm_conv1d(x.reshape(b, c, n1 * n2)).view(b, self.width, n1, n2)
 
 
@@ -150,7 +157,8 @@ class RNO_cell(nn.Module):
         layers' input gradients are summed inside the backward kernels."""
         sc = layers[0].spec_conv
         return F.fourier_fanout(t, [l.norm_conv1d.weight for l in layers], [l.norm_conv1d.bias for l in layers],
-                                [w for l in layers for w in l.spec_conv.fourier_weight], (sc.modes1, sc.modes2), sc.norm)
+                                [w for l in layers for w in l.spec_conv.fourier_weight], (sc.modes1, sc.modes2), sc.norm,
+                                direct_grads=all(getattr(l.spec_conv, "_direct_grads", False) for l in layers))
 
     def forward(self, x, h):
         sc = self.f1.spec_conv
@@ -300,7 +308,10 @@ class RNO2d(nn.Module):
             shapes = {k: v.shape for k, v in twin.named_parameters()}
             padded = {k: _pad_to(v, shapes[k]) for k, v in self.named_parameters()}
             return torch.func.functional_call(twin, padded, (x,), {"v_plane": v_plane, "timestep": timestep})
-        return self.predict(x, num_steps=x.shape[1])[:, self.recurrent_index]
+        # every parameter is used once per time step and per predicted step (both = x.shape[1]): gradients may be written in
+        # place only for a single step
+        with F.single_use(x.shape[1] == 1):
+            return self.predict(x, num_steps=x.shape[1])[:, self.recurrent_index]
 
     def count_params(self):
         return int(sum(p.numel() for p in self.parameters() if p.requires_grad))

@@ -126,7 +126,9 @@ def run(args, log=print):
     if fused and world > 1:
         bucket = FlatGradBucket.for_fno(model, split_layer=1)
     else:
-        bucket = FlatGradBucket(model.parameters(), direct_module=model if fused else None)
+        # RNO2d: the spectral weights' gradients are written in place while a step uses every parameter once (one time
+        # step: functional.single_use); cleared in full for the accumulating fallback
+        bucket = FlatGradBucket(model.parameters(), direct_module=model, zero_all=not fused)
         if world > 1:
             bucket.enable_segmented_exchange()       # RNO2d: 95 MB at width 64 leave in layer-ordered segments during backward
     opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)

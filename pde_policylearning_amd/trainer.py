@@ -172,12 +172,14 @@ class FlatGradBucket(object):
     the data-parallel exchange is a single all-reduce(SUM) - sized for xGMI: one 9.6 MB message
     for FNO2d(12,12,64) instead of ~30 small ones."""
 
-    def __init__(self, params, process_group=None, direct_module=None):
+    def __init__(self, params, process_group=None, direct_module=None, zero_all=False):
         """direct_module: a model whose engine calls may WRITE their gradients into the bucket (no autograd
         accumulation kernels, no zeroing); valid when every such parameter is used by exactly one engine call per
         step, as in the reference training steps.  A fused engine FNO covers all of its parameters; modules exposing
         `direct_grad_params()` (the PINO observers' spectral convolutions: > 99 % of their parameter bytes) cover those,
-        and the remaining parameters are laid out at the tail of the bucket, which is the only part zero() clears."""
+        and the remaining parameters are laid out at the tail of the bucket, which is the only part zero() clears.
+        zero_all: clear the whole bucket anyway - for models that fall back to autograd accumulation when a parameter
+        is used more than once in a step (RNO2d over several time steps: functional.single_use)."""
         self.direct_module = direct_module
         self.params = [p for p in params if p.requires_grad]
         self.user_order = list(self.params)       # the order an optimizer built on the same iterable would number them in
@@ -195,6 +197,8 @@ class FlatGradBucket(object):
                 self.params = [p for p in self.params if id(p) in direct_ids] + [p for p in self.params if id(p) not in direct_ids]
         n = sum(self._nfloat(p) for p in self.params)
         self._zero_from = sum(self._nfloat(p) for p in self.params if id(p) in direct_ids) if direct_module is not None else 0
+        if zero_all:
+            self._zero_from = 0
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         for p, v in zip(self.params, self.views(self.flat)):

@@ -1045,6 +1045,41 @@ def test_rno2d_regressor_train_mode_dropout(dev, engine_tail, shape, modes):
     assert rel_l2(_cpu(ye), _cpu(yr)) < TOL_COMP
 
 
+@pytest.mark.parametrize("steps", [1, 2])
+def test_rno2d_direct_gradient_writes_equal_autograd_accumulation(dev, steps):
+    """RNO2d's spectral weights in a FlatGradBucket(direct_module=model, zero_all=True): with ONE time step the engine writes
+    their gradients straight into the bucket (no autograd accumulation launches); with two, every parameter is used twice and
+    functional.single_use switches the same calls back to accumulation.  Both must equal the plain bucket bit for bit."""
+    import copy
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    torch.manual_seed(2)
+    m1 = RNO2dObserver(6, 6, 64, 0, layer_num=1).to(dev).eval()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(2, steps, 32, 32, 1, device=dev)
+    b1 = FlatGradBucket(m1.parameters(), direct_module=m1, zero_all=True)
+    b2 = FlatGradBucket(m2.parameters())
+    seen = []
+    F.DIRECT_WRITE_HOOKS.append(lambda tensors: seen.extend(tensors))
+    try:
+        for m, b in ((m1, b1), (m2, b2)):
+            b.zero()
+            m(x).square().sum().backward()
+    finally:
+        F.DIRECT_WRITE_HOOKS.pop()
+    n_spec = sum(1 for n, _ in m1.named_parameters() if "fourier_weight" in n)
+    assert len(seen) == (n_spec if steps == 1 else 0), (len(seen), n_spec)
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+    # a second step: the in-place writes overwrite, the accumulating paths start from the cleared bucket
+    for m, b in ((m1, b1), (m2, b2)):
+        b.zero()
+        m(0.5 * x).square().sum().backward()
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1.grad, p2.grad), n1
+
+
 def test_engine_dropout_scale_statistics(dev):
     """The counter-based dropout field (fno_dev.h: drop_scale): keep rate, independence of neighbouring elements and of the
     two seed words, reproducibility."""
