@@ -31,7 +31,7 @@ else:
     inputs = (x, re)
     with torch.no_grad():
         tgt = torch.randn(model(*inputs).shape, device=dev)
-bucket = trainer.FlatGradBucket(model.parameters(), direct_module=None if kind.startswith("rno2d") else model)
+bucket = trainer.FlatGradBucket(model.parameters(), direct_module=model, zero_all=kind.startswith("rno2d"))      # as bench.py
 opt = trainer.FusedAdam(bucket, lr=1e-3, weight_decay=1e-4)
 loss_fn = trainer.FusedLpLoss(size_average=False)
 step = lambda: trainer.train_step(model, bucket, opt, inputs, tgt, loss_fn)
