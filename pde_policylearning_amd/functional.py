@@ -66,6 +66,8 @@ DIRECT_WRITE_HOOKS = []
 # the flag off, `direct_grads` requests inside are ignored and autograd accumulates as usual (the bucket is zeroed in full
 # for such models: FlatGradBucket(direct_module=..., zero_all=True)).
 _SINGLE_USE = [True]
+LAST_FORWARD_SINGLE_USE = [True]       # what the most recent declaring forward said (read by the gradient buckets: a parameter
+                                       # used several times "arrives" several times, so segments must not leave early)
 
 
 class single_use(object):
@@ -74,6 +76,7 @@ class single_use(object):
 
     def __enter__(self):
         _SINGLE_USE.append(self.ok)
+        LAST_FORWARD_SINGLE_USE[0] = self.ok
 
     def __exit__(self, *exc):
         _SINGLE_USE.pop()

@@ -313,9 +313,13 @@ class FlatGradBucket(object):
                 self._arrived(p)
 
     def _arrived(self, p):
+        from . import functional as F
         sg = self._seg_of.get(id(p))
         if sg is None or sg["work"] is not None:
             return
+        if not F.LAST_FORWARD_SINGLE_USE[0]:
+            return      # parameters used several times per step (RNO2d over T > 1 steps) accumulate several times: the
+                        # first arrival is not the last - all_reduce() exchanges every segment after the backward pass
         sg["pending"].discard(id(p))
         if not sg["pending"] and self._collective_needed():
             self._launch(sg, async_op=True)

@@ -1473,6 +1473,47 @@ def test_backward_in_parts_equals_full_backward(dev):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("steps", [1, 2])
+def test_rno2d_segmented_exchange_with_direct_writes(dev, steps):
+    """RNO2d under the data-parallel bucket (in-place spectral-weight gradients + segmented, overlapped exchange; a 1-rank
+    RCCL group with the collective forced) leaves the plain bucket's gradients, for one time step (segments leave as the engine
+    reports its in-place writes) and for two (every parameter accumulates twice: no segment may leave early)."""
+    import copy
+    import torch.distributed as dist
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedLpLoss, train_step
+    torch.manual_seed(4)
+    m1 = RNO2dObserver(6, 6, 64, 0, layer_num=1).to(dev).eval()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(2, steps, 32, 32, 1, device=dev)
+    t = torch.randn(2, 32, 32, 1, device=dev)
+    b1 = FlatGradBucket(m1.parameters())
+    b2 = FlatGradBucket(m2.parameters(), direct_module=m2, zero_all=True)
+    started = False
+    if not dist.is_initialized():
+        import os, socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        started = True
+    b2.enable_segmented_exchange(min_bytes=1 << 20)
+    b2.force_collective = True
+    try:
+        for _ in range(2):
+            l1 = train_step(m1, b1, None, (x,), t, FusedLpLoss(size_average=False))
+            l2 = train_step(m2, b2, None, (x,), t, FusedLpLoss(size_average=False))
+            assert float(l1) == float(l2)
+            assert b2.wire_bytes_last == 4 * b2.flat.numel()            # every element went on the wire exactly once
+            g1 = {n: p.grad for n, p in m1.named_parameters()}
+            for n, p in m2.named_parameters():
+                assert torch.equal(p.grad, g1[n]), n
+    finally:
+        from pde_policylearning_amd import functional as F
+        F.DIRECT_WRITE_HOOKS.clear()
+        if started:
+            dist.destroy_process_group()
+
+
 def test_device_prefetcher_feeds_the_training_loop(dev, tmp_path):
     """trainer.DevicePrefetcher (pinned staging + copy stream, one batch ahead) over a DataLoader on the reference's on-disk
     plane format: same tensors as a synchronous `.cuda().float()`, every batch delivered once, usable by the engine."""
