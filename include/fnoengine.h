@@ -244,7 +244,8 @@ int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg,
  *   ||u_b(t = 0) - u0_b|| / ||u0_b||  (LpLoss(size_average=True).rel).
  * forward leaves the derived fields and per-sample coefficients in `ws` (fno_pino_loss_workspace_bytes);
  * backward writes du = g_ic * dloss_ic/du + g_f * dloss_f/du (device scalars, NULL = 1).
- * n must be 32, 64 or 128 (one plane per workgroup, in-LDS radix-2 FFTs).
+ * n must be 32, 64, 128 (one plane per workgroup, in-LDS radix-2 FFTs) or 256 (three slab passes each way, planes in
+ * chunks of 64: csrc/k_pino_loss2.h).
  * ---------------------------------------------------------------------- */
 size_t fno_pino_loss_workspace_bytes(int batch, int n, int nt);
 int fno_pino_loss_forward(int batch, int n, int nt, const float* u, const float* u0, const float* forcing,

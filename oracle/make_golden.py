@@ -565,6 +565,83 @@ def gen_chanflow(outdir):
         save(os.path.join(outdir, f"chanflow_{tag}.npz"), **out)
 
 
+def gen_options(outdir):
+    """Constructor options beside the accelerated configuration: separable weights, incremental
+    modes, output scaling (one convolution, and a block with its resampled skip), all on the dense weight container."""
+    from neuralop.models.spectral_convolution import FactorizedSpectralConv
+    from neuralop.models.fno_block import FNOBlocks
+    cases = {
+        # name: (cin, cout, n_modes, spatial, n_layers, fft_norm, batch, ctor options)
+        "A2d_separable": (4, 4, (6, 8), (16, 20), 2, "forward", 2, dict(separable=True)),
+        "A2d_incremental": (4, 6, (8, 8), (16, 16), 1, "forward", 2, dict(incremental_n_modes=(4, 6))),
+        "A2d_scaled": (3, 5, (6, 6), (12, 16), 2, "forward", 2, dict(output_scaling_factor=[2.0, 0.5])),
+        "A3d_separable": (3, 3, (4, 4, 4), (8, 8, 10), 1, "ortho", 2, dict(separable=True)),
+    }
+    for cname, (cin, cout, n_modes, sp, nl, norm, B, opts) in cases.items():
+        torch.manual_seed(0)
+        conv = FactorizedSpectralConv(cin, cout, n_modes, n_layers=nl, fft_norm=norm, factorization=None,
+                                      implementation="factorized", rank=1.0, **opts)
+        scales = refill_parameters(conv)
+        x = input_fill(cname + ".x", (B, cin, *sp)).requires_grad_(True)
+        idx = nl - 1
+        y = conv(x, idx)
+        dy = input_fill(cname + ".dy", tuple(y.shape))
+        y.backward(dy)
+        save(os.path.join(outdir, f"specconv_{cname}.npz"), x=x, dy=dy, y=y, dx=x.grad, grads=grads_of(conv),
+             scales=scales, meta=np.array([cin, cout, nl, idx, B, len(n_modes), *n_modes, *sp]), fft_norm=np.array(norm))
+    for cname, (sp, scale) in {"blocks2d_scaled": ((12, 16), [[1.5, 1.5], [0.5, 1.0]]),
+                               "blocks3d_scaled": ((8, 8, 8), [[1.5, 1.0, 1.0], [1.0, 1.0, 1.0]])}.items():
+        torch.manual_seed(0)
+        n_modes = (4,) * len(sp)
+        blk = FNOBlocks(4, 4, n_modes, output_scaling_factor=scale, n_layers=2, fft_norm="forward",
+                        factorization=None, implementation="factorized")
+        scales = refill_parameters(blk)
+        x = input_fill(cname + ".x", (2, 4, *sp)).requires_grad_(True)
+        y = blk(blk(x, 0), 1)
+        dy = input_fill(cname + ".dy", tuple(y.shape))
+        y.backward(dy)
+        save(os.path.join(outdir, f"{cname}.npz"), x=x, dy=dy, y=y, dx=x.grad, grads=grads_of(blk), scales=scales,
+             scale=np.array(scale), sp=np.array(sp))
+
+
+def gen_regressor3d(outdir):
+    """neuralop.models.SpectralRegressor (the 3-D one, spectral_regressor.py:93-201), eval mode (dropout off)."""
+    from neuralop.models import SpectralRegressor
+    cases = {"regressor3d_small": dict(kw=dict(in_dim=5, n_hidden=5, freq_dim=6, out_dim=2, modes=3, spacial_dim=3),
+                                       shp=(2, 8, 8, 10, 5)),
+             # width 32 tiles the engine's pointwise kernel; modes 6 > Nz/2+1 = 5: zero-padded last-dim spectrum
+             "regressor3d_w32": dict(kw=dict(in_dim=32, n_hidden=32, freq_dim=32, out_dim=1, modes=6, spacial_dim=3,
+                                             activation='relu', last_activation=True), shp=(2, 16, 8, 8, 32))}
+    for cname, c in cases.items():
+        torch.manual_seed(0)
+        model = SpectralRegressor(**c["kw"]).eval()
+        scales = refill_parameters(model)
+        x = input_fill(cname + ".x", c["shp"]).requires_grad_(True)
+        y = model(x)
+        dy = input_fill(cname + ".dy", tuple(y.shape))
+        y.backward(dy)
+        g = grads_of(model)
+        gnorm = {k: np.array([np.sqrt((v.astype(np.float64) ** 2).sum())]) for k, v in g.items()}
+        g = {k: (v if v.size <= 20000 else v.reshape(-1)[:2048].copy()) for k, v in g.items()}
+        save(os.path.join(outdir, f"{cname}.npz"), x=x, dy=dy, y=y, dx=x.grad, grads=g, gnorm=gnorm, scales=scales,
+             shapes={k: np.array(v.shape) for k, v in model.state_dict().items()})
+
+
+def gen_rno_predict(outdir):
+    """RNO2d.predict (rno.py:370-379): autoregressive roll-out, every prediction fed back as the next one-step input."""
+    from neuralop.models import RNO2d
+    torch.manual_seed(0)
+    model = RNO2d(4, 4, 8, 0, layer_num=2).eval()
+    scales = refill_parameters(model)
+    x = input_fill("rno2d_predict.x", (2, 1, 16, 16, 1))
+    y = model.predict(x, num_steps=3)
+    tgt = input_fill("rno2d_predict.t", tuple(y.shape))
+    loss = _lp_rel_sum(y, tgt)
+    loss.backward()
+    save(os.path.join(outdir, "rno2d_predict.npz"), x=x, target=tgt, y=y, loss=np.array([float(loss.detach())]),
+         grads=grads_of(model), scales=scales, shapes={k: np.array(v.shape) for k, v in model.state_dict().items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -575,7 +652,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_fno_models_fp64, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow]
+    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_fno_models_fp64, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow, gen_options, gen_regressor3d, gen_rno_predict]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

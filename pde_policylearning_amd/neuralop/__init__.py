@@ -1,4 +1,23 @@
 """Host-side mirror of the reference's `neuralop` operator API for the hot path
 (reference neuralop/__init__.py:1-9): same class names, constructor arguments,
 parameter names and forward semantics; the arithmetic runs in the HIP engine."""
-from .models import FNO, FNO2d, FNO3d, SpectralConv, FactorizedSpectralConv  # noqa: F401
+__version__ = '0.2.1'
+
+from .models import TFNO3d, TFNO2d, TFNO1d, TFNO  # noqa: F401
+from .models import FNO, FNO1d, FNO2d, FNO3d, SFNO, UNO  # noqa: F401
+from .models import RNO2d, SpectralRegressor  # noqa: F401
+from .models import get_model  # noqa: F401
+from .models import SpectralConv, FactorizedSpectralConv  # noqa: F401
+
+# `neuralop.{datasets, mpu, Trainer, LpLoss, H1Loss}` (neuralop/__init__.py:6-9) are the reference's generic training
+# stack: none of it is on the accelerated path (run_pde_observers.py trains with libs.utilities3.LpLoss and its own
+# loop, mirrored by pde_policylearning_amd.trainer / train_observer).  Asking for them says so instead of a bare
+# AttributeError.
+_OUT_OF_SCOPE = ("datasets", "mpu", "Trainer", "LpLoss", "H1Loss")
+
+
+def __getattr__(name):
+    if name in _OUT_OF_SCOPE:
+        raise ImportError(f"neuralop.{name} is not part of the MI355X engine (out of scope, SURVEY section 2); "
+                          "the observer training step lives in pde_policylearning_amd.trainer / train_observer")
+    raise AttributeError(name)

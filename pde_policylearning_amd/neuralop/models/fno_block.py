@@ -1,9 +1,34 @@
 """FNOBlocks with the reference surface (neuralop/models/fno_block.py:10-170), default
 path only: linear (bias-free 1x1 conv) skip, no MLP, no norm, no preactivation."""
+import itertools
+
+import torch
 import torch.nn.functional as TF
 from torch import nn
 
 from .spectral_convolution import SpectralConv, _unsupported
+
+
+def _resample(x, scales):
+    """The skip branch on the resized grid of `output_scaling_factor` (fno_block.py:132-134 -> resample.py:6-56):
+    linear / antialiased bicubic interpolation with aligned corners in 1-D / 2-D, Fourier zero-padding or truncation
+    in 3-D.  Torch operations: this option has no HIP kernel (SpectralConv._torch_composition)."""
+    old = x.shape[-len(scales):]
+    new = tuple(int(round(s * r)) for s, r in zip(old, scales))
+    if len(new) == 1:
+        return TF.interpolate(x, size=new[0], mode='linear', align_corners=True)
+    if len(new) == 2:
+        return TF.interpolate(x, size=new, mode='bicubic', align_corners=True, antialias=True)
+    dims = list(range(-len(new), 0))
+    X = torch.fft.rfftn(x.float(), norm='forward', dim=dims)
+    fsz = list(new[:-1]) + [new[-1] // 2 + 1]
+    keep = [min(a, b) for a, b in zip(fsz, X.shape[-len(new):])]
+    out = torch.zeros(x.shape[0], x.shape[1], *fsz, device=x.device, dtype=torch.cfloat)
+    corners = [((None, m // 2), (-m // 2, None)) for m in keep[:-1]] + [((None, keep[-1]),)]
+    for bounds in itertools.product(*corners):
+        sl = (slice(None), slice(None)) + tuple(slice(*b) for b in bounds)
+        out[sl] = X[sl]
+    return torch.fft.irfftn(out, s=new, norm='forward', dim=dims)
 
 
 class FNOBlocks(nn.Module):
@@ -32,6 +57,12 @@ class FNOBlocks(nn.Module):
         self.in_channels, self.out_channels, self.n_layers = in_channels, out_channels, n_layers
         self.non_linearity = non_linearity
         self.fft_norm = fft_norm
+        if output_scaling_factor is not None:           # fno_block.py:37-42
+            if isinstance(output_scaling_factor, (float, int)):
+                output_scaling_factor = [[float(output_scaling_factor)] * self.n_dim] * n_layers
+            elif isinstance(output_scaling_factor[0], (float, int)):
+                output_scaling_factor = [[s] * self.n_dim for s in output_scaling_factor]
+        self.output_scaling_factor = output_scaling_factor
         self.convs = SpectralConv(in_channels, out_channels, self.n_modes,
                                   output_scaling_factor=output_scaling_factor,
                                   incremental_n_modes=incremental_n_modes, rank=rank, fft_norm=fft_norm,
@@ -49,6 +80,8 @@ class FNOBlocks(nn.Module):
     def forward(self, x, index=0):
         """Unfused composition (one block on its own); FNO.forward uses the fused engine path."""
         x_skip = self.fno_skips[index](x)
+        if self.convs.output_scaling_factor is not None:
+            x_skip = _resample(x_skip, self.output_scaling_factor[index])
         x = self.convs(x, index) + x_skip
         if self.gelu_after(index):
             x = self.non_linearity(x)

@@ -71,7 +71,7 @@ class FNO(nn.Module):
         blk = self.fno_blocks
         L = self.n_layers
         skip_ws = [blk.fno_skips[l].weight for l in range(L)]
-        spec_ws = [w.tensor for w in blk.convs.weight]
+        spec_ws = [w for l in range(L) for w in blk.convs.layer_weights(l)]    # sliced under incremental_n_modes
         return dict(lift_w=self.lifting.fc.weight, lift_b=self.lifting.fc.bias, skip_ws=skip_ws,
                     spec_ws=spec_ws, spec_bias=blk.convs.bias,
                     w1=self.projection.fc1.weight, b1=self.projection.fc1.bias,
@@ -83,6 +83,8 @@ class FNO(nn.Module):
         <= 4 input / output channels, projection_channels 256, and either rows that tile the 128 / 256-pixel workgroup tile
         (last dim 32, 64, 128, 256) or "loose rows" (any last dim in 32..320 on planes that tile by 128 pixels: 96 x 96,
         160 x 160, 192 x 192 grids ...; split-precision GEMM mode)."""
+        if self.fno_blocks.convs.separable or self.fno_blocks.convs.output_scaling_factor is not None:
+            return False           # torch compositions (SpectralConv._torch_composition): layer by layer
         w = x.shape[-1]
         npx = 256 if w > 128 else 128
         plane = 1
@@ -104,9 +106,11 @@ class FNO(nn.Module):
                                       tuple(m // 2 for m in self.n_modes), self.fft_norm, gelu_mask, x.device)
 
     def forward(self, x):
-        if self.fused_supported(x):
+        sliced = self.fno_blocks.convs.incremental_n_modes is not None
+        if self.fused_supported(x) and not (sliced and getattr(self, "_direct_grads", False)):
             # direct_grads: set by trainer.FlatGradBucket(model, direct=True); the engine then writes
-            # parameter gradients straight into the flat bucket (one use of each parameter per step)
+            # parameter gradients straight into the flat bucket (one use of each parameter per step; sliced weights
+            # under incremental_n_modes are copies, so that combination takes the composition below)
             return F.fno_model(x, direct_grads=getattr(self, "_direct_grads", False),
                                overlap=getattr(self, "_grad_overlap", None), **self.engine_args())
         # other widths / grids: spectral convolutions on the engine, pointwise glue in torch
@@ -163,3 +167,39 @@ class FNO3d(FNO):
             implementation=implementation, decomposition_kwargs=decomposition_kwargs,
             domain_padding=domain_padding, domain_padding_mode=domain_padding_mode, fft_norm=fft_norm)
         self.n_modes_height, self.n_modes_width, self.n_modes_depth = n_modes_height, n_modes_width, n_modes_depth
+
+
+class FNO1d(FNO):
+    """Name kept for `from neuralop.models import FNO1d` (tfno.py:222-340).  One-dimensional grids are not on the
+    accelerated path (configs 1-5 are 2-D / 3-D): constructing one raises."""
+
+    def __init__(self, n_modes_height, hidden_channels, in_channels=3, out_channels=1, lifting_channels=256,
+                 projection_channels=256, incremental_n_modes=None, n_layers=4, output_scaling_factor=None,
+                 non_linearity=TF.gelu, use_mlp=False, mlp_dropout=0, mlp_expansion=0.5, norm=None,
+                 skip='soft-gating', separable=False, preactivation=False, factorization=None, rank=1.0,
+                 joint_factorization=False, fixed_rank_modes=False, implementation='factorized',
+                 decomposition_kwargs=dict(), domain_padding=None, domain_padding_mode='one-sided',
+                 fft_norm='forward', **kwargs):
+        _unsupported("FNO1d (one-dimensional grids)")
+
+
+def _with_defaults(new_name, cls, **defaults):
+    """A subclass of `cls` whose constructor has other default values (the role of tfno.py:594-615)."""
+    def __init__(self, *args, **kwargs):
+        for k, v in defaults.items():
+            kwargs.setdefault(k, v)
+        cls.__init__(self, *args, **kwargs)
+    return type(new_name, (cls,), {"__init__": __init__, "__doc__": cls.__doc__})
+
+
+# Tucker-factorised and spherical variants (tfno.py:619-624): their weights live in tltorch / torch_harmonics containers
+# that this image does not have, so the constructors raise (SpectralConv refuses the factorization; SFNO needs the SHT).
+TFNO = _with_defaults('TFNO', FNO, factorization='Tucker')
+TFNO1d = _with_defaults('TFNO1d', FNO1d, factorization='Tucker')
+TFNO2d = _with_defaults('TFNO2d', FNO2d, factorization='Tucker')
+TFNO3d = _with_defaults('TFNO3d', FNO3d, factorization='Tucker')
+
+
+class SFNO(FNO):
+    def __init__(self, *args, **kwargs):
+        _unsupported("SFNO (spherical harmonic convolution, torch_harmonics)")

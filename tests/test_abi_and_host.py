@@ -109,6 +109,65 @@ def test_unsupported_configurations_fail_loudly():
         FNO((8, 8), 32, norm="group_norm")
 
 
+def test_reference_import_lines_resolve_against_the_package():
+    """The reference's own import statements (libs/models/fno_models.py:9, libs/models/rno_models.py:8,
+    neuralop/__init__.py:3-5, neuralop/models/__init__.py:1-7), executed verbatim with the package aliased as `neuralop`."""
+    import importlib
+    import sys
+    import pde_policylearning_amd.neuralop as pkg
+    saved = {k: sys.modules.get(k) for k in ("neuralop", "neuralop.models")}
+    sys.modules["neuralop"], sys.modules["neuralop.models"] = pkg, pkg.models
+    try:
+        ns = {}
+        for line in ("from neuralop.models import FNO2d", "from neuralop.models import RNO2d",
+                     "from neuralop.models import TFNO3d, TFNO2d, TFNO1d, TFNO", "from neuralop.models import get_model",
+                     "from neuralop.models import FNO, FNO1d, FNO2d, FNO3d", "from neuralop.models import SFNO",
+                     "from neuralop.models import UNO", "from neuralop.models import SpectralRegressor",
+                     "from neuralop import TFNO3d, TFNO2d, TFNO1d, TFNO", "from neuralop import RNO2d",
+                     "from neuralop import get_model"):
+            exec(line, ns)
+        from pde_policylearning_amd.neuralop.models import rno, tfno
+        assert ns["RNO2d"] is rno.RNO2d and ns["FNO2d"] is tfno.FNO2d
+        # the classes outside the accelerated path keep name and signature and say so when constructed
+        for cls, args in ((ns["TFNO2d"], (4, 4, 8)), (ns["TFNO"], ((4, 4), 8)), (ns["FNO1d"], (4, 8)),
+                          (ns["SFNO"], ((4, 4), 8)), (ns["UNO"], (3, 1, 8))):
+            with pytest.raises(NotImplementedError):
+                cls(*args)
+        with pytest.raises(ImportError, match="out of scope"):
+            exec("from neuralop import Trainer", {})
+        # get_model builds the accelerated classes from a reference-style config (model_dispatcher.py:26-62)
+        cfg = {"arch": "FNO2d", "fno2d": dict(data_channels=3, n_modes_height=8, n_modes_width=8, hidden_channels=32),
+               "patching": {"levels": 1}}
+        m = ns["get_model"](cfg)
+        assert type(m) is tfno.FNO2d and m.in_channels == 6
+        with pytest.raises(ValueError):
+            ns["get_model"]({"arch": "nope", "nope": {}})
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_constructor_options_beside_the_accelerated_path():
+    """separable / incremental_n_modes / output_scaling_factor build (torch compositions or sliced engine weights, GPU
+    parity in tests/test_boundary_gpu.py); shapes follow spectral_convolution.py:243-268."""
+    from pde_policylearning_amd.neuralop.models import FNO, SpectralConv
+    c = SpectralConv(4, 4, (8, 6), separable=True, n_layers=2)
+    assert tuple(c.weight[0].tensor.shape) == (4, 4, 3, 2) and len(c.weight) == 4
+    with pytest.raises(ValueError):
+        SpectralConv(4, 6, (8, 6), separable=True)
+    c = SpectralConv(4, 6, (8, 8), incremental_n_modes=(4, 6))
+    assert c.half_n_modes == [2, 3] and tuple(c.layer_weights(0)[0].shape) == (4, 6, 2, 3, 2)
+    c.incremental_n_modes = None
+    assert c.half_n_modes == [4, 4]
+    m = FNO((8, 8), 16, output_scaling_factor=[2, 1, 1, 0.5])
+    assert m.fno_blocks.convs.output_scaling_factor == [[2, 2], [1, 1], [1, 1], [0.5, 0.5]]
+    with pytest.raises(RuntimeError, match="GPU"):       # still no CPU path
+        c(torch.zeros(1, 4, 16, 16))
+
+
 def test_no_cpu_fallback():
     from pde_policylearning_amd.neuralop.models import FNO2d
     m = FNO2d(8, 8, 32)
