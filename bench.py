@@ -32,9 +32,8 @@ CONFIGS = {
     "fno3d_64_w32_m8_b16": dict(kind="3d", modes=(8, 8, 8), width=32, batch=16, size=(64, 64, 64)),
     # a grid whose rows do not tile the kernels' 128-pixel tile ("loose rows": spectral rows gathered per tile)
     "fno2d_96x96_w64_m12_b64": dict(kind="2d", modes=(12, 12), width=64, batch=64, size=(96, 96)),
-    # observer models of BASELINE configs 3 / 5.  Secondary workloads: their spectral
-    # convolutions run in the engine (fno_spec_*), the channels-last pointwise glue is still torch ops; no
-    # roofline / cpu_baseline legs.
+    # observer models of BASELINE configs 3 / 5.  Secondary workloads (same roofline / cpu_baseline
+    # legs, kernel model at their own batch / plane size).
     "rno2d_128x128_w64_m12_b32": dict(kind="rno2d", batch=32, size=(128, 128)),            # cfg 3 as named (256 / 8 GPUs)
     "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32), graph=True),   # configs/matlab_rno.yaml values; launch-bound
     "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32)),     # the YAML's active model
@@ -49,8 +48,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r02_pmc_traffic.json"
-PMC_SQ_CSV = "r02_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r03_pmc_traffic.json"
+PMC_SQ_CSV = "r03_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def source_hash():
@@ -68,8 +67,9 @@ def source_hash():
 def git_sha():
     try:
         import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD",) and not k.startswith("ROCP")}
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+                              timeout=5, env=env).stdout.strip() or None
     except Exception:
         return None
 
@@ -102,6 +102,170 @@ def kernel_model(cfg):
     }
 
 
+def make_workload(cfg, rank, dev, tgt_shape=None):
+    """(model, inputs, target) of a workload on `dev`: default init under torch.manual_seed(0) (run_pde_observers.py:25),
+    N(0,1) inputs from a per-rank CPU generator.  With `tgt_shape` (the pinned CPU-baseline process: no engine there) the
+    target is drawn at that shape instead of at the model output's."""
+    import torch
+    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
+    torch.manual_seed(0)
+    B = cfg["batch"]
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    if cfg["kind"] in ("2d", "3d"):
+        ctor = FNO2d if cfg["kind"] == "2d" else FNO3d
+        model = ctor(*cfg["modes"], cfg["width"], in_channels=3, out_channels=1).to(dev)
+        x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
+        tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
+        return model, (x,), tgt
+    if cfg["kind"].startswith("rno2d"):
+        from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+        width = 64 if cfg["kind"] == "rno2d" else 34
+        model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82
+        x = torch.randn((B, 1) + cfg["size"] + (1,), generator=gen).to(dev)    # (B, T, X, Y, 1), model_timestep 1
+        tgt = torch.randn((B,) + cfg["size"] + (1,), generator=gen).to(dev)
+        return model, (x,), tgt
+    from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
+    if cfg["kind"] == "pino2d_train":   # train_pino.py:79-106; a = (x, y, t, u0) grid as libs/pino_utils/datasets.py:612-617 builds it
+        from pde_policylearning_amd.libs.pino_utils.utils import get_grid3d
+        S, T = cfg["size"][0], cfg["size"][2]
+        m = cfg.get("modes", 8)
+        model = PINObserver2d(modes1=[m] * 4, modes2=[m] * 4, modes3=[m] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+                              out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)
+        u0 = torch.randn((B, S, S, 1, 1), generator=gen)
+        grid = torch.cat([g[0] for g in get_grid3d(S, T)], dim=-1)
+        x = torch.cat((grid.expand(B, -1, -1, -1, -1), u0.repeat(1, 1, 1, T, 1)), dim=-1).to(dev)
+    elif cfg["kind"] in ("pino_ff", "pino_ff_pde"):     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
+        model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
+                                     layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
+        x = torch.randn((B,) + cfg["size"] + (1, 1), generator=gen).to(dev)
+    else:                             # train_pino.py:154-160: x (B, X, Y, T, 4), T padded by round(T * 0.0625)
+        model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
+                              out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)      # YAML: a float pads both ends, T 65 -> 73
+        x = torch.randn((B,) + cfg["size"] + (4,), generator=gen).to(dev)
+    re = (torch.rand((B, 1), generator=gen) * 100 + 100).to(dev)
+    inputs = (x, re)
+    if tgt_shape is None:
+        with torch.no_grad():
+            tgt_shape = model(*inputs).shape
+    tgt = torch.randn(tuple(tgt_shape), generator=gen).to(dev)
+    return model, inputs, tgt
+
+
+def cpu_loss_builder(cfg, pc, cin, ts, bs):
+    """The oracle's (CPU restatement of the reference) loss of one step on `bs` fields, as a closure."""
+    from oracle import fno_oracle as O
+    from oracle import observers_oracle as OO
+    kind = cfg["kind"]
+    if kind in ("2d", "3d"):
+        return lambda: O.lp_loss_rel_sum(O.fno_forward(pc, cin[0], cfg["modes"]), ts)
+    if kind.startswith("rno2d"):
+        width = 64 if kind == "rno2d" else 34
+        return lambda: O.lp_loss_rel_sum(OO.rno2d_forward(pc, cin[0], 12, 12, width, 0, 1), ts)
+    if kind in ("pino_ff", "pino_ff_pde"):
+        # (the channel-flow physics term of pino_ff_pde is not part of the CPU sample: model + LpLoss only, said in `sample`)
+        def f():
+            y = OO.pinobserver_fullfield_forward(pc, cin[0], cin[1], [64] * 5, [(12, 12, 12)] * 4, [0.0, 0.0625])
+            return O.lp_loss_rel_sum(y.reshape(bs, -1), ts.reshape(bs, -1)) if y.numel() == ts.numel() else y.square().sum()
+        return f
+    from oracle import pino_loss_oracle as P
+    m = cfg.get("modes", 8)
+    S = cfg["size"][0]
+
+    def g():
+        y = OO.pinobserver2d_forward(pc, cin[0], cin[1], [64] * 5, [(m, m, m)] * 4, [0.0625, 0.0625])
+        if kind == "pino2d_train":     # 5 * IC + PDE residual (train_pino.py:86-106)
+            lic, lf = P.pino_loss(y.reshape(y.shape[:4]), cin[0][:, :, :, 0, -1], P.forcing(S), 1.0 / cin[1].reshape(bs), 0.5)
+            return 5.0 * lic + lf
+        return O.lp_loss_rel_sum(y, ts)
+    return g
+
+
+def physical_cores(node=None):
+    """One hardware thread per physical core this process may run on, in CPU-number order; node = a NUMA node number
+    restricts the list to that node (falls back to all cores when sysfs does not describe it)."""
+    allowed = sorted(os.sched_getaffinity(0))
+
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                out += list(range(int(a), int(b or a) + 1))
+        return out
+    if node is not None:
+        try:
+            on_node = set(parse(open(f"/sys/devices/system/node/node{node}/cpulist").read()))
+            if on_node & set(allowed):
+                allowed = [c for c in allowed if c in on_node]
+        except OSError:
+            pass
+    seen, cores = set(), []
+    for c in allowed:
+        try:
+            sib = tuple(parse(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read()))
+        except OSError:
+            sib = (c,)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(c)
+    return cores
+
+
+def cpu_child(spec):
+    """The CPU-baseline process: pins itself to `threads` physical cores (of NUMA node 0 unless `all_nodes`) BEFORE torch
+    creates its thread pool, rebuilds the workload on the CPU, runs `warmups` untimed + up to `iters` timed oracle steps
+    (zero_grad + forward + loss + backward) within `budget` seconds and prints one JSON line per timed step (cumulative), so
+    that a parent which has to stop it early still has the completed steps."""
+    cores = physical_cores(None if spec.get("all_nodes") else 0)
+    nthr = min(spec["threads"], len(cores))
+    os.sched_setaffinity(0, cores[:nthr])
+    os.environ["OMP_NUM_THREADS"] = str(nthr)
+    import torch
+    torch.set_num_threads(nthr)
+    cfg = dict(CONFIGS[spec["config"]], batch=spec["bs"])
+    model, inputs, tgt = make_workload(cfg, 0, "cpu", tgt_shape=spec["tgt_shape"])
+    pc = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    loss = cpu_loss_builder(cfg, pc, [t.detach() for t in inputs], None if cfg["kind"] == "pino2d_train" else tgt, spec["bs"])
+
+    def one():
+        for v in pc.values():
+            v.grad = None
+        loss().backward()
+    for _ in range(spec["warmups"]):
+        one()
+    t0, n = time.perf_counter(), 0
+    while n < spec["iters"]:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        print(json.dumps(dict(iters=n, seconds=round(el, 4), threads=nthr, pinned_cpus=cores[:nthr][:4] + ["..."] * (nthr > 4))),
+              flush=True)
+        if el > spec["budget"]:
+            break
+    return 0
+
+
+def run_cpu_child(spec, timeout):
+    """Run cpu_child(spec) in its own process (never initialises the GPU); returns its last progress record or None."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "OMP_", "MKL_"))}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(spec)]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()                               # exactly the process started here
+        out, _ = proc.communicate()
+    last = None
+    for line in (out or "").splitlines():
+        try:
+            last = json.loads(line)
+        except ValueError:
+            pass
+    return last
+
+
 def spawn_ranks(n, cmd, extra_env=None):
     """Start `cmd` n times, one process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, a free
     rendezvous port on 127.0.0.1); returns (rank 0's stdout, worst return code).  The other ranks' stdout is discarded, every
@@ -128,7 +292,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="fno2d_128x128_w64_m12_b64", choices=sorted(CONFIGS))
+    ap.add_argument("--repeats", type=int, default=15,
+                    help="the timed block of --steps steps is run this many times (each bracketed by barrier + synchronize, "
+                         "MAX over ranks); ms_per_step / value are the MEDIAN block, value_min / value_max the extremes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-child", default=None, help=argparse.SUPPRESS)     # internal: the pinned CPU-baseline process
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: exchange all gradients in one all-reduce after the backward pass instead of starting "
@@ -138,6 +306,8 @@ def main():
                          "launch-bound small configurations, marked graph=True in CONFIGS)")
     ap.add_argument("--eager", action="store_true", help="never replay a hipGraph, also where it is the workload's default")
     args = ap.parse_args()
+    if args.cpu_child:
+        return cpu_child(json.loads(args.cpu_child))
     if CONFIGS[args.config].get("graph") and not args.eager and args.gpus == 1:
         args.graph = True
 
@@ -148,6 +318,8 @@ def main():
         sys.stdout.write(out0)
         sys.stdout.flush()
         sys.exit(rc)
+
+    sha, src_hash = git_sha(), source_hash()          # child process + file reads: before anything touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -179,46 +351,10 @@ def main():
     from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, broadcast_parameters, train_step
 
     cfg = CONFIGS[args.config]
-    torch.manual_seed(0)                       # run_pde_observers.py:25
     B = cfg["batch"]
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
     fused_model = cfg["kind"] in ("2d", "3d")
-    if fused_model:
-        ctor = FNO2d if cfg["kind"] == "2d" else FNO3d
-        model = ctor(*cfg["modes"], cfg["width"], in_channels=3, out_channels=1).to(dev)
-        x = torch.randn((B, 3) + cfg["size"], generator=gen).to(dev)
-        tgt = torch.randn((B, 1) + cfg["size"], generator=gen).to(dev)
-        inputs = (x,)
-    elif cfg["kind"].startswith("rno2d"):
-        from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
-        width = 64 if cfg["kind"] == "rno2d" else 34
-        model = RNO2dObserver(12, 12, width, 0, layer_num=1).to(dev)          # configs/matlab_rno.yaml:67,80-82
-        x = torch.randn((B, 1) + cfg["size"] + (1,), generator=gen).to(dev)    # (B, T, X, Y, 1), model_timestep 1
-        tgt = torch.randn((B,) + cfg["size"] + (1,), generator=gen).to(dev)
-        inputs = (x,)
-    else:
-        from pde_policylearning_amd.libs.models.pino_models import PINObserver2d, PINObserverFullField
-        if cfg["kind"] == "pino2d_train":   # train_pino.py:79-106; a = (x, y, t, u0) grid as libs/pino_utils/datasets.py:612-617 builds it
-            from pde_policylearning_amd.libs.pino_utils.utils import get_grid3d
-            S, T = cfg["size"][0], cfg["size"][2]
-            m = cfg.get("modes", 8)
-            model = PINObserver2d(modes1=[m] * 4, modes2=[m] * 4, modes3=[m] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
-                                  out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)
-            u0 = torch.randn((B, S, S, 1, 1), generator=gen)
-            grid = torch.cat([g[0] for g in get_grid3d(S, T)], dim=-1)
-            x = torch.cat((grid.expand(B, -1, -1, -1, -1), u0.repeat(1, 1, 1, T, 1)), dim=-1).to(dev)
-        elif cfg["kind"] in ("pino_ff", "pino_ff_pde"):     # run_pde_observers.py:201-207: x (B, X, Y, T=1, 1), re (B, 1)
-            model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128,
-                                         layers=[64] * 5, in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)
-            x = torch.randn((B,) + cfg["size"] + (1, 1), generator=gen).to(dev)
-        else:                             # train_pino.py:154-160: x (B, X, Y, T, 4), T padded by round(T * 0.0625)
-            model = PINObserver2d(modes1=[8] * 4, modes2=[8] * 4, modes3=[8] * 4, fc_dim=128, layers=[64] * 5, in_dim=4,
-                                  out_dim=1, act="gelu", pad_ratio=0.0625).to(dev)      # YAML: a float pads both ends, T 65 -> 73
-            x = torch.randn((B,) + cfg["size"] + (4,), generator=gen).to(dev)
-        re = (torch.rand((B, 1), generator=gen) * 100 + 100).to(dev)
-        inputs = (x, re)
-        with torch.no_grad():
-            tgt = torch.randn(model(*inputs).shape, generator=gen).to(dev)
+    model, inputs, tgt = make_workload(cfg, rank, dev)
+    x = inputs[0]
     broadcast_parameters(model)
     overlap = fused_model and dist_on and not args.no_overlap
     if overlap:
@@ -273,18 +409,36 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    dt = time.perf_counter() - t0
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        sync()
+        blocks.append(time.perf_counter() - t0)
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tmax = torch.tensor(blocks, dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # every block: the slowest rank's time
+        blocks = [float(v) for v in tmax.tolist()]
     assert torch.isfinite(loss).all(), "non-finite loss"
+    srt = sorted(blocks)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     fields_per_s = B * world * args.steps / dt
+
+    # ---- N > 1: what the gradient exchange costs, and how much of it the overlap hides ----
+    exchange = None
+    if dist_on:
+        bucket.time_exchange(True)
+        for _ in range(max(5, args.profile_steps)):
+            eager_step()
+        torch.cuda.synchronize()
+        ms = bucket.exchange_ms()
+        bucket.time_exchange(False)
+        if ms is not None:
+            tm = torch.tensor(ms, dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            exchange = [round(float(v), 4) for v in tm.tolist()]
 
     # ---- per-kernel timing with HIP events on the launch stream (separate profiled steps) ----
     roofline = None
@@ -327,9 +481,9 @@ def main():
             # was collected on THESE kernel sources (source_hash) and this workload
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_JSON)))
-                if pj.get("source_hash") != source_hash():
+                if pj.get("source_hash") != src_hash:
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} was collected on other kernel sources "
-                                                  f"({pj.get('source_hash')} != {source_hash()}): not quoted")
+                                                  f"({pj.get('source_hash')} != {src_hash}): not quoted")
                 elif pj.get("workload", "fno2d_128x128_w64_m12_b64") == args.config:
                     pt = pj["kernels"]
                     base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
@@ -360,107 +514,45 @@ def main():
             roofline["measured"] = f"HIP events on the launch stream, {args.profile_steps} profiled steps after the timed region"
 
     # ---- CPU baseline: the oracle (validated restatement of the reference) on the host cores ----
+    # Each measurement is its own process, pinned to physical cores of NUMA node 0 before torch creates its thread pool
+    # (2 warm-ups, >= 5 timed steps).  torch's CPU FFT / einsum stop scaling long before a many-core
+    # host is full, so `value` is the best of an 8 / 16 / 32-thread sweep and `all_cores` the figure SURVEY section 8d asks
+    # for: every physical core of the host, one field, bounded at 120 s.
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import fno_oracle as O
-        from oracle import observers_oracle as OO
-        ncores = os.cpu_count() or 1
         kind = cfg["kind"]
         bs = min({"2d": 8, "rno2d": 2, "rno2d_shipped": 8, "pino_ff": 4, "pino_ff_pde": 4}.get(kind, 1), B)
-        pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-        cin = [t[:bs].detach().cpu() for t in inputs]
-        if kind in ("2d", "3d"):
-            ts = tgt[:bs].cpu()
-
-            def cpu_loss():
-                return O.lp_loss_rel_sum(O.fno_forward(pc, cin[0], cfg["modes"]), ts)
-        elif kind.startswith("rno2d"):
-            ts = tgt[:bs].cpu()
-            width = 64 if kind == "rno2d" else 34
-
-            def cpu_loss():
-                return O.lp_loss_rel_sum(OO.rno2d_forward(pc, cin[0], 12, 12, width, 0, 1), ts)
-        elif kind in ("pino_ff", "pino_ff_pde"):
-            # (the channel-flow physics term of pino_ff_pde is not part of the CPU sample: model + LpLoss only, said in `sample`)
-            ts = (tgt[0] if isinstance(tgt, tuple) else tgt)[:bs].cpu()
-
-            def cpu_loss():
-                y = OO.pinobserver_fullfield_forward(pc, cin[0], cin[1], [64] * 5, [(12, 12, 12)] * 4, [0.0, 0.0625])
-                return O.lp_loss_rel_sum(y.reshape(bs, -1), ts.reshape(bs, -1)) if y.numel() == ts.numel() else y.square().sum()
-        else:
-            from oracle import pino_loss_oracle as P
-            m = cfg.get("modes", 8)
-            S = cfg["size"][0]
-            ts = None if kind == "pino2d_train" else tgt[:bs].cpu()
-
-            def cpu_loss():
-                y = OO.pinobserver2d_forward(pc, cin[0], cin[1], [64] * 5, [(m, m, m)] * 4, [0.0625, 0.0625])
-                if kind == "pino2d_train":     # 5 * IC + PDE residual (train_pino.py:86-106)
-                    lic, lf = P.pino_loss(y.reshape(y.shape[:4]), cin[0][:, :, :, 0, -1], P.forcing(S), 1.0 / cin[1].reshape(bs), 0.5)
-                    return 5.0 * lic + lf
-                return O.lp_loss_rel_sum(y, ts)
-
-        def cpu_step():
-            for v in pc.values():
-                v.grad = None
-            cpu_loss().backward()
-
-        # torch's CPU FFT/einsum stop scaling (and then degrade badly) long before a many-core host is full (measured on the
-        # 256-core GPU box at config 2: 8 threads 22.9 fields/s, 64 threads 6.7, 256 threads 0.02).  Reported: the best of a
-        # 4/8/16/32-thread sweep (`value`, `cores`) AND the all-cores figure asked for by SURVEY section 8d (`all_cores`),
-        # each on a time-bounded sample.
-        def timed(nthr, budget, max_it):
-            torch.set_num_threads(nthr)
-            t_w = time.perf_counter()
-            cpu_step()                                   # warm-up at this thread count
-            if time.perf_counter() - t_w > budget:       # one step already exceeds the budget: that step is the sample
-                return bs / (time.perf_counter() - t_w), 1, time.perf_counter() - t_w
-            n_it, t_c0 = 0, time.perf_counter()
-            while True:
-                cpu_step()
-                n_it += 1
-                el = time.perf_counter() - t_c0
-                if el > budget or n_it >= max_it:
-                    return bs * n_it / el, n_it, el
-        best = None
-        probe = min(16, ncores)
-        torch.set_num_threads(probe)
-        t_p = time.perf_counter()
-        cpu_step()
-        t_p = time.perf_counter() - t_p
-        # weight-dominated observers (seconds per step; torch's complex einsum also degrades unboundedly at some thread
-        # counts on the 256-core boxes, and a running C++ op cannot be interrupted): one more step at this count, no sweep
-        heavy = t_p > 2.0 or cfg.get("n_params", 0) > 50_000_000
-        for nthr in ([probe] if heavy else [t for t in (4, 8, 16, 32) if t <= ncores] or [ncores]):
-            rate, n_it, el = timed(nthr, 3.0, 12)
-            if best is None or rate > best[0]:
-                best = (rate, nthr, n_it, el)
+        tshape = [bs] + list((tgt[0] if isinstance(tgt, tuple) else tgt).shape[1:])
+        if kind == "pino_ff_pde":
+            tshape = [bs, 3 * cfg["size"][0] * cfg["size"][1]]
+        node0 = len(physical_cores(0))
+        heavy = cfg.get("n_params", 0) > 50_000_000       # weight-dominated observers: seconds per step, one thread count
+        sweep = [16] if heavy else [t for t in (8, 16, 32) if t <= node0] or [node0]
+        runs = []
+        for nthr in sweep:
+            spec = dict(config=args.config, bs=bs, tgt_shape=tshape, threads=nthr, warmups=1 if heavy else 2,
+                        iters=2 if heavy else 8, budget=20.0 if heavy else 6.0)
+            r = run_cpu_child(spec, timeout=240 if heavy else 90)
+            if r:
+                runs.append(dict(threads=r["threads"], iters=r["iters"], seconds=r["seconds"],
+                                 value=round(bs * r["iters"] / r["seconds"], 3)))
         allc = None
-        if ncores > 32 and not heavy:
-            try:
-                import signal
-
-                def _alarm(*_):
-                    raise TimeoutError()
-                signal.signal(signal.SIGALRM, _alarm)
-                signal.alarm(25)                          # the all-cores run can take minutes per step: bounded
-                r_all, n_all, el_all = timed(ncores, 6.0, 4)
-                signal.alarm(0)
-                allc = dict(value=round(r_all, 3), cores=ncores, iters=n_all, seconds=round(el_all, 1))
-            except TimeoutError:
-                allc = dict(value=None, cores=ncores, note="one step did not finish within 25 s")
-            finally:
-                try:
-                    signal.alarm(0)
-                except Exception:
-                    pass
-        rate, nthr, n_it, el = best
-        cpu_baseline = dict(value=round(rate, 3), unit="fields/s", cores=nthr, kind="port",
-                            sample=f"oracle (CPU restatement of the reference, torch ops) zero_grad+fwd+loss+bwd on "
-                                   f"{bs} fields of the same shape; best of a 4/8/16/32-thread sweep on a "
-                                   f"{ncores}-core host: {nthr} threads, {n_it} iters in {el:.1f}s"
-                                   + ("; physics term not included" if kind == "pino_ff_pde" else ""),
-                            all_cores=allc)
+        nall = len(physical_cores(None))
+        if not heavy and nall > max(sweep):
+            r = run_cpu_child(dict(config=args.config, bs=1, tgt_shape=[1] + tshape[1:], threads=nall, all_nodes=True,
+                                   warmups=1, iters=5, budget=40.0), timeout=120)
+            allc = (dict(value=round(r["iters"] / r["seconds"], 3), cores=r["threads"], iters=r["iters"], seconds=r["seconds"],
+                         sample="1 field per step, 1 warm-up") if r else
+                    dict(value=None, cores=nall, note="not one timed step of 1 field finished within 120 s"))
+        if runs:
+            best = max(runs, key=lambda r: r["value"])
+            cpu_baseline = dict(value=best["value"], unit="fields/s", cores=best["threads"], kind="port",
+                                sample=f"oracle (CPU restatement of the reference, torch ops) zero_grad+fwd+loss+bwd on "
+                                       f"{bs} fields of the same shape, own process pinned to {best['threads']} physical cores "
+                                       f"of NUMA node 0 ({node0} there, {nall} on the host): {best['iters']} timed steps in "
+                                       f"{best['seconds']:.1f}s after {1 if heavy else 2} warm-ups; best of the thread sweep"
+                                       + ("; physics term not included" if kind == "pino_ff_pde" else ""),
+                                sweep=runs, all_cores=allc)
 
     if rank == 0:
         out = {
@@ -479,13 +571,19 @@ def main():
             "gemm_mode": "bf16x3-split (fp32 operands as 3 bf16 terms, 6 products, fp32 accumulate on the bf16 matrix pipe)"
                          if _lib.lib().fno_get_gemm_mode() == 1 else "f32 (v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
+            "repeats": len(blocks),
+            "value_min": round(B * world * args.steps / max(blocks), 2),
+            "value_max": round(B * world * args.steps / min(blocks), 2),
+            "ms_per_step_all": [round(1e3 * b / args.steps, 4) for b in blocks],
             "n_ranks": dist.get_world_size() if dist_on else 1,
+            "allreduce_ms_total": exchange[0] if exchange else None,
+            "allreduce_ms_exposed": exchange[1] if exchange else None,
             "gradient_exchange": {"bucket_bytes": 4 * bucket.flat.numel(), "wire_bytes_per_rank_per_step": bucket.planned_wire_bytes(),
                                   "segments": len(getattr(bucket, "_segments", None) or [1]),
                                   "kind": "overlapped late-layer segment + rest" if overlap else
                                           ("segmented, live slices of dialect-C weights only" if not fused_model else "single all-reduce")},
-            "git_sha": git_sha(),
-            "source_hash": source_hash(),
+            "git_sha": sha,
+            "source_hash": src_hash,
             "config": {"workload": args.config, "batch_per_gpu": B, "global_batch": B * world,
                        "step": "zero_grad+fwd+" + {"pino_ff_pde": "decode+LpLoss(sum)+channel-flow pde_loss", "pino2d_train": "5*IC+PDE residual loss"}.get(cfg["kind"], "LpLoss(sum)") + "+bwd" +
                                ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",

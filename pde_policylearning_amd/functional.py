@@ -5,6 +5,8 @@ forward->backward stash) and the stream; all arithmetic happens in the HIP libra
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -91,8 +93,17 @@ def _direct_views(direct_grads, spec_ws):
 
 
 def _notify_direct(tensors):
-    for h in DIRECT_WRITE_HOOKS:
-        h(tensors)
+    """DIRECT_WRITE_HOOKS holds weak references to bound methods (a bucket that went away must not be kept alive, nor
+    polled): dead entries are dropped here."""
+    dead = []
+    for ref in DIRECT_WRITE_HOOKS:
+        h = ref() if isinstance(ref, weakref.WeakMethod) else ref
+        if h is None:
+            dead.append(ref)
+        else:
+            h(tensors)
+    for ref in dead:
+        DIRECT_WRITE_HOOKS.remove(ref)
 
 
 class _SpectralConvFn(torch.autograd.Function):

@@ -207,7 +207,7 @@ class RNO_layer(nn.Module):
         return torch.stack(seq, dim=1) if steps > 1 else seq[0].unsqueeze(1)
 
 
-# width-64 twins of narrow models (see RNO2d._wide_twin): keyed by the configuration, parameters on the meta device
+# wider twins (32 or 64 channels) of narrow models (see RNO2d._wide_twin): keyed by the configuration, parameters on the meta device
 _WIDE_TWINS = {}
 ENGINE_WIDTHS = (32, 64)
 
@@ -225,6 +225,7 @@ def _pad_to(t, shape):
 class RNO2d(nn.Module):
     def __init__(self, modes1, modes2, width, recurrent_index, layer_num=3, pad_amount=None, pad_dim='1'):
         super().__init__()
+        pad_amount = tuple(pad_amount) if pad_amount is not None else None       # a list (YAML / JSON) is not hashable
         self._ctor = (modes1, modes2, recurrent_index, layer_num, pad_amount, pad_dim)
         self.modes1 = modes2           # the reference overwrites modes1 with modes2 (rno.py:301-302)
         self.width, self.pad_amount, self.pad_dim = width, pad_amount, pad_dim
@@ -289,15 +290,16 @@ class RNO2d(nn.Module):
 
     def _wide_twin(self):
         """A width the fused kernels do not tile (the shipped YAML's 34, configs/matlab_rno.yaml:80) runs EXACTLY as the same
-        network embedded in 64 channels: every parameter zero-padded to the shapes of a width-64 twin.  Padded input columns
+        network embedded in the next width the kernels tile (32 or 64 channels): every parameter zero-padded to the twin's shapes.  Padded input columns
         are zero, so the padded channels (which the scalar gate biases make non-zero) never reach a real channel, and the
-        gradient of a padded weight entry is discarded by the pad's adjoint (a slice); the regressor head widens 4 * 34 ->
-        256 hidden units the same way.  The twin is a structure only (meta-device parameters, shared per configuration)."""
-        key = self._ctor
+        gradient of a padded weight entry is discarded by the pad's adjoint (a slice); the regressor head widens its 4 * width hidden units the
+        same way.  The twin is a structure only (meta-device parameters, shared per configuration)."""
+        wide = min(w for w in ENGINE_WIDTHS if w >= self.width)      # the narrowest width the fused kernels tile
+        key = self._ctor + (wide,)
         if key not in _WIDE_TWINS:
-            m1, m2, ri, ln, pa, pd = key
+            m1, m2, ri, ln, pa, pd = self._ctor
             with torch.device("meta"):
-                _WIDE_TWINS[key] = RNO2d(m1, m2, 64, ri, layer_num=ln, pad_amount=pa, pad_dim=pd)
+                _WIDE_TWINS[key] = RNO2d(m1, m2, wide, ri, layer_num=ln, pad_amount=pa, pad_dim=pd)
         return _WIDE_TWINS[key]
 
     def forward(self, x, v_plane=None, timestep=2):

@@ -224,9 +224,12 @@ class FlatGradBucket(object):
         if self._zero_from < self.flat.numel():
             self.flat[self._zero_from:].zero_()
 
-    def check_views(self):
-        """autograd accumulates in place into an existing .grad; re-attach if something replaced it."""
+    def check_views(self, skip=()):
+        """autograd accumulates in place into an existing .grad; re-attach if something replaced it (`skip`: ids of
+        parameters whose bucket region an asynchronous all-reduce is still reducing)."""
         for p, v in zip(self.params, self.views(self.flat)):
+            if id(p) in skip:
+                continue
             if p.grad is None:
                 p.grad = v
             elif p.grad.data_ptr() != v.data_ptr():
@@ -236,24 +239,73 @@ class FlatGradBucket(object):
     def all_reduce(self):
         """SUM over ranks, no division (sum-reduced loss).  With an overlapped bucket (for_fno) the late
         layers' part is already in flight: wait for it and exchange the rest."""
-        self.check_views()
+        self._check_live_extents()
         if not self._collective_needed():
+            self.check_views()
             self._inflight = None
-            for sg in getattr(self, "_segments", []):
+            for sg in getattr(self, "_segments", None) or []:
                 sg["work"], sg["pending"] = None, set(sg["ids"])
             return
+        ev0 = self._event()
         if getattr(self, "_segments", None) is not None:
+            # gradients of segments already on the wire must not be touched: re-attach views only where nothing is in flight
+            self.check_views(skip={i for sg in self._segments if sg["work"] is not None for i in sg["ids"]})
             self.wire_bytes = self.wire_bytes if any(sg["work"] is not None for sg in self._segments) else 0
             self._finish_segments()
             self.wire_bytes_last, self.wire_bytes = self.wire_bytes, 0
-            return
-        self.wire_bytes_last = 4 * self.flat.numel()
-        work, self._inflight = getattr(self, "_inflight", None), None
-        if work is not None:
-            dist.all_reduce(self.flat[self._late_numel:], op=dist.ReduceOp.SUM, group=self.group)
-            work.wait()
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.wire_bytes_last = 4 * self.flat.numel()
+            work, self._inflight = getattr(self, "_inflight", None), None
+            if work is not None:
+                late = {id(p) for p in self.params[:self._late_count]}
+                self.check_views(skip=late)
+                dist.all_reduce(self.flat[self._late_numel:], op=dist.ReduceOp.SUM, group=self.group)
+                work.wait()
+            else:
+                self.check_views()
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if ev0 is not None:
+            first, self._ev_first = getattr(self, "_ev_first", None) or ev0, None
+            self.exchange_events.append((first, ev0, self._event()))
+
+    # ---- timing of the exchange (bench.py, N > 1): HIP events on the compute stream ---------------------------------
+    def time_exchange(self, on=True):
+        """Record, per step, events at the first collective's launch, at the start of the post-backward wait and at its end
+        (exchange_ms() turns them into total / exposed milliseconds)."""
+        self.exchange_events = [] if on else None
+        self._ev_first = None
+
+    def _event(self):
+        if getattr(self, "exchange_events", None) is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _mark_first_launch(self):
+        if getattr(self, "exchange_events", None) is not None and getattr(self, "_ev_first", None) is None:
+            self._ev_first = self._event()
+
+    def exchange_ms(self):
+        """(total, exposed) milliseconds per step, averaged over the recorded steps: total = first collective enqueued ->
+        every collective complete on the compute stream; exposed = the part after the backward pass's last kernel (what
+        the overlap did not hide).  Call after a device synchronise."""
+        ev = getattr(self, "exchange_events", None)
+        if not ev:
+            return None
+        tot = sum(a.elapsed_time(c) for a, _, c in ev) / len(ev)
+        exp = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev)
+        return tot, exp
+
+    def _check_live_extents(self):
+        """The live last-dim extents of dialect-C weights were recorded once (enable_dp_exchange); a later batch with a
+        longer last dimension puts gradient into slices that are never packed, and the ranks would drift apart silently."""
+        for m, k in getattr(self, "_live_modules", ()):
+            now = m.__dict__.get("_live_last")
+            if now is not None and now > k:
+                raise RuntimeError(f"FlatGradBucket: {type(m).__name__} now has {now} live last-dim modes, the gradient "
+                                   f"exchange was planned for {k} (longer last dimension than the sample batch): call "
+                                   "enable_dp_exchange again with a sample of the new shape")
 
     # ---- segmented exchange: any model, segments go on the wire as their gradients complete ---------------------------
     def enable_segmented_exchange(self, min_bytes=16 << 20, live_last=None):
@@ -292,11 +344,32 @@ class FlatGradBucket(object):
         self._seg_of = {i: sg for sg in segs for i in sg["ids"]}
         self._by_ptr = {}
         self.wire_bytes = 0
+        self.close()
+        import weakref
+        me = weakref.ref(self)
+
+        def arrived(p):              # the parameters must not keep the bucket (and its buffers) alive
+            b = me()
+            if b is not None:
+                b._arrived(p)
         for p, v in zip(self.params, self.views(self.flat)):
             self._by_ptr[(torch.view_as_real(v) if v.is_complex() else v).data_ptr()] = p
-            p.register_post_accumulate_grad_hook(self._arrived)
-        F.DIRECT_WRITE_HOOKS.append(self._direct_written)
+            self._hook_handles.append(p.register_post_accumulate_grad_hook(arrived))
+        self._direct_ref = weakref.WeakMethod(self._direct_written)
+        F.DIRECT_WRITE_HOOKS.append(self._direct_ref)
         return self
+
+    def close(self):
+        """Detach from the parameters' gradient hooks and from functional.DIRECT_WRITE_HOOKS (a bucket that is dropped
+        without close() is released as well: both registrations hold weak references only)."""
+        from . import functional as F
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+        ref = getattr(self, "_direct_ref", None)
+        if ref is not None and ref in F.DIRECT_WRITE_HOOKS:
+            F.DIRECT_WRITE_HOOKS.remove(ref)
+        self._direct_ref = None
 
     def planned_wire_bytes(self):
         """bytes one rank puts on the wire per step: the whole bucket, or with a segmented exchange the segments' buffers
@@ -317,7 +390,7 @@ class FlatGradBucket(object):
         sg = self._seg_of.get(id(p))
         if sg is None or sg["work"] is not None:
             return
-        if not F.LAST_FORWARD_SINGLE_USE[0]:
+        if not getattr(self, "single_use_step", F.LAST_FORWARD_SINGLE_USE[0]):
             return      # parameters used several times per step (RNO2d over T > 1 steps) accumulate several times: the
                         # first arrival is not the last - all_reduce() exchanges every segment after the backward pass
         sg["pending"].discard(id(p))
@@ -338,6 +411,7 @@ class FlatGradBucket(object):
         return out
 
     def _launch(self, sg, async_op):
+        self._mark_first_launch()
         if sg["sliced"]:
             for live, slot in self._live_views(sg):
                 slot.copy_(live)
@@ -377,6 +451,7 @@ class FlatGradBucket(object):
         rest = [p for p in model.parameters() if id(p) not in late_ids and p.requires_grad]
         bucket = cls([p for p in late if p.requires_grad] + rest, process_group=process_group, direct_module=model)
         bucket._late_numel = sum(cls._nfloat(p) for p in late if p.requires_grad)
+        bucket._late_count = sum(1 for p in late if p.requires_grad)
         bucket._inflight = None
         bucket.split_layer = split_layer
         fno._grad_overlap = bucket
@@ -390,6 +465,7 @@ class FlatGradBucket(object):
 
     def late_gradients_ready(self):
         if self._collective_needed():
+            self._mark_first_launch()
             self._inflight = dist.all_reduce(self.flat[:self._late_numel], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True)
 
@@ -404,6 +480,8 @@ def enable_dp_exchange(bucket, model, sample_inputs=None, min_bytes=16 << 20):
         with torch.no_grad():
             model(*sample_inputs)
         model.train(was)
+    bucket._live_modules = [(m, int(m.__dict__["_live_last"])) for m in model.modules()
+                            if m.__dict__.get("_live_last") is not None and hasattr(m, "modes3")]
     return bucket.enable_segmented_exchange(min_bytes=min_bytes, live_last=live_last_of(model))
 
 
@@ -518,8 +596,12 @@ def shard_batch(t, rank, world):
 def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None):
     """zero_grad -> forward -> decode -> loss -> backward -> all-reduce -> optimizer step
     (run_pde_observers.py:185-193).  Returns the local loss tensor (no host sync)."""
+    from . import functional as F
     bucket.zero()
     pred = model_fn(*inputs)
+    # whether this forward used every parameter once (read by the bucket's early-launch decision during THIS backward pass;
+    # another model's forward in between must not change it)
+    bucket.single_use_step = F.LAST_FORWARD_SINGLE_USE[0]
     if isinstance(loss_fn, FusedLpLoss):
         # decode, both norms and the gradient happen inside the engine's loss kernels
         if decoder is not None:

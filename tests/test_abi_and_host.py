@@ -368,3 +368,46 @@ def test_bench_self_launch_spawns_one_process_per_rank(tmp_path):
     assert rc == 0 and rec == {"rank": 0, "world": 2, "sum": 3.0, "local": "0"}
     out, rc = bench.spawn_ranks(2, [sys.executable, str(script)], extra_env={"FAIL_RANK": "1"})
     assert rc != 0
+
+
+def test_bucket_hooks_are_released_and_live_extent_growth_is_refused():
+    """a segmented bucket registers parameter hooks and a direct-write hook; close() (or dropping the bucket)
+    releases both, and a batch with a longer last dimension than the sample the exchange was planned on is refused."""
+    import gc
+    from torch import nn
+    from pde_policylearning_amd import functional as F
+    from pde_policylearning_amd.trainer import FlatGradBucket
+
+    class Conv(nn.Module):                       # stand-in for basics.SpectralConv3d: four complex corner weights
+        def __init__(self):
+            super().__init__()
+            self.modes3 = 6
+            for i in range(1, 5):
+                setattr(self, f"weights{i}", nn.Parameter(torch.zeros(2, 2, 3, 3, 6, dtype=torch.cfloat)))
+            self._live_last = 2
+    m = Conv()
+    n0 = len(F.DIRECT_WRITE_HOOKS)
+    b = FlatGradBucket(m.parameters())
+    b._live_modules = [(m, 2)]
+    b.enable_segmented_exchange(min_bytes=64, live_last={w: 2 for w in m.parameters()})
+    assert len(F.DIRECT_WRITE_HOOKS) == n0 + 1 and len(b._hook_handles) == 4
+    assert b.planned_wire_bytes() == 4 * 4 * (2 * 2 * 3 * 3 * 2 * 2)          # live slices only
+    b.all_reduce()                                # single process: nothing to exchange, extents unchanged
+    m._live_last = 3
+    with pytest.raises(RuntimeError, match="live last-dim"):
+        b.all_reduce()
+    b.close()
+    assert len(F.DIRECT_WRITE_HOOKS) == n0 and not b._hook_handles
+    b2 = FlatGradBucket(m.parameters()).enable_segmented_exchange(min_bytes=64)
+    assert len(F.DIRECT_WRITE_HOOKS) == n0 + 1
+    del b2
+    gc.collect()
+    F._notify_direct([])                          # a dead bucket's entry is dropped, not called
+    assert len(F.DIRECT_WRITE_HOOKS) == n0
+
+
+def test_rno2d_accepts_list_pad_amount_and_picks_the_narrowest_twin():
+    from pde_policylearning_amd.neuralop.models import RNO2d
+    m = RNO2d(4, 4, 20, 0, layer_num=1, pad_amount=[2, 2], pad_dim='both')
+    assert m._wide_twin().width == 32
+    assert RNO2d(4, 4, 34, 0, layer_num=1)._wide_twin().width == 64
