@@ -1,0 +1,106 @@
+"""BASELINE configurations 2, 3 and 4 AT FULL SIZE against the CPU oracle: the whole batch, output and every parameter
+gradient (tests/test_parity_gpu.py holds the same shapes to batch-independence / additivity properties; here the
+persistent grids' tails and the slab reductions over thousands of tiles meet the oracle's numbers).
+
+The oracle runs in float64 on float64 copies of the same float32 inputs and parameters (the value both float32
+evaluations approximate) and once more in float32 (the reference's own distance from it: the budget of
+test_parity_gpu._within_budget), in chunks of samples - the loss is a sum over samples, so gradients add.
+Tolerance: 1e-5 relative L2 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fno_oracle as O
+from oracle import observers_oracle as OO
+from oracle.detfill import fill_named
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+BUDGET_SLACK = 2.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from pde_policylearning_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _oracle(forward, params, x, tgt, dtype, chunk):
+    """forward(params, x_chunk) -> prediction; sum-reduced relative L2 against tgt; gradients accumulated over the chunks.
+    Returns (y, {name: grad}) as numpy arrays of `dtype`."""
+    pc = {k: (v.to(dtype) if v.is_floating_point() else v.to(torch.complex128 if dtype == torch.float64 else v.dtype))
+          .clone().requires_grad_(True) for k, v in params.items()}
+    ys = []
+    for lo in range(0, x.shape[0], chunk):
+        y = forward(pc, x[lo:lo + chunk].to(dtype))
+        O.lp_loss_rel_sum(y, tgt[lo:lo + chunk].to(dtype).reshape(y.shape)).backward()
+        ys.append(y.detach())
+    g = {k: (torch.view_as_real(v.grad) if v.grad.is_complex() else v.grad).numpy() for k, v in pc.items()}
+    return torch.cat(ys).numpy(), g
+
+
+def _compare(model, y, params, y64, g64, g32):
+    assert rel_l2(y.detach().cpu().numpy().reshape(y64.shape), y64) < TOL
+    worst = ("", 0.0)
+    for name, prm in model.named_parameters():
+        got = prm.grad
+        got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
+        e, e32 = rel_l2(got, g64[name]), rel_l2(g32[name], g64[name])
+        assert np.isfinite(got).all() and e < max(TOL, BUDGET_SLACK * e32), (name, e, e32)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+    print(f"worst gradient vs float64 oracle: {worst[0]} {worst[1]:.2e}")
+
+
+def test_fno2d_config2_fullsize_vs_oracle(dev):
+    """BASELINE config 2: FNO2d(12, 12, 64), 128 x 128, batch 64 (the bench workload)."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    torch.manual_seed(0)
+    model = FNO2d(12, 12, 64, in_channels=3, out_channels=1)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(fill_named("c2full.x", (64, 3, 128, 128), 1.0))
+    tgt = torch.from_numpy(fill_named("c2full.t", (64, 1, 128, 128), 1.0))
+    fwd = lambda p, xc: O.fno_forward(p, xc, (12, 12))
+    y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 16)
+    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 16)
+    model = model.to(dev)
+    y = model(x.to(dev))
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    _compare(model, y, params, y64, g64, g32)
+
+
+def test_rno2d_config3_fullsize_vs_oracle(dev):
+    """BASELINE config 3 as named: RNO2d(12, 12, 64, layer_num 1), 128 x 128, 32 fields per GPU, eval mode (dropout off)."""
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    torch.manual_seed(0)
+    model = RNO2dObserver(12, 12, 64, 0, layer_num=1).eval()
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(fill_named("c3full.x", (32, 1, 128, 128, 1), 1.0))
+    tgt = torch.from_numpy(fill_named("c3full.t", (32, 128, 128, 1), 1.0))
+    fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
+    y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 8)
+    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
+    model = model.to(dev)
+    y = model(x.to(dev))
+    O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
+    _compare(model, y, params, y64, g64, g32)
+
+
+def test_fno3d_config4_fullsize_vs_oracle(dev):
+    """BASELINE config 4: FNO3d(8, 8, 8, 32) on 64^3 fields, batch 16."""
+    from pde_policylearning_amd.neuralop.models import FNO3d
+    torch.manual_seed(0)
+    model = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(fill_named("c4full.x", (16, 3, 64, 64, 64), 1.0))
+    tgt = torch.from_numpy(fill_named("c4full.t", (16, 1, 64, 64, 64), 1.0))
+    fwd = lambda p, xc: O.fno_forward(p, xc, (8, 8, 8))
+    y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 2)
+    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 4)
+    model = model.to(dev)
+    y = model(x.to(dev))
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    _compare(model, y, params, y64, g64, g32)

@@ -264,8 +264,8 @@ def test_fno2d_vs_oracle(dev, C, S, modes, B, L, gemm_mode):
 
 
 def test_fno2d_fullsize_properties(dev):
-    """BASELINE config 2 shape (batch 64, 128x128, width 64, n_modes 12): the oracle is
-    too slow to run here in seconds, so check size-independent properties:
+    """BASELINE config 2 shape (batch 64, 128x128, width 64, n_modes 12): size-independent properties (the full batch
+    against the float64 oracle: tests/test_fullsize_gpu.py):
     (i) batch independence: sample 0 of the batch-64 run == a batch-1 run of sample 0;
     (ii) parameter gradients are additive over the batch (sum loss);
     (iii) every parameter receives a finite, non-zero gradient (reference test_tfno.py:61-65)."""
