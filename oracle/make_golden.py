@@ -611,7 +611,7 @@ def gen_regressor3d(outdir):
                                        shp=(2, 8, 8, 10, 5)),
              # width 32 tiles the engine's pointwise kernel; modes 6 > Nz/2+1 = 5: zero-padded last-dim spectrum
              "regressor3d_w32": dict(kw=dict(in_dim=32, n_hidden=32, freq_dim=32, out_dim=1, modes=6, spacial_dim=3,
-                                             activation='relu', last_activation=True), shp=(2, 16, 8, 8, 32))}
+                                             activation='relu', last_activation=True), shp=(2, 16, 16, 8, 32))}
     for cname, c in cases.items():
         torch.manual_seed(0)
         model = SpectralRegressor(**c["kw"]).eval()

@@ -17,6 +17,7 @@
 #include "k_block_bwd2.h"
 #include "k_chanflow.h"
 #include "k_pointwise.h"
+#include "k_block_fwd2.h"
 #include "k_projection.h"
 #include "k_projection2.h"
 #include "k_spectral_mid.h"
@@ -1075,8 +1076,45 @@ static const int g_no_lift_fuse = getenv("FNO_NO_LIFT_FUSE") ? 1 : 0;      // A/
 static bool lift_fused(const FnoModelPlan* p) {
   return !g_no_lift_fuse && p->d.Cin > 0 && g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !p->loose;
 }
+// second-generation block forward (k_block_fwd2.h): whole rows in 128-pixel tiles; FNO_BFWD_V1=1 keeps k_pw_fwd_x3 (A/B arm)
+static const int g_bfwd_v1 = getenv("FNO_BFWD_V1") ? 1 : 0;
+static const int g_grid_bf2 = getenv("FNO_GRID_BF2") ? atoi(getenv("FNO_GRID_BF2")) : 0;   // 0: 2 per CU at 64 channels, 3 at 32
+template <int C>
+static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds) {
+  if (g_bfwd_v1 || p->NPX != 128 || p->loose || !a.x) return false;
+  if ((size_t)a.PW * 4 * C >= (size_t)1 << 31) return false;          // 32-bit buffer offsets within one sample
+  if (a.z && a.K2in > 16) return false;                                // spectral extension: at most two 16-deep k blocks
+  if (C == 32 && !a.x1) return false;      // 32 channels without a row-DFT epilogue: k_pw_fwd_x3 is faster (59 vs 70 us at config-2 size)
+  *lds = blk_fwd_t_lds_bytes(C, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
+  return *lds + 2048 <= 160 * 1024;
+}
 template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+  size_t lds2 = 0;
+  if (blk_fwd_t_ok<C>(p, a, &lds2)) {
+    const dim3 g2(std::min(a.ntiles, (g_grid_bf2 > 0 ? g_grid_bf2 : (C == 64 ? 2 : 3)) * p->ncu)), blk((C / 32) * 2 * 64);
+    const int epi = a.x1 ? (a.act_out ? 2 : 1) : 0;
+    // (template flags: LIFT, RELU, ACT_IN, EPI, ADD - k_block_fwd2.h; other combinations keep k_pw_fwd_x3)
+    const int kz = a.z ? (2 * a.K2in + 15) / 16 : 0;
+#define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
+    if (kz == 0) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
+    if (kz == 1) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); \
+    return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 2>, g2, blk, lds2, st, a); } while (0)
+    if (a.lw && !a.relu_out && !a.add) {
+      if (epi == 2) BF2(true, false, false, 2, false);
+      if (epi == 1) BF2(true, false, false, 1, false);
+      BF2(true, false, false, 0, false);
+    }
+    if (!a.lw && !a.relu_out && !a.add) {
+      if (a.act_in) { if (epi == 2) BF2(false, false, true, 2, false); if (epi == 1) BF2(false, false, true, 1, false); BF2(false, false, true, 0, false); }
+      if (epi == 2) BF2(false, false, false, 2, false);
+      if (epi == 1) BF2(false, false, false, 1, false);
+      BF2(false, false, false, 0, false);
+    }
+    if (!a.lw && !a.relu_out && a.add && epi == 0) { if (a.act_in) BF2(false, false, true, 0, true); BF2(false, false, false, 0, true); }
+    if (!a.lw && a.relu_out && !a.add && epi == 0 && !a.act_in) BF2(false, true, false, 0, false);
+#undef BF2
+  }
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
                      (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
   if (p->loose && !a.relu_out)

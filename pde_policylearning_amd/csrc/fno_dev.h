@@ -91,6 +91,98 @@ FNO_DEV float gelu_f(float x) {
 }
 FNO_DEV float gelu_grad_f(float x) { float g, d; gelu_both(x, g, d); return d; }
 
+// ---- GELU on pairs -----------------------------------------------------------------------------------------------------------
+// The kernels are bound by VALU issue, and gelu_f / gelu_both compile to one instruction per scalar step plus canonicalisation
+// moves around fminf / fmaxf (3 v_max + 1 v_min per element).  On pairs the polynomial steps are v_pk_fma_f32 / v_pk_mul_f32
+// (half the issue slots), the clamps v_med3_f32 (a target intrinsic: no canonicalisation) and the sign select of the
+// derivative form a v_bfi: 15 instead of 26 instructions per pair for the value, 22 instead of ~36 for value + derivative.
+// Same polynomials and the same final operations as the scalar forms.  `six` / `inf` = 6.0f / +infinity in SGPRs
+// (gelu_consts: VOP3 takes no literal on gfx9).  -DFNO_GELU_PK=0 restores the scalar forms (A/B arm).
+#ifndef FNO_GELU_PK
+#define FNO_GELU_PK 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+FNO_DEV void gelu_consts(float& six, float& inf) {
+  asm volatile("s_mov_b32 %0, 0x40c00000\n\ts_mov_b32 %1, 0x7f800000" : "=s"(six), "=s"(inf));
+}
+template <int NP>
+FNO_DEV void gelu_pairs(f32x2 (&x)[NP], float six, float inf) {
+#if !FNO_GELU_PK
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { x[p][0] = gelu_f(x[p][0]); x[p][1] = gelu_f(x[p][1]); }
+  return;
+#endif
+  f32x2 s[NP], r[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    s[p][0] = __builtin_amdgcn_fmed3f(__builtin_fabsf(x[p][0]), 0.0f, six);
+    s[p][1] = __builtin_amdgcn_fmed3f(__builtin_fabsf(x[p][1]), 0.0f, six);
+  }
+  constexpr float cf[8] = {6.119213594502071e-06f, -3.2478157663717866e-05f, -0.0004947108100168407f, 0.0075082844123244286f,
+                           -0.052784692496061325f, -0.4591203033924103f, -1.1511149406433105f, -0.9999998211860657f};
+#pragma unroll
+  for (int p = 0; p < NP; ++p) r[p] = __builtin_elementwise_fma(s[p], f32x2{cf[0], cf[0]}, f32x2{cf[1], cf[1]});
+#pragma unroll
+  for (int k = 2; k < 8; ++k)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) r[p] = __builtin_elementwise_fma(s[p], r[p], f32x2{cf[k], cf[k]});
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    r[p][0] = __builtin_amdgcn_exp2f(r[p][0]);
+    r[p][1] = __builtin_amdgcn_exp2f(r[p][1]);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    x[p][0] = __builtin_fmaf(-__builtin_fabsf(x[p][0]), r[p][0], __builtin_amdgcn_fmed3f(x[p][0], 0.0f, inf));
+    x[p][1] = __builtin_fmaf(-__builtin_fabsf(x[p][1]), r[p][1], __builtin_amdgcn_fmed3f(x[p][1], 0.0f, inf));
+  }
+}
+FNO_DEV void gelu8(float (&v)[8], float six, float inf) {
+  f32x2 x[4] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, f32x2{v[4], v[5]}, f32x2{v[6], v[7]}};
+  gelu_pairs<4>(x, six, inf);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) { v[2 * p] = x[p][0]; v[2 * p + 1] = x[p][1]; }
+}
+FNO_DEV float4 gelu4(const float4& v, float six, float inf) {
+  f32x2 x[2] = {f32x2{v.x, v.y}, f32x2{v.z, v.w}};
+  gelu_pairs<2>(x, six, inf);
+  return make_float4(x[0][0], x[0][1], x[1][0], x[1][1]);
+}
+// value and derivative of a pair (gelu_both's formulas: erfc by Abramowitz-Stegun 7.1.26, one v_exp and one v_rcp per element
+// shared by both).  The branch `x >= 0 ? 1 - q : q` becomes 0.5 + copysign(0.5 - q, x).
+FNO_DEV void gelu_both2(f32x2 x, f32x2& g, f32x2& dg) {
+#if !FNO_GELU_PK
+  gelu_both(x[0], g[0], dg[0]); gelu_both(x[1], g[1], dg[1]);
+  return;
+#endif
+  const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  f32x2 t = __builtin_elementwise_fma(ax, f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2{1.0f, 1.0f});
+  t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+  // 0.5 * (((((a5 t + a4) t + a3) t + a2) t + a1) t): the 0.5 of q = 0.5 poly e is folded into the coefficients
+  f32x2 poly = __builtin_elementwise_fma(t, f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  poly = __builtin_elementwise_fma(t, poly, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  poly = __builtin_elementwise_fma(t, poly, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  poly = __builtin_elementwise_fma(t, poly, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  poly = poly * t;
+  f32x2 e = (x * x) * f32x2{-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f};      // exp(-x^2 / 2) = exp2(-x^2 log2(e) / 2)
+  e[0] = __builtin_amdgcn_exp2f(e[0]); e[1] = __builtin_amdgcn_exp2f(e[1]);
+  const f32x2 q = poly * e;                                 // = 0.5 erfc(|x| / sqrt 2)
+  const f32x2 hq = f32x2{0.5f, 0.5f} - q;
+  f32x2 sg;
+  sg[0] = __builtin_copysignf(hq[0], x[0]); sg[1] = __builtin_copysignf(hq[1], x[1]);
+  const f32x2 cdf = f32x2{0.5f, 0.5f} + sg;
+  g = x * cdf;
+  dg = __builtin_elementwise_fma(x * f32x2{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
+}
+// four values at once (a float4 of activations): value back in v, derivative in d
+FNO_DEV void gelu_both4(float4& v, float4& d) {
+  f32x2 g0, g1, d0, d1;
+  gelu_both2(f32x2{v.x, v.y}, g0, d0);
+  gelu_both2(f32x2{v.z, v.w}, g1, d1);
+  v = make_float4(g0[0], g0[1], g1[0], g1[1]);
+  d = make_float4(d0[0], d0[1], d1[0], d1[1]);
+}
+
 // sum over the 32 lanes of each wave half (lanes 0-31 / 32-63); every lane gets its half's sum.
 // 4 DPP adds (quad xor 1, quad xor 2, row_half_mirror, row_mirror) + one cross-row exchange.
 FNO_DEV float dpp_add_(float v, const int ctrl_sel) {

@@ -197,10 +197,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
         if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
         else uv = uq[i];
         if (a.act_in) {
-          gelu_both(uv.x, uv.x, dg[i].x);
-          gelu_both(uv.y, uv.y, dg[i].y);
-          gelu_both(uv.z, uv.z, dg[i].z);
-          gelu_both(uv.w, uv.w, dg[i].w);
+          gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
         }
         put_split4(aimg, TERM, off, uv);
       }
@@ -524,10 +521,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
           if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
           else uv = uq[i];
           if (a.act_in) {
-            gelu_both(uv.x, uv.x, dg[i].x);
-            gelu_both(uv.y, uv.y, dg[i].y);
-            gelu_both(uv.z, uv.z, dg[i].z);
-            gelu_both(uv.w, uv.w, dg[i].w);
+            gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
           }
           put_split4(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv);
         }

@@ -1,0 +1,361 @@
+// Forward of one fused FNO block, second generation (whole rows, 128-pixel tiles).  Same mathematics and arguments as
+// k_pw_fwd_x3 (k_pointwise.h; reference semantics: fno_block.py:123-150 + the last-dim passes of
+// spectral_convolution.py:324,342-345), rebuilt around what bounds that kernel on gfx950: VALU issue, not HBM and not the
+// matrix pipe (2.3 k vector instructions per tile and wave, a third of them address arithmetic, and 1.8 k cycles of fp32
+// MFMAs that execute on the same lanes).
+//   * the tile comes in through BUFFER loads (descriptor + row offset in SGPRs, one 32-bit lane offset) and the output leaves
+//     through buffer stores: no 64-bit per-lane address arithmetic at all;
+//   * the GEMM is computed TRANSPOSED (D[pixel][channel] - the same LDS fragments with the MFMA operands swapped): a lane
+//     owns one output channel and runs of 4 consecutive pixels, so the bias is one register, u leaves as 16-byte stores and
+//     the tile for the row DFT as 16-byte LDS writes;
+//   * the spectral K-extension (the last-dim inverse DFT folded into the GEMM) runs on the bf16 matrix pipe as well: the
+//     inverse table is split once per workgroup, the tile's spectral rows once per tile (a few hundred values), and the
+//     extension becomes one more 16-deep k block of the split-precision GEMM instead of 2 x K2in fp32 MFMAs on the VALU lanes;
+//   * GELU is evaluated on pairs (v_pk_fma_f32 Horner steps, v_med3 clamps: no canonicalisation moves);
+//   * the pixel-major split image is XOR-swizzled instead of padded (48 instead of 55 KB at 64 channels), which pays for the
+//     split tables: two 4-wave workgroups still share a CU.
+// Per tile: commit (GELU, split -> image; spectral rows -> image) | barrier | GEMM + K-extension | barrier | bias, u store,
+// act_out -> fp32 tile | barrier | row DFT of the tile (fp32 MFMA) | barrier.
+#pragma once
+#include "fno_dev.h"
+#include "k_pointwise.h"
+#include <type_traits>
+
+// Pixel-major split image [term][pixel][C x bf16], rows of 2 C bytes, 16-byte chunks XOR-swizzled by the pixel index so that
+// b128 reads with lanes <-> consecutive pixels (one chunk index per wave half) and the b128 writes of the commit (lanes <->
+// consecutive pixels) are bank-conflict-free without row padding.
+template <int C>
+FNO_DEV int pimg_off(int px, int ch) {
+  if constexpr (C == 64) return 128 * px + 16 * (ch ^ ((px >> 1) & 7));
+  else return 64 * px + 16 * (ch ^ ((px >> 2) & 3));
+}
+
+static inline size_t blk_fwd_t_lds_bytes(int c, int W, int K2in, int NJ, bool has_z, bool has_x1) {
+  size_t bytes = (size_t)3 * 128 * c * 2;
+  const size_t out_tile = (size_t)c * (128 + 4) * 4;
+  if (out_tile > bytes) bytes = out_tile;
+  const int KZ = (2 * K2in + 15) / 16;
+  if (has_z) bytes += (size_t)3 * W * KZ * 32 + (size_t)3 * (128 / W) * c * KZ * 32;
+  if (has_x1) bytes += (size_t)16 * NJ * (W + 4) * 4;
+  return bytes;
+}
+
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v.x, v.y, v.z, v.w}), r, voff, soff, 0);
+}
+
+// LIFT: block 0 of a model with a lifting layer: the tile is u_0 = W_l x + b_l of the <= 4-channel model input, computed on
+// commit (k_pointwise.h, LiftSplitTilePrefetch).  RELU: the stored tensor is max(u, 0) (rno.py:92-106 regressor layers).
+// ACT_IN: GELU on load (a.act_in).  EPI: 0 = store only, 1 = store + row DFT of the output, 2 = store + row DFT of gelu(output)
+// (a.x1 / a.act_out).  ADD: a tensor is added to the output before the store (a.add; EPI 0 only).  Compile-time so that the
+// unrolled commit / epilogue bodies carry no per-iteration branches.  KZ: 16-deep k blocks of the spectral extension
+// (0 = no spectral branch, 1 = up to 8 kept last-dim modes, 2 = up to 16).
+template <int C, bool LIFT, bool RELU, bool ACT_IN, int EPI, bool ADD, int KZ>
+__global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a) {
+  static_assert(!(LIFT && ACT_IN) && !(ADD && EPI != 0), "variants");
+  constexpr int NPX = 128, MT = C / 32, NTG = 2, NTW = 2, NW = MT * NTG, NT = NW * 64, KB = C / 16;
+  constexpr int TERM = NPX * C * 2;                      // bytes per term plane of the activation image
+  constexpr int PITCH = NPX + 4;
+  constexpr int ITER = NPX * (C / 8) / NT;               // (pixel, 8-channel group) items per thread: 4
+  constexpr int CGS = NT / NPX;                          // channel groups covered per pass: 2 (C = 64) or 1 (C = 32)
+  static_assert(ITER * NT == NPX * (C / 8) && NT % NPX == 0, "one pixel per thread");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* xb = reinterpret_cast<unsigned char*>(smem);
+  float* xs = smem;                                      // fp32 output tile C x PITCH for the row DFT: reuses the image
+  constexpr size_t REGION = (size_t)3 * TERM > (size_t)C * PITCH * 4 ? (size_t)3 * TERM : (size_t)C * PITCH * 4;
+  const int R = NPX / a.W;
+  const int TT = a.W * KZ * 32, ZT = R * C * KZ * 32;    // bytes per term plane of the table / spectral-row images
+  unsigned char* timg = xb + REGION;                     // [3][W][KZ * 16] bf16: Tinv^T, k = 2 s + (re, im)
+  unsigned char* zimg = timg + 3 * TT;                   // [3][R][C][KZ * 16] bf16: the tile's spectral rows
+  float* tfwd_s = reinterpret_cast<float*>(zimg + 3 * ZT);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave / NTG, ng = wave % NTG;
+  const int opx = tid & (NPX - 1);                       // the pixel this thread stages
+  const int cg0 = __builtin_amdgcn_readfirstlane(tid / NPX);
+  float six, inf;                                        // clamp constants of the packed GELU, kept in SGPRs
+  gelu_consts(six, inf);
+
+  // ---- once per workgroup: tables ------------------------------------------------------------------------------------------
+  if constexpr (KZ > 0) {
+    for (int i = tid; i < 3 * (TT + ZT) / 4; i += NT) reinterpret_cast<unsigned*>(timg)[i] = 0u;   // k pads stay zero
+    __syncthreads();
+    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) {
+      const int k = i / a.W, w = i - k * a.W;
+      unsigned short h, m, l;
+      split3(a.tinv[i], h, m, l);
+      unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * KZ * 16 + k;
+      d[0] = h; d[TT / 2] = m; d[TT] = l;
+    }
+  }
+  if constexpr (EPI != 0)
+    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+
+  // B fragments of the transposed GEMM: B[k = c][n = o] = W[o][c], lane <-> output channel o, split into (h, m, l)
+  const int orow = mt * 32 + l31;
+  bf16x8 wfrag[KB][3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w[orow * C + kb * 16 + 8 * half + j];
+    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+  }
+  // With a row-DFT epilogue (EPI != 0) the accumulators are TRANSPOSED (lane <-> channel, registers <-> 4-pixel runs: one bias
+  // register, 16-byte LDS writes of the tile).  Without one the only consumer is the store, and the plain orientation
+  // (lane <-> pixel, registers <-> channel rows) leaves as whole 128-byte lines per wave half: 118 vs 127 us at config-2 size.
+  constexpr bool TR = EPI != 0;
+  const float bias_o = a.bias ? a.bias[orow] : 0.f;
+  float bias_r[TR ? 1 : 16];
+  if constexpr (!TR) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)] : 0.f;
+  }
+
+  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
+  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
+  __syncthreads();
+
+  const int zc4 = KZ > 0 ? R * a.K2in * C / 2 : 0;          // float4 pieces of one tile's spectral rows
+  const unsigned PWb = (unsigned)a.PW * 4u;              // bytes per channel row
+  float pv[ITER][8];                                     // the NEXT tile, 8 channels of this thread's pixel per item
+  float xin[4];                                          // LIFT: the model input at this thread's pixel
+  constexpr int ZP = 2;                                  // float4 pieces of spectral rows prefetched per thread
+  float4 zpf[ZP];
+  auto issue = [&](int tile) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    if constexpr (LIFT) {
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)b * a.CL * a.PW + px0, (unsigned)(a.CL - 1) * PWb + NPX * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xin[k] = k < a.CL ? buf_ld1(rx, opx * 4, k * PWb) : 0.f;
+    } else {
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)b * C * a.PW + px0, (unsigned)(C - 1) * PWb + NPX * 4);
+      unsigned so = (unsigned)cg0 * 8u * PWb;              // running row offset: one scalar add per load
+#pragma unroll
+      for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pv[i][j] = buf_ld1(rx, opx * 4, so); so += PWb; }
+        so += (unsigned)(CGS - 1) * 8u * PWb;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ZP; ++k)
+      if (tid + k * NT < zc4) zpf[k] = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * (tid + k * NT));
+  };
+  // one float4 of spectral rows = (o, re), (o, im), (o + 1, re), (o + 1, im) of row-mode rs -> k = 2 s, 2 s + 1 of two channels
+  auto put_z = [&](int f, const float4& zq) {
+    const int rs = (4 * f) / (2 * C), o = ((4 * f) % (2 * C)) >> 1;
+    const int row = rs / a.K2in, s = rs - row * a.K2in;
+    unsigned short h[4], m[4], l[4];
+    split3(zq.x, h[0], m[0], l[0]); split3(zq.y, h[1], m[1], l[1]);
+    split3(zq.z, h[2], m[2], l[2]); split3(zq.w, h[3], m[3], l[3]);
+    unsigned char* d = zimg + ((row * C + o) * KZ * 16 + 2 * s) * 2;
+    *reinterpret_cast<unsigned*>(d) = h[0] | ((unsigned)h[1] << 16);
+    *reinterpret_cast<unsigned*>(d + KZ * 32) = h[2] | ((unsigned)h[3] << 16);
+    *reinterpret_cast<unsigned*>(d + ZT) = m[0] | ((unsigned)m[1] << 16);
+    *reinterpret_cast<unsigned*>(d + ZT + KZ * 32) = m[2] | ((unsigned)m[3] << 16);
+    *reinterpret_cast<unsigned*>(d + 2 * ZT) = l[0] | ((unsigned)l[1] << 16);
+    *reinterpret_cast<unsigned*>(d + 2 * ZT + KZ * 32) = l[2] | ((unsigned)l[3] << 16);
+  };
+  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
+
+  // per-lane offsets that do not change from tile to tile
+  // output / addend: row orow (the descriptor starts at row mt * 32), pixels ng * 64 + 4 half ..; the (q, g) part of the
+  // offset is a compile-time constant that lands in the instruction's immediate field.  soffset stays 0 on purpose: with
+  // a REGISTER soffset the compiler assumes there is no "store data overwritten behind a > 8-byte store" hazard and pads
+  // nothing, and on gfx950 that lost 5 % of the outputs when the next float4 was formed in the same registers.
+  const int st_voff = (l31 * a.PW + 4 * half + ng * NTW * 32) * 4;
+
+  // Two workgroups share a CU and run the same phase sequence at the same period: started together they stay in lockstep
+  // (both in their VALU phases, then both on the matrix pipe: SQ_VALU_MFMA_COEXEC_CYCLES ~ 6 % of the matrix-pipe cycles).
+  // The workgroup in the odd wave slot of its SIMDs starts `a.loose` x 2 k cycles late (the field is otherwise unused here).
+  if (a.loose > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID[3:0] = wave slot
+    if (hwid & 1)
+      for (int i = 0; i < a.loose; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  int tslot = 0;
+  FNO_TRACE_IF(true);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / a.tiles_per_plane;
+    const int px0 = (tile % a.tiles_per_plane) * NPX;
+    FNO_STAMP(tslot + 0);
+
+    // ---- commit: (lifting |) GELU, split, pixel-major image; spectral rows -> image -----------------------------------------
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int cg = cg0 + CGS * i;
+      float v[8];
+      if constexpr (LIFT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = cg * 8 + j;
+          const float4 wv = ld4(lws + 4 * c);
+          v[j] = fmaf(wv.w, xin[3], fmaf(wv.z, xin[2], fmaf(wv.y, xin[1], fmaf(wv.x, xin[0], lws[4 * C + c]))));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pv[i][j];
+        if constexpr (ACT_IN) gelu8(v, six, inf);
+      }
+      bf16x8 h, m, l;
+      split3x8(v, h, m, l);
+      unsigned char* dst = xb + pimg_off<C>(opx, cg);
+      *reinterpret_cast<bf16x8*>(dst) = h;
+      *reinterpret_cast<bf16x8*>(dst + TERM) = m;
+      *reinterpret_cast<bf16x8*>(dst + 2 * TERM) = l;
+    }
+#pragma unroll
+    for (int k = 0; k < ZP; ++k)
+      if (tid + k * NT < zc4) put_z(tid + k * NT, zpf[k]);
+    for (int i = tid + ZP * NT; i < zc4; i += NT)        // still more spectral rows (short rows, many modes): straight from L2
+      put_z(i, ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
+    FNO_STAMP(tslot + 1);
+    __syncthreads();
+    FNO_STAMP(tslot + 2);
+
+    // ---- D^T[px][o] = sum_c act[px][c] W[o][c] + sum_k Tinv[k][w(px)] Z[row(px)][k][o] --------------------------------------
+    // Software-pipelined over the k blocks WITHOUT a second fragment buffer: the six products of a block are ordered so that
+    // each term's last use comes early (l: 1st product, m: 2nd + 3rd, h: 4th - 6th) and the term's registers are reloaded with
+    // the NEXT block's fragment right behind it - 3 to 5 MFMAs (100 - 160 cycles) before its first use.  Left to itself the
+    // compiler reads, waits for lgkmcnt(0) and multiplies: three exposed LDS latencies per block, 5.8 k cycles per tile for
+    // 1.9 k cycles of MFMAs.  (sched_group_barrier pins the MFMA / DS-read interleaving.)
+    f32x16 acc[NTW];
+    {
+      auto frag = [&](const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); };
+      auto act_src = [&](int q, int kb) { return xb + pimg_off<C>((ng * NTW + q) * 32 + l31, 2 * kb + half); };
+      bf16x8 a0, a1, a2;                                   // h, m, l terms of the current A fragment
+      {
+        const unsigned char* s0 = act_src(0, 0);
+        a0 = frag(s0); a1 = frag(s0 + TERM); a2 = frag(s0 + 2 * TERM);
+      }
+      auto qtile = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const int n0 = (ng * NTW + q) * 32;
+        f32x16 hi, lo;                                     // hh products / cross terms of the split (fno_dev.h: mfma_x3s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hi[r] = 0.0f; lo[r] = 0.0f; }
+        const unsigned char* tsrc = timg + ((n0 % a.W + l31) * KZ * 16 + 8 * half) * 2;
+        const unsigned char* zsrc = zimg + (((n0 / a.W) * C + orow) * KZ * 16 + 8 * half) * 2;
+        bf16x8 zb[KZ > 0 ? KZ : 1][3];                      // B fragments of the extension blocks: this tile's spectral rows
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) zb[kz][t] = frag(zsrc + t * ZT + kz * 32);
+        // one block: six products against B = (b0, b1, b2); the A terms are replaced by the fragment at `nx` (stride `ns`)
+        auto block = [&](const bf16x8& b0, const bf16x8& b1, const bf16x8& b2, const unsigned char* nx, int ns, auto has_next) {
+          constexpr bool HN = decltype(has_next)::value;
+          // (pixel-side fragment x, channel-side fragment y) -> D^T[px][o] (TR) or D[o][px]: the same registers, swapped operands
+          auto mm = [&](const bf16x8& x, const bf16x8& y, const f32x16& c) {
+            if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
+          };
+          lo = mm(a2, b0, lo);
+          if constexpr (HN) a2 = frag(nx + 2 * ns);
+          lo = mm(a1, b1, lo);
+          lo = mm(a1, b0, lo);
+          if constexpr (HN) a1 = frag(nx + ns);
+          lo = mm(a0, b2, lo);
+          lo = mm(a0, b1, lo);
+          hi = mm(a0, b0, hi);
+          if constexpr (HN) a0 = frag(nx);
+          if constexpr (HN) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        };
+        using yes = std::integral_constant<bool, true>;
+        using no = std::integral_constant<bool, false>;
+        constexpr bool LASTQ = q + 1 == NTW;
+        const unsigned char* qnext = act_src(LASTQ ? q : q + 1, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          if (kb + 1 < KB) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], act_src(q, kb + 1), TERM, yes{});
+          else if constexpr (KZ > 0) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], tsrc, TT, yes{});
+          else if constexpr (!LASTQ) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], qnext, TERM, yes{});
+          else block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], nullptr, 0, no{});
+        }
+#pragma unroll
+        for (int kz = 0; kz < KZ; ++kz) {
+          if (kz + 1 < KZ) block(zb[kz][0], zb[kz][1], zb[kz][2], tsrc + (kz + 1) * 32, TT, yes{});
+          else if constexpr (!LASTQ) block(zb[kz][0], zb[kz][1], zb[kz][2], qnext, TERM, yes{});
+          else block(zb[kz][0], zb[kz][1], zb[kz][2], nullptr, 0, no{});
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = hi[r] + lo[r];
+      };
+      static_assert(NTW == 2, "two 32-pixel column tiles per wave");
+      qtile(std::integral_constant<int, 0>{});
+      qtile(std::integral_constant<int, 1>{});
+    }
+    // the next tile's loads go out behind the GEMM (their 32 registers must not be live beside the weight fragments, the
+    // accumulators and the fragment double buffer); epilogue, row DFT and the other workgroup's phases cover their latency
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    FNO_STAMP(tslot + 3);
+    __syncthreads();        // every wave is done with the images (the fp32 output tile reuses them)
+    FNO_STAMP(tslot + 4);
+
+    // ---- epilogue: bias (+ addend), store, activation -> fp32 tile -------------------------------------------------------------
+    {
+      const size_t obase = ((size_t)b * C + mt * 32) * a.PW + px0;
+      const unsigned obytes = 31u * PWb + NPX * 4;
+      const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u ? a.u + obase : nullptr, a.u ? obytes : 0u);
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(ADD ? a.add + obase : nullptr, ADD ? obytes : 0u);
+      if constexpr (!TR) {
+        // plain orientation: acc[q][r] = channel mt * 32 + 4 half + (r & 3) + 8 (r >> 2), pixel (ng * 2 + q) * 32 + l31:
+        // dword stores, a whole 128-byte line per wave half; the row offset rides in the scalar offset
+        const int vo = (4 * half * a.PW + ng * NTW * 32 + l31) * 4;
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * PWb + q * 128u;
+            float v = acc[q][r] + bias_r[r];
+            if constexpr (ADD) v += buf_ld1(ra, vo, so);
+            if constexpr (RELU) v = v < 0.f ? 0.f : v;      // (NaN stays NaN, as torch's relu)
+            if (a.u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ru, vo, so, 0);
+          }
+        }
+      } else {
+      // (soffset 0 + per-lane voffset: see st_voff - the compiler then pads the store-data hazard itself)
+#pragma unroll
+      for (int q = 0; q < NTW; ++q) {
+        float* xp = xs + orow * PITCH + (ng * NTW + q) * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(acc[q][4 * g] + bias_o, acc[q][4 * g + 1] + bias_o, acc[q][4 * g + 2] + bias_o,
+                                 acc[q][4 * g + 3] + bias_o);
+          if constexpr (ADD) {
+            const float4 ad = buf_ld4(ra, st_voff + (q * 32 + 8 * g) * 4, 0);
+            v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+          }
+          if constexpr (RELU) {      // (NaN stays NaN, as torch's relu)
+            v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+          }
+          if (a.u) buf_st4(ru, st_voff + (q * 32 + 8 * g) * 4, 0, v);
+          if constexpr (EPI != 0) {
+            if constexpr (EPI == 2) v = gelu4(v, six, inf);
+            st4(xp + 8 * g, v);
+          }
+        }
+      }
+      }
+    }
+    FNO_STAMP(tslot + 5);
+    if constexpr (EPI != 0) {
+      __syncthreads();
+      FNO_STAMP(tslot + 6);
+      row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      FNO_STAMP(tslot + 7);
+      __syncthreads();      // the next commit rewrites the images under the tile
+    }
+    tslot += 8;
+  }
+}

@@ -706,6 +706,8 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
   float* b1s = reinterpret_cast<float*>(w1b + (HID / 32) * KB * 3 * 64 * 8);   // HID
   float* w2s = b1s + HID;                                                 // NCO x HID
   float* ysh = w2s + NCO * HID;                                           // NCO x NPX
+  float gk_six, gk_inf;                    // clamp constants of the packed GELU (fno_dev.h), in SGPRs
+  gelu_consts(gk_six, gk_inf);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int hm = wave / NTN, nt = wave % NTN;
@@ -772,11 +774,21 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
       }
       const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
       const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
+      // the hidden activation on pairs (fno_dev.h: gelu_pairs): 16 hidden rows of this lane's pixel
+      f32x2 hp[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        hp[r >> 1][0] = acc[r] + lo[r] + b1p[(r & 3) + 8 * (r >> 2)];
+        hp[r >> 1][1] = acc[r + 1] + lo[r + 1] + b1p[((r + 1) & 3) + 8 * ((r + 1) >> 2)];
+      }
+      if constexpr (RELU) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { hp[k][0] = fmaxf(hp[k][0], 0.f); hp[k][1] = fmaxf(hp[k][1], 0.f); }
+      } else gelu_pairs<8>(hp, gk_six, gk_inf);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ro = (r & 3) + 8 * (r >> 2);
-        const float p1 = acc[r] + lo[r] + b1p[ro];
-        const float gl = RELU ? fmaxf(p1, 0.f) : gelu_f(p1);
+        const float gl = hp[r >> 1][r & 1];
 #pragma unroll
         for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
       }

@@ -186,14 +186,16 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
           const float4 dy4 = ld4(douts + n0 + 8 * i + 4 * half);
           const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
           float dp[4];
+          float4 glv = make_float4(acc[4 * i] + b1v, acc[4 * i + 1] + b1v, acc[4 * i + 2] + b1v, acc[4 * i + 3] + b1v), dgv;
+          if constexpr (RELU) {
+            dgv = make_float4(glv.x > 0.f ? 1.f : 0.f, glv.y > 0.f ? 1.f : 0.f, glv.z > 0.f ? 1.f : 0.f, glv.w > 0.f ? 1.f : 0.f);
+            glv = make_float4(fmaxf(glv.x, 0.f), fmaxf(glv.y, 0.f), fmaxf(glv.z, 0.f), fmaxf(glv.w, 0.f));
+          } else gelu_both4(glv, dgv);          // value and derivative on pairs (fno_dev.h)
+          const float gl4[4] = {glv.x, glv.y, glv.z, glv.w}, dg4[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p1 = acc[4 * i + j] + b1v;
-            float gl, dg;
-            if constexpr (RELU) { gl = fmaxf(p1, 0.f); dg = p1 > 0.f ? 1.f : 0.f; }
-            else gelu_both(p1, gl, dg);
-            dp[j] = dg * (w2v * dyv[j]);
-            sdw = fmaf(gl, dyv[j], sdw);
+            dp[j] = dg4[j] * (w2v * dyv[j]);
+            sdw = fmaf(gl4[j], dyv[j], sdw);
             sdb += dp[j];
           }
           put_split4(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dp[0], dp[1], dp[2], dp[3]));
@@ -271,8 +273,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         for (int i = 0; i < 4; ++i) uq[i] = buf_ld4(rs, (crow * a.PW + n0 + 4 * half) * 4, (px0 + 8 * i) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i].x *= gelu_grad_f(uq[i].x); v[i].y *= gelu_grad_f(uq[i].y);
-          v[i].z *= gelu_grad_f(uq[i].z); v[i].w *= gelu_grad_f(uq[i].w);
+          { float4 uu = uq[i], dd; gelu_both4(uu, dd); v[i].x *= dd.x; v[i].y *= dd.y; v[i].z *= dd.z; v[i].w *= dd.w; }
         }
       }
 #pragma unroll
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         const float4 o = ld4(pq + 8 * i);
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         if (a.act_in) {
-          v.x *= gelu_grad_f(uq[j].x); v.y *= gelu_grad_f(uq[j].y); v.z *= gelu_grad_f(uq[j].z); v.w *= gelu_grad_f(uq[j].w);
+          { float4 uu = uq[j], dd; gelu_both4(uu, dd); v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w; }
         }
         st4(a.gout + ro + 8 * i, v);
         if (a.x1g) st4(r3p + 8 * i, v);

@@ -34,7 +34,7 @@ def _cpu(t):
 
 
 def _load(model, g, dev, complex_names=()):
-    shapes = g["shapes"] if "shapes" in g else {k: v.shape for k, v in g["grads"].items()}
+    shapes = g["shapes"] if "shapes" in g else {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict(rebuild_params(g["scales"], shapes, complex_names=complex_names), strict=True)
     return model.to(dev)
 
