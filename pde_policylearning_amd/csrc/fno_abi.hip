@@ -20,6 +20,7 @@
 #include "k_block_fwd2.h"
 #include "k_projection.h"
 #include "k_projection2.h"
+#include "k_projection_h2.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
 #include "k_pino_loss2.h"
@@ -50,6 +51,9 @@ extern "C" int fno_version(void) { return FNO_VERSION; }
 // GEMM arithmetic of the fused model path: 1 = 3-term bf16 split on the matrix cores (fp32-grade,
 // default), 0 = fp32 MFMA.  FNO_GEMM_F32=1 in the environment selects 0 at load time.
 static int g_gemm_x3 = []() { const char* e = getenv("FNO_GEMM_F32"); return (e && e[0] == '1') ? 0 : 1; }();
+// Two-term fp16 channel GEMMs (fno_dev.h "h2": half the matrix-pipe work of the three-term bf16 split) where a kernel has
+// the variant and its operands' magnitude bounds are known: FNO_NO_H2=1 keeps bf16x3 everywhere (A/B arm)
+static int g_h2 = getenv("FNO_NO_H2") ? 0 : 1;
 extern "C" void fno_set_gemm_mode(int x3) { g_gemm_x3 = x3 ? 1 : 0; }
 extern "C" int fno_get_gemm_mode(void) { return g_gemm_x3; }
 extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
@@ -874,10 +878,13 @@ struct FnoModelPlan {
   int NPX;      // pixels per workgroup tile (128 or 256)
   bool loose;   // rows do not tile the pixel tile (last dim 96, 160, 73, ...): spectral rows gathered per tile, separate row-DFT passes
   mutable bool u0_skipped = false;   // the last forward pass left u_0 (the lifting output) unwritten: block 0 recomputes it
+  mutable bool h2_fwd = false;       // the last forward pass published max |u_L| behind the saved tensors (two-term fp16 projection)
   int ncu;      // compute units of the device the plan was made on
 };
 
 static const int kHID = 256;
+// magnitude bounds kept at the end of the forward's `saved` buffer (fno_dev.h "h2"): [0] max |u_L| (projection input), [1] max |dy|
+static const int kNAmax = 16;
 // persistent-grid size per CU of the forward kernels (= workgroups that fit: registers / LDS)
 #ifndef FNO_GRID_LIFT
 #define FNO_GRID_LIFT 3
@@ -1045,7 +1052,7 @@ extern "C" size_t fno_model_workspace_bytes(const FnoModelPlan* p, int B) {
 }
 extern "C" size_t fno_model_saved_bytes(const FnoModelPlan* p, int B) {
   const ModelSizes s = model_sizes(p, B);
-  return ((size_t)(p->d.n_layers + 1) * s.n_act + (size_t)p->d.n_layers * (s.n_hat + 2 * s.n_wp)) * sizeof(float);
+  return ((size_t)(p->d.n_layers + 1) * s.n_act + (size_t)p->d.n_layers * (s.n_hat + 2 * s.n_wp) + kNAmax) * sizeof(float);
 }
 
 // ---- templated launch dispatch ---------------------------------------------
@@ -1233,6 +1240,11 @@ static int bbwd_ksplit(const FnoModelPlan* p) {
 template <int C, int NCO>
 static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
   // no row structure in the projection: always 128-pixel tiles
+  if (g_gemm_x3 && g_h2 && a.xmax) {
+    const size_t lds = (size_t)2 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 2 * 64 * 16 +
+                       (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
+    return launch("k_proj_fwd", k_proj_fwd_h2<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  }
   if (g_gemm_x3) {
     const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 3 * 64 * 16 +
                        (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
@@ -1265,20 +1277,26 @@ static size_t pbwd_x3_lds(int C, int npx, int nco) {
 }
 // second-generation projection backward (k_projection2.h): C = 64, one output channel, 128-pixel tiles, split-precision mode
 static size_t pbwd_t_lds(int C, const ProjBwdArgs& a) {
-  return (size_t)3 * C * 256 + (size_t)2 * 3 * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
+  const size_t nt = a.amax ? 2 : 3;       // term planes per image
+  return nt * C * 256 + 2 * nt * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
 }
 static bool use_pbwd_t(int C, int CO, int npx) {
   static const int v1 = getenv("FNO_PBWD_V1") ? 1 : 0;        // A/B switch: the first-generation kernel
   return !v1 && g_gemm_x3 && (C == 64 || C == 32) && CO == 1 && npx == 128;
 }
 // W1 -> bf16x3 fragments in the order the selected projection-backward kernel reads them
-static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsigned short* wa3, int HID, int C, bool t_order) {
+static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsigned short* wa3, int HID, int C, bool t_order,
+                      const float* wmax = nullptr) {
   const int nitems = (HID / 32) * (C / 16) * 64 + (HID / 32) * 2 * (C / 32) * 64;
-  if (t_order) return launch("k_pack_w1_x3", k_pack_w1_t, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
+  if (t_order && wmax)      // two fp16 terms (k_proj_bwd_t<.., 2>): scaled by the weights' magnitude bound
+    return launch("k_pack_w1_x3", k_pack_w1_t<2>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
+  if (t_order) return launch("k_pack_w1_x3", k_pack_w1_t<3>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
   return launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
 }
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  if (a.wa1 && a.amax && use_pbwd_t(C, a.CO, p->NPX))      // two fp16 terms: same LDS carve with two planes per image
+    return launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false, 2>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
     return launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
@@ -1338,6 +1356,9 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   float* hats = u + (size_t)(L + 1) * s.n_act;              // hats[l] = hats + l * n_hat
   float* wps = hats + (size_t)L * s.n_hat;                  // packed weights of every layer (kept for backward)
   float* wpts = wps + (size_t)L * s.n_wp;
+  float* amax = wpts + (size_t)L * s.n_wp;                  // kNAmax magnitude bounds (fp16 two-term GEMMs)
+  const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0;
+  if (h2 && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   {
     CornerPtrsL cp;
     memset(&cp, 0, sizeof(cp));
@@ -1401,6 +1422,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     a.act_out = (d.gelu_mask >> l) & 1u;
     a.relu_out = tail && tail->relu_out;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
+    if (h2 && l == L - 1) a.umax = amax;       // the projection scales its fp16 operand by max |u_L|
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
 
@@ -1411,6 +1433,8 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   pa.x = u + (size_t)L * s.n_act; pa.w1 = prm->proj_w1; pa.b1 = prm->proj_b1; pa.w2 = prm->proj_w2; pa.b2 = prm->proj_b2;
   pa.y = y; pa.PW = g.PW; pa.CO = d.Cout; pa.act_in = (d.gelu_mask >> (L - 1)) & 1u;
   pa.tiles_per_plane = g.PW / 128; pa.ntiles = B * pa.tiles_per_plane;
+  pa.xmax = (h2 && L > 0) ? amax : nullptr;
+  p->h2_fwd = pa.xmax != nullptr;
   const int pgrid = std::min(pa.ntiles, FNO_GRID_PF * p->ncu);
   if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, pgrid, pa));
   else LAUNCHCHK(launch_pfwd_c<64>(p, st, pgrid, pa));
@@ -1491,8 +1515,17 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   } else if (!has_proj) {
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
+  // two-term fp16 GEMMs (fno_dev.h "h2") when the forward pass left the bound of |u_L|: bounds of dy and the weights now
+  float* amax = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
+  const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && p->h2_fwd;      // (the last forward published max |u_L|)
+  if (h2) {
+    if (hipMemsetAsync(amax + 1, 0, 3 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
+    LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
+                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, amax + 1));
+    pb.amax = amax;
+  }
   if (g_gemm_x3) {
-    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX)));
+    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? amax + 2 : nullptr));
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;

@@ -268,9 +268,11 @@ FNO_DEV void split3x8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
 }
 // acc += A * B for one 16-deep k block; a[0..2] / b[0..2] = (h, m, l) fragments; small terms first
 FNO_DEV f32x16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+#ifndef FNO_EXP_HALF_MFMA      // (timing experiment: what three instead of six products per k block would buy; results are wrong)
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+#endif
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
@@ -298,15 +300,99 @@ FNO_DEV bf16x8 buf_ld8h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 // result feeds activations or the dx chain uses this form; `hi` may be a long-running accumulator (products of one size
 // class), `lo` is summed into the result once.
 FNO_DEV void mfma_x3s(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+#ifndef FNO_EXP_HALF_MFMA
   lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
   lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
   lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+#endif
   lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
   lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
   hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
 }
 FNO_DEV bf16x8 ld8h(const unsigned short* p) { return *reinterpret_cast<const bf16x8*>(p); }
 FNO_DEV void st8h(unsigned short* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+// ---------------------------------------------------------------------------
+// fp32-grade GEMMs from TWO fp16 terms and THREE products ("h2").  The training step runs at the board's power cap
+// (1400 W, tools/smi_sample.sh): time follows energy, and halving the matrix-pipe work of the split-precision GEMMs took
+// 10 % off the step in a timing experiment (-DFNO_EXP_HALF_MFMA).  x = h + l with h = fp16(s x), l = fp16(s x - h) keeps
+// 22 significant bits when s (a power of two) brings the operand's largest magnitude to 2^13: values above 2^-16 of the
+// maximum keep a relative error of 2^-23, smaller ones an absolute error of 2^-38 of the maximum.  The products hh,
+// hl, lh (ll <= 2^-22) in fp32 accumulators give a GEMM error equal to the fp32 MFMA's own (1.5e-7 at K = 64, measured
+// against fp64 on the host: DESIGN.md section 4d); hh and the cross terms keep separate accumulators as in mfma_x3s.
+// The scale needs a BOUND of the operand's magnitude before it is split: producers publish max |x| of what they store
+// (absmax_publish), weights are scanned by the kernel that splits them, products of known factors use the factors' bounds.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// power of two s with s * amax < 2^13 (amax >= 0; 0 and denormals -> 1)
+FNO_DEV float h2_scale(float amax) {
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);      // amax < 2^(e - 126)
+  int f = 266 - e;                                                              // exponent field of 2^(13 - (e - 126))
+  f = f < 1 ? 1 : (f > 254 ? 254 : f);
+  return e == 0 ? 1.0f : __builtin_bit_cast(float, (unsigned)f << 23);
+}
+FNO_DEV void split2x8(const float (&x)[8], float s, f16x8& h, f16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 v = f32x2{x[j], x[j + 1]} * f32x2{s, s};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f16x2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x2), f16x2);
+    h[j] = hh[0]; h[j + 1] = hh[1]; l[j] = ll[0]; l[j + 1] = ll[1];
+  }
+}
+// acc += A * B for one 16-deep k block; a / b = (h, l) fragments; cross terms first
+FNO_DEV void mfma_h2s(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16& hi, f32x16& lo) {
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], hi, 0, 0, 0);
+}
+FNO_DEV f32x16 mfma_h2(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 acc) {      // one accumulator (weight-gradient GEMMs)
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+// ---- term-count generic forms: NTERM = 3 (bf16, six products) or 2 (fp16 "h2", three products).  Fragments are carried
+// as 8 x 16-bit vectors (bf16x8) either way; the fp16 forms re-type them at the MFMA.
+template <int NTERM>
+FNO_DEV void mfma_split_s(const bf16x8 (&a)[NTERM], const bf16x8 (&b)[NTERM], f32x16& hi, f32x16& lo) {
+  if constexpr (NTERM == 3) mfma_x3s(a, b, hi, lo);
+  else {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, hi, 0, 0, 0);
+  }
+}
+template <int NTERM>
+FNO_DEV f32x16 mfma_split(const bf16x8 (&a)[NTERM], const bf16x8 (&b)[NTERM], f32x16 acc) {
+  if constexpr (NTERM == 3) return mfma_x3(a, b, acc);
+  else {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+  }
+}
+// 8 values -> NTERM fragments (the fp16 form multiplies by `scale` first; the bf16 form ignores it)
+template <int NTERM>
+FNO_DEV void split_n_x8(const float (&x)[8], float scale, bf16x8 (&f)[NTERM]) {
+  if constexpr (NTERM == 3) split3x8(x, f[0], f[1], f[2]);
+  else {
+    f16x8 h, l;
+    split2x8(x, scale, h, l);
+    f[0] = __builtin_bit_cast(bf16x8, h); f[1] = __builtin_bit_cast(bf16x8, l);
+  }
+}
+// max |v| over the wave -> *dst (float bits, atomic max of the non-negative pattern: order-independent, so deterministic)
+FNO_DEV void absmax_publish(float vmax, float* dst) {
+  unsigned u = __builtin_bit_cast(unsigned, vmax) & 0x7fffffffu;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)u, o, 64); u = t > u ? t : u; }
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(dst), u);
+}
 
 // Pixel-major split-precision activation tile in LDS: xb[t][px][c] (t = h, m, l), rows of
 // C + 8 halfs (16-B aligned, b128 reads with lanes <-> pixels are bank-conflict-free).

@@ -44,6 +44,20 @@ FNO_DEV void put_split4(unsigned char* img, int term_bytes, int off, const float
   *reinterpret_cast<uint2*>(img + 2 * term_bytes + off) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
 }
 
+// term-count generic form (fno_dev.h): NTERM = 2 writes the two fp16 terms of scale * t
+template <int NTERM>
+FNO_DEV void put_split4_n(unsigned char* img, int term_bytes, int off, const float4& t, float scale) {
+  if constexpr (NTERM == 3) put_split4(img, term_bytes, off, t);
+  else {
+    const f32x2 v0 = f32x2{t.x, t.y} * f32x2{scale, scale}, v1 = f32x2{t.z, t.w} * f32x2{scale, scale};
+    const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+    const f16x2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2), f16x2);
+    const f16x2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2), f16x2);
+    *reinterpret_cast<uint2*>(img + off) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    *reinterpret_cast<uint2*>(img + term_bytes + off) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+  }
+}
+
 // kext_loose_rows (fno_dev.h) for the transposed accumulator: the table value rides on the A operand (lane <-> pixel), the
 // spectral row on the B operand (lane <-> channel); each lane supplies the same two values as before.
 template <int C>

@@ -172,15 +172,13 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   // nothing, and on gfx950 that lost 5 % of the outputs when the next float4 was formed in the same registers.
   const int st_voff = (l31 * a.PW + 4 * half + ng * NTW * 32) * 4;
 
-  // Two workgroups share a CU and run the same phase sequence at the same period: started together they stay in lockstep
-  // (both in their VALU phases, then both on the matrix pipe: SQ_VALU_MFMA_COEXEC_CYCLES ~ 6 % of the matrix-pipe cycles).
-  // The workgroup in the odd wave slot of its SIMDs starts `a.loose` x 2 k cycles late (the field is otherwise unused here).
-  if (a.loose > 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID[3:0] = wave slot
-    if (hwid & 1)
-      for (int i = 0; i < a.loose; ++i) __builtin_amdgcn_s_sleep(32);
-  }
+#ifdef FNO_ELIM      // phase elimination (tools/bf2_test.hip -DFNO_ELIM, timing only: results are wrong): bits of a.loose switch phases off
+  const int elim = a.loose;
+#else
+  constexpr int elim = 0;
+#endif
   int tslot = 0;
+  float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(true);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
@@ -202,7 +200,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = pv[i][j];
-        if constexpr (ACT_IN) gelu8(v, six, inf);
+        if constexpr (ACT_IN) { if (!(elim & 2)) gelu8(v, six, inf); }
       }
       bf16x8 h, m, l;
       split3x8(v, h, m, l);
@@ -256,20 +254,28 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
             if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
             else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
           };
+#ifndef FNO_EXP_HALF_MFMA
           lo = mm(a2, b0, lo);
+#endif
           if constexpr (HN) a2 = frag(nx + 2 * ns);
+#ifndef FNO_EXP_HALF_MFMA
           lo = mm(a1, b1, lo);
+#endif
           lo = mm(a1, b0, lo);
           if constexpr (HN) a1 = frag(nx + ns);
+#ifndef FNO_EXP_HALF_MFMA
           lo = mm(a0, b2, lo);
+#endif
           lo = mm(a0, b1, lo);
           hi = mm(a0, b0, hi);
           if constexpr (HN) a0 = frag(nx);
+#ifndef FNO_EXP_HALF_MFMA
           if constexpr (HN) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
+#endif
         };
         using yes = std::integral_constant<bool, true>;
         using no = std::integral_constant<bool, false>;
@@ -292,8 +298,15 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
         for (int r = 0; r < 16; ++r) acc[q][r] = hi[r] + lo[r];
       };
       static_assert(NTW == 2, "two 32-pixel column tiles per wave");
-      qtile(std::integral_constant<int, 0>{});
-      qtile(std::integral_constant<int, 1>{});
+      if (!(elim & 1)) {
+        qtile(std::integral_constant<int, 0>{});
+        qtile(std::integral_constant<int, 1>{});
+      } else {
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q][r] = (float)a0[r & 3];
+      }
     }
     // the next tile's loads go out behind the GEMM (their 32 registers must not be live beside the weight fragments, the
     // accumulators and the fragment double buffer); epilogue, row DFT and the other workgroup's phases cover their latency
@@ -321,6 +334,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
             if constexpr (ADD) v += buf_ld1(ra, vo, so);
             if constexpr (RELU) v = v < 0.f ? 0.f : v;      // (NaN stays NaN, as torch's relu)
             if (a.u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ru, vo, so, 0);
+            if (a.umax) vmax = fmaxf(vmax, fabsf(v));
           }
         }
       } else {
@@ -339,9 +353,10 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
           if constexpr (RELU) {      // (NaN stays NaN, as torch's relu)
             v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
           }
-          if (a.u) buf_st4(ru, st_voff + (q * 32 + 8 * g) * 4, 0, v);
+          if (a.u && !(elim & 16)) buf_st4(ru, st_voff + (q * 32 + 8 * g) * 4, 0, v);
+          if (a.umax) vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
           if constexpr (EPI != 0) {
-            if constexpr (EPI == 2) v = gelu4(v, six, inf);
+            if constexpr (EPI == 2) { if (!(elim & 4)) v = gelu4(v, six, inf); }
             st4(xp + 8 * g, v);
           }
         }
@@ -352,10 +367,11 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     if constexpr (EPI != 0) {
       __syncthreads();
       FNO_STAMP(tslot + 6);
-      row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
+      if (!(elim & 8)) row_dft_epilogue<C, NPX, NW>(xs, tfwd_s, a.W + 4, a.x1, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
       FNO_STAMP(tslot + 7);
       __syncthreads();      // the next commit rewrites the images under the tile
     }
     tslot += 8;
   }
+  if (a.umax) absmax_publish(vmax, a.umax);
 }

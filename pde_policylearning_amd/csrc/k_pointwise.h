@@ -49,6 +49,8 @@ struct PwFwdArgs {
   const float* lb;    // ... and bias (C); x is then the (B, CL, PW) model input
   int CL;
   int tiles_per_plane, ntiles;
+  float* umax;        // if set: max |u| of what this launch stores is published here (atomic max of the float pattern; the
+                      // two-term fp16 GEMMs of the consumer scale their operand by it: fno_dev.h, "h2")
 };
 
 // dynamic LDS bytes needed by k_pw_fwd<CIN, COUT, NPX>
@@ -316,6 +318,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
   int tslot = 0;
+  float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(FNO_TRACE_SEL);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
@@ -387,6 +390,10 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
 #pragma unroll
           for (int r = 0; r < 16; ++r) up[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[q][r];
         }
+        if (a.umax) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(acc[q][r]));
+        }
         if (a.x1) {
           if (a.act_out) {
 #pragma unroll
@@ -408,6 +415,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     __syncthreads();
     tslot += 8;
   }
+  if (a.umax) absmax_publish(vmax, a.umax);
 }
 
 // ---------------------------------------------------------------------------

@@ -20,6 +20,7 @@ struct ProjFwdArgs {
   const float* b2;   // (CO)
   float* y;          // (B, CO, PW)
   int PW, CO, act_in, tiles_per_plane, ntiles;
+  const float* xmax; // k_proj_fwd_h2: device scalar, a bound of |x| (published by the kernel that stored x)
 };
 
 constexpr int PROJ_MAXCO = 4;   // largest supported projection output width
@@ -119,6 +120,7 @@ struct ProjBwdArgs {
   float* db1_part;    // (gridDim * NPX/32, HID)
   float* dw2_part;    // (gridDim * NPX/32, CO, HID)
   int PW, W, P, K2out, NJ, CO, act_in, tiles_per_plane, ntiles;
+  const float* amax;  // k_proj_bwd_t<.., 2>: {max |x|, max |dy|, max |W1|, max |w2|} (device scalars)
 };
 
 template <int C, int HID, int NPX>

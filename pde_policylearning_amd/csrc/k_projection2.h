@@ -16,35 +16,55 @@
 
 // W1 (HID, C) fp32 -> bf16x3 fragments for k_proj_bwd_t: wa1 as k_pack_w1_x3; the dx product's B fragments in natural k order
 //   wb3[(((ch*4 + kb)*MT + cb)*3 + t)*64 + lane][j] = term t of W1[ch*64 + kb*16 + 8*(lane>>5) + j][cb*32 + (lane&31)]
+// NTERM = 2: two fp16 terms of h2_scale(*wmax) * W1 (fno_dev.h "h2"; wmax = device scalar max |W1|, k_absmax)
+template <int NTERM>
 __global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
-                            int HID, int C) {
+                            int HID, int C, const float* __restrict__ wmax) {
   const int KB = C / 16, MT = C / 32;
   const int n1 = (HID / 32) * KB * 64, n3 = (HID / 16) * MT * 64;
   const int it = blockIdx.x * blockDim.x + threadIdx.x;
+  const float sw = NTERM == 2 ? h2_scale(*wmax) : 1.f;
   float v[8];
-  bf16x8 h, m, l;
+  bf16x8 f[NTERM];
   if (it < n1) {
     const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
-    split3x8(v, h, m, l);
-    unsigned short* dst = wa1 + ((size_t)((mt * KB + kb) * 3) * 64 + ln) * 8;
-    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
+    split_n_x8<NTERM>(v, sw, f);
+    unsigned short* dst = wa1 + ((size_t)((mt * KB + kb) * NTERM) * 64 + ln) * 8;
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) st8h(dst + t * 64 * 8, f[t]);
   } else if (it < n1 + n3) {
     const int i3 = it - n1;
     const int ln = i3 & 63, cb = (i3 >> 6) % MT, kh = (i3 >> 6) / MT;      // kh = ch*4 + kb: 16-row block of W1
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(kh * 16 + 8 * (ln >> 5) + j) * C + cb * 32 + (ln & 31)];
-    split3x8(v, h, m, l);
-    unsigned short* dst = wb3 + ((size_t)((kh * MT + cb) * 3) * 64 + ln) * 8;
-    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
+    split_n_x8<NTERM>(v, sw, f);
+    unsigned short* dst = wb3 + ((size_t)((kh * MT + cb) * NTERM) * 64 + ln) * 8;
+#pragma unroll
+    for (int t = 0; t < NTERM; ++t) st8h(dst + t * 64 * 8, f[t]);
   }
+}
+// max |x| of three arrays in one launch -> dst[0..2] (atomic max of the float pattern; zeroed by the caller): blocks
+// [0, g0) scan x0, [g0, g0 + g1) x1, the rest x2
+__global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
+                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst) {
+  const int bi = blockIdx.x;
+  const int job = bi < g0 ? 0 : (bi < g0 + g1 ? 1 : 2);
+  const float* x = job == 0 ? x0 : (job == 1 ? x1 : x2);
+  const size_t n = job == 0 ? n0 : (job == 1 ? n1 : n2);
+  const int b0 = job == 0 ? 0 : (job == 1 ? g0 : g0 + g1), nb = job == 0 ? g0 : (job == 1 ? g1 : (int)gridDim.x - g0 - g1);
+  float m = 0.f;
+  for (size_t i = (size_t)(bi - b0) * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+  absmax_publish(m, dst + job);
 }
 
 // C = 32: the dx product's K (hidden rows) is split between the two wave groups (wave (hm, nt) contracts over rows
 // 32 hm .. 32 hm + 31 of every chunk: one channel block, two partial tiles per pixel block, added through LDS once per tile) and
 // a chunk's dW1 (two 32 x 32 tiles) is split over the owner group's four waves by pixel halves (added through LDS at the end).
-template <int C, int HID, bool RELU = false>
+// NT3 = 3: three bf16 terms, six products per k block; NT3 = 2: two fp16 terms, three products (fno_dev.h "h2"), operands
+// scaled by powers of two from a.amax = {max |x|, max |dy|, max |W1|, max |w2|} (device scalars)
+template <int C, int HID, bool RELU = false, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   constexpr int NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32, XI = C / 16;
   static_assert(C == 32 || C == 64, "32 or 64 channels");
@@ -52,11 +72,14 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   constexpr int PITCH = NPX + 4;
   constexpr int ATERM = C * 256, DTERM = 64 * 256;          // bytes per term plane of the a image / one dP1 buffer
   static_assert(NCH % 2 == 0, "two owner groups");
-  static_assert((size_t)64 * PITCH * 4 <= (size_t)3 * DTERM, "the gout tile / the partial-sum exchange alias a dP1 buffer");
+  static_assert((size_t)64 * PITCH * 4 <= (size_t)2 * NT3 * DTERM, "the gout tile / the partial-sum exchange alias the dP1 buffers");
+  // C = 32: the partial-sum exchange [2][32][PITCH] sits at the start of the dP1 buffers, the gout tile behind it
+  constexpr int R3B_OFF = NT3 * DTERM;
+  static_assert(C == 64 || (size_t)2 * 32 * (NT3 == 3 ? PITCH : NPX) * 4 <= (size_t)NT3 * DTERM, "C = 32: the exchange buffer fits dP1 buffer 0");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* aimg = reinterpret_cast<unsigned char*>(smem);             // a = act(u_L): [3][C][128] bf16, swizzled
-  unsigned char* dr0 = aimg + 3 * ATERM;                                     // dP1 chunk, two buffers [3][64][128] bf16, swizzled
-  float* douts = reinterpret_cast<float*>(dr0 + 2 * 3 * DTERM);              // dy row of the tile (NPX)
+  unsigned char* dr0 = aimg + NT3 * ATERM;                                   // dP1 chunk, two buffers [NT3][64][128] x 16 bit, swizzled
+  float* douts = reinterpret_cast<float*>(dr0 + 2 * NT3 * DTERM);            // dy row of the tile (NPX)
   float* r3 = reinterpret_cast<float*>(dr0);                                 // after the chunk loop: gout tile C x PITCH
   float* tfwd_s = douts + NPX;                                               // 16*NJ x (W + 4): forward row table (if x1g)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -72,6 +95,13 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   const int tpx = n0 + 16 * (quad & 1) + 4 * tp;
   const int trow = 8 * (quad >> 1) + tq;
 
+  // operand scales of the fp16 form (powers of two; 1 for bf16x3): a = act(u_L), W1, dP1 = act'(P1) w2 dy
+  float sa = 1.f, sw = 1.f, sd = 1.f;
+  if constexpr (NT3 == 2) {
+    sa = h2_scale(a.amax[0]); sw = h2_scale(a.amax[2]);
+    sd = h2_scale(1.13f * a.amax[3] * a.amax[1]);         // |gelu'| <= 1.13 (ReLU: 1)
+  }
+  const float inv_aw = 1.f / (sa * sw), inv_dw = 1.f / (sd * sw), inv_da = 1.f / (sd * sa);
   f32x16 dw1acc[CPW];
 #pragma unroll
   for (int k = 0; k < CPW; ++k)
@@ -83,14 +113,14 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
 
   // ONE set of weight fragments, time-shared: the recompute's (wa1) during A1, the dx product's (wb3) during A3.  Buffer loads:
   // descriptor + fragment offset in SGPRs, one 32-bit lane offset
-  const __amdgpu_buffer_rsrc_t rs_wa1 = make_rsrc(a.wa1, (unsigned)((HID / 32) * KB * 3 * 64 * 16));
-  const __amdgpu_buffer_rsrc_t rs_wb3 = make_rsrc(a.wa3, (unsigned)((HID / 16) * MT * 3 * 64 * 16));
-  bf16x8 wf[4][3];        // (KB used by the recompute, 4 / 2 by the dx product)
+  const __amdgpu_buffer_rsrc_t rs_wa1 = make_rsrc(a.wa1, (unsigned)((HID / 32) * KB * NT3 * 64 * 16));
+  const __amdgpu_buffer_rsrc_t rs_wb3 = make_rsrc(a.wa3, (unsigned)((HID / 16) * MT * NT3 * 64 * 16));
+  bf16x8 wf[4][NT3];      // (KB used by the recompute, 4 / 2 by the dx product)
   auto load_wa1 = [&](int ch) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) wf[kb][t] = buf_ld8h(rs_wa1, lane * 16, (((ch * 2 + hm) * KB + kb) * 3 + t) * 1024);
+      for (int t = 0; t < NT3; ++t) wf[kb][t] = buf_ld8h(rs_wa1, lane * 16, (((ch * 2 + hm) * KB + kb) * NT3 + t) * 1024);
   };
   constexpr int NK3 = MT == 2 ? 4 : 2;            // 16-row k blocks of the dx product per wave and chunk
   auto load_wb3 = [&](int ch) {
@@ -98,7 +128,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     for (int kk = 0; kk < NK3; ++kk) {
       const int kb = MT == 2 ? kk : 2 * hm + kk, cb = MT == 2 ? hm : 0;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) wf[kk][t] = buf_ld8h(rs_wb3, lane * 16, ((((ch * 4 + kb) * MT + cb) * 3) + t) * 1024);
+      for (int t = 0; t < NT3; ++t) wf[kk][t] = buf_ld8h(rs_wb3, lane * 16, ((((ch * 4 + kb) * MT + cb) * NT3) + t) * 1024);
     }
   };
   // the tile's rows of u_L: thread (c = tid / 32 + 16 i, q = tid % 32) loads 16 bytes; per-sample descriptor
@@ -140,7 +170,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       const int c = (tid >> 5) + 16 * i, q = tid & 31;
       float4 t = xq[i];
       if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
-      put_split4(aimg, ATERM, swz_off(c, q >> 1) + 8 * (q & 1), t);
+      put_split4_n<NT3>(aimg, ATERM, swz_off(c, q >> 1) + 8 * (q & 1), t, sa);
     }
     if (tid < NPX) douts[tid] = a.dy[(size_t)b * a.PW + px0 + tid];
     FNO_STAMP(tslot + 1);
@@ -152,7 +182,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
-      unsigned char* dr = dr0 + (ch & 1) * 3 * DTERM;
+      unsigned char* dr = dr0 + (ch & 1) * NT3 * DTERM;
       // per-lane constants of this chunk: hidden row ch*64 + hm*32 + l31 (L2-resident; used after the recompute)
       const float b1v = a.b1[ch * 64 + hm * 32 + l31], w2v = a.w2[ch * 64 + hm * 32 + l31];
       if (ch == 1) FNO_STAMP(tslot + 3);
@@ -164,16 +194,16 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          bf16x8 af[3];
+          bf16x8 af[NT3];
           const int o0 = swz_off(kb * 16 + trow, tpx >> 3) + 2 * (tpx & 7);
           const int o1 = swz_off(kb * 16 + trow + 4, tpx >> 3) + 2 * (tpx & 7);
 #pragma unroll
-          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(aimg + t * ATERM + o0), lds_tr16(aimg + t * ATERM + o1));
-          mfma_x3s(af, wf[kb], hi, lo);
+          for (int t = 0; t < NT3; ++t) af[t] = cat4(lds_tr16(aimg + t * ATERM + o0), lds_tr16(aimg + t * ATERM + o1));
+          mfma_split_s<NT3>(af, wf[kb], hi, lo);
           __builtin_amdgcn_sched_barrier(0);      // keep at most one k block of operand fragments live
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+        for (int r = 0; r < 16; ++r) acc[r] = NT3 == 2 ? (hi[r] + lo[r]) * inv_aw : hi[r] + lo[r];
       }
       load_wb3(ch);            // the dx product's fragments arrive while the GELU phase runs
       if (ch == 1) FNO_STAMP(tslot + 4);
@@ -198,7 +228,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
             sdw = fmaf(gl4[j], dyv[j], sdw);
             sdb += dp[j];
           }
-          put_split4(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dp[0], dp[1], dp[2], dp[3]));
+          put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dp[0], dp[1], dp[2], dp[3]), sd);
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
@@ -216,13 +246,13 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       {
 #pragma unroll
         for (int kk = 0; kk < NK3; ++kk) {
-          bf16x8 af[3];
+          bf16x8 af[NT3];
           const int kb = MT == 2 ? kk : 2 * hm + kk;       // C = 32: this wave group's half of the chunk's hidden rows
           const int o0 = swz_off(kb * 16 + trow, tpx >> 3) + 2 * (tpx & 7);
           const int o1 = swz_off(kb * 16 + trow + 4, tpx >> 3) + 2 * (tpx & 7);
 #pragma unroll
-          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(dr + t * DTERM + o0), lds_tr16(dr + t * DTERM + o1));
-          mfma_x3s(af, wf[kk], dxh, dxl);
+          for (int t = 0; t < NT3; ++t) af[t] = cat4(lds_tr16(dr + t * DTERM + o0), lds_tr16(dr + t * DTERM + o1));
+          mfma_split_s<NT3>(af, wf[kk], dxh, dxl);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -241,13 +271,13 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         for (int kq = 0; kq < (MT == 2 ? NPX / 16 : NPX / 32); ++kq) {
           const int chn = 2 * (kq + dkh * (NPX / 32)) + half;
           const int od = swz_off(ro, chn), oa = swz_off(rc, chn);
-          bf16x8 af[3], bf[3];
+          bf16x8 af[NT3], bf[NT3];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
+          for (int t = 0; t < NT3; ++t) {
             af[t] = *reinterpret_cast<const bf16x8*>(dr + t * DTERM + od);
             bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * ATERM + oa);
           }
-          dacc = mfma_x3(af, bf, dacc);
+          dacc = mfma_split<NT3>(af, bf, dacc);
         }
         dw1acc[k] = dacc;
           }
@@ -256,6 +286,10 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       if (ch == 1) FNO_STAMP(tslot + 8);
     }
     FNO_STAMP(tslot + 9);
+    if constexpr (NT3 == 2) {      // undo the operand scales of the dx product (exact: powers of two)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dxh[r] *= inv_dw; dxl[r] *= inv_dw; }
+    }
     // ---- epilogue: x act'(u), gout store (before the barrier: the last chunk's dW1 owners are still on the matrix pipe),
     //      then the gout tile for the row DFT ----------------------------------------------------------------------------
     if constexpr (MT == 2) {
@@ -290,17 +324,24 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       // pixel groups i = 2 hm, 2 hm + 1 of its 32 pixels and hands the other two to its partner through dP1 buffer 0 (free
       // since the last chunk's barrier); the gout tile goes to buffer 1 (free behind the barrier below).
       const size_t ro = ((size_t)b * C + l31) * a.PW + px0 + n0 + 4 * half;
-      float* part = reinterpret_cast<float*>(dr0);                       // [hm][32][PITCH]
-      float* r3b = reinterpret_cast<float*>(dr0 + 3 * DTERM);
+      // the exchange buffer [hm][32 rows][128 px] must fit dP1 buffer 0 (the owners of the last chunk still read buffer 1 for
+      // their dW1): rows of PITCH floats with three term planes (48 KB), unpadded rows with the 16-byte pieces XOR-swizzled by
+      // the row with two (32 KB)
+      float* part = reinterpret_cast<float*>(dr0);
+      auto poff = [&](int prow, int col) {      // float offset of (row of the [2 x 32] block, pixel), col % 4 == 0
+        if constexpr (NT3 == 3) return prow * PITCH + col;
+        else return prow * NPX + 4 * ((col >> 2) ^ (prow & 7));
+      };
+      float* r3b = reinterpret_cast<float*>(dr0 + R3B_OFF);
       {
-        float* pp = part + (hm * 32 + l31) * PITCH + n0 + 4 * half;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * (1 - hm) + j;
 #pragma unroll
           for (int ii = 0; ii < 4; ++ii)
-            if (ii == i) st4(pp + 8 * ii, make_float4(dxh[4 * ii] + dxl[4 * ii], dxh[4 * ii + 1] + dxl[4 * ii + 1],
-                                                       dxh[4 * ii + 2] + dxl[4 * ii + 2], dxh[4 * ii + 3] + dxl[4 * ii + 3]));
+            if (ii == i) st4(part + poff(hm * 32 + l31, n0 + 4 * half + 8 * ii),
+                             make_float4(dxh[4 * ii] + dxl[4 * ii], dxh[4 * ii + 1] + dxl[4 * ii + 1],
+                                         dxh[4 * ii + 2] + dxl[4 * ii + 2], dxh[4 * ii + 3] + dxl[4 * ii + 3]));
         }
       }
       float4 uq[2];
@@ -311,7 +352,6 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       }
       FNO_STAMP(tslot + 10);
       __syncthreads();
-      const float* pq = part + ((1 - hm) * 32 + l31) * PITCH + n0 + 4 * half;
       float* r3p = r3b + l31 * PITCH + n0 + 4 * half;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -321,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         for (int ii = 0; ii < 4; ++ii)
           if (ii == i) v = make_float4(dxh[4 * ii] + dxl[4 * ii], dxh[4 * ii + 1] + dxl[4 * ii + 1],
                                        dxh[4 * ii + 2] + dxl[4 * ii + 2], dxh[4 * ii + 3] + dxl[4 * ii + 3]);
-        const float4 o = ld4(pq + 8 * i);
+        const float4 o = ld4(part + poff((1 - hm) * 32 + l31, n0 + 4 * half + 8 * i));
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         if (a.act_in) {
           { float4 uu = uq[j], dd; gelu_both4(uu, dd); v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w; }
@@ -332,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     }
     if (a.x1g) {
       __syncthreads();
-      row_dft_epilogue<C, NPX, 8>(MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + 3 * DTERM), tfwd_s, a.W + 4, a.x1g, b, px0, a.P,
+      row_dft_epilogue<C, NPX, 8>(MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + R3B_OFF), tfwd_s, a.W + 4, a.x1g, b, px0, a.P,
                                   a.W, a.K2out, a.NJ, wave, lane);
       FNO_STAMP(tslot + 11);
       // no barrier here: the gout tile (a dP1 buffer) is rewritten by the next tile's chunks, behind the commit barrier, which
@@ -342,6 +382,12 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   }
 
   // ---- partial slabs ---------------------------------------------------------------------------------------------------------
+  if constexpr (NT3 == 2) {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dw1acc[k][r] *= inv_da;
+  }
   if constexpr (MT == 1) {      // C = 32: add the two pixel halves of every dW1 tile (waves nt, nt ^ 1 of the owner group)
     __syncthreads();
     float* sc = smem;           // [hm][k][dmt][16][64]
