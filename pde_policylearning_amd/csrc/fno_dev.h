@@ -391,7 +391,12 @@ FNO_DEV void absmax_publish(float vmax, float* dst) {
   unsigned u = __builtin_bit_cast(unsigned, vmax) & 0x7fffffffu;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)u, o, 64); u = t > u ? t : u; }
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(dst), u);
+  // same-address atomics serialise at ~12 ns each (32 k of them cost k_lift_rowdft 0.33 ms at 64^3): only a wave that would
+  // raise the published value issues one - a handful per launch once the first waves have finished
+  if ((threadIdx.x & 63) == 0) {
+    unsigned* d = reinterpret_cast<unsigned*>(dst);
+    if (u > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, u);
+  }
 }
 
 // Pixel-major split-precision activation tile in LDS: xb[t][px][c] (t = h, m, l), rows of

@@ -47,6 +47,11 @@ struct BlkBwdArgs {
   int tiles_per_plane, ntiles;
   const unsigned* drop_seed;   // k_block_bwd_t<.., DROPK = true>: the forward's dropout words and rate (fno_dev.h: drop_cfg)
   float drop_p;
+  // two-term fp16 GEMMs (k_block_bwd_t / _g2 with NT3 = 2; fno_dev.h "h2"): device scalars bounding |g| and |u| (|u_0| with a
+  // recomputed lifting); gmax_out (any variant): max |gout| is published there for the next kernel of the chain
+  const float* gmax_in;
+  const float* umax;
+  float* gmax_out;
 };
 
 template <int C, int NPX>

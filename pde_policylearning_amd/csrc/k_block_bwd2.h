@@ -85,8 +85,11 @@ FNO_DEV f32x16 kext_loose_rows_t(f32x16 acc, const float* zs, const float* tinv_
 
 // DROPK: the spectral branch saw drop(x) in the forward pass (rno.py:98): its gradient, the K-extension part of dx, is
 // multiplied by the regenerated dropout scale before the skip branch's W^T g is accumulated on top of it.
-template <int C, int NPX, bool LOOSE = false, bool LIFT = false, bool DROPK = false>
+// NT3: terms of the two channel GEMMs' operands: 3 = bf16 (six products per k block), 2 = fp16 (three; fno_dev.h "h2") with g, a
+// and W scaled by powers of two from a.gmax_in, a.umax and the weights' own maximum.
+template <int C, int NPX, bool LOOSE = false, bool LIFT = false, bool DROPK = false, int NT3 = 3>
 __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(BlkBwdArgs a) {
+  static_assert(!(NT3 == 2 && DROPK), "dropout of the spectral branch: three-term kernel only");
   using Cfg = BlkBwdCfg<C, NPX>;
   static_assert(NPX == 128, "images are 128 pixels wide");
   static_assert(!DROPK || (!LOOSE && !LIFT), "dropout of the spectral branch: whole rows, no lifting");
@@ -99,9 +102,9 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
   static_assert(PXK % 16 == 0, "dW k blocks");
   constexpr int LJ = (C / 16 + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned char* gimg = reinterpret_cast<unsigned char*>(smem);       // g,          [3][C][128] bf16, swizzled
-  unsigned char* aimg = gimg + 3 * TERM;                              // a = act(u), [3][C][128] bf16, swizzled
-  float* r3 = reinterpret_cast<float*>(aimg + 3 * TERM);              // C x PITCH fp32: the gout tile (row DFT / lifting gradients)
+  unsigned char* gimg = reinterpret_cast<unsigned char*>(smem);       // g,          [NT3][C][128] x 16 bit, swizzled
+  unsigned char* aimg = gimg + NT3 * TERM;                            // a = act(u), [NT3][C][128] x 16 bit, swizzled
+  float* r3 = reinterpret_cast<float*>(aimg + NT3 * TERM);            // C x PITCH fp32: the gout tile (row DFT / lifting gradients)
   float* xls = r3 + C * PITCH;                                         // 2 x 8 x PITCH: lifting input rows (block 0), by tile parity
   float* tinv_s = xls + (a.xin ? 2 * 8 * PITCH : 0);
   const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
@@ -128,14 +131,31 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
     return (a.zg && !chunked) ? nrows * a.K2in * C / 2 : 0;
   };
 
-  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i, split into (h, m, l)
-  bf16x8 wfrag[KB][3];
+  // operand scales of the two-term fp16 GEMMs (powers of two; 1 with three bf16 terms)
+  float sg = 1.f, sa = 1.f, sw = 1.f;
+  if constexpr (NT3 == 2) {
+    float mw = 0.f;
+    for (int i = tid; i < C * C; i += NT) mw = fmaxf(mw, fabsf(a.w[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    __shared__ float red[NT / 64];
+    if (lane == 0) red[tid >> 6] = mw;
+    __syncthreads();
+    mw = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) mw = fmaxf(mw, red[k]);
+    sw = h2_scale(mw); sg = h2_scale(*a.gmax_in); sa = h2_scale(*a.umax);
+  }
+  const float inv_gw = 1.f / (sg * sw), inv_ga = 1.f / (sg * sa);
+  float vmax = 0.f;                                     // max |gout| of this thread (a.gmax_out)
+  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i, split into terms
+  bf16x8 wfrag[KB][NT3];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
-    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+    split_n_x8<NT3>(v, sw, wfrag[kb]);
   }
   // LIFT: u_0[px][c] = sum_k x[k][px] Wl[c][k] + bl[c] as fp32 MFMAs; B[k][n = c] with k = half + 2 s, the bias rides on k = CL
   constexpr int NKL = 3;
@@ -206,14 +226,14 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
         const int off = swz_off(crow, (n0 >> 3) + i) + 8 * half;
         const float4 gv = gq[i];
         dbsum[i] += (gv.x + gv.y) + (gv.z + gv.w);
-        put_split4(gimg, TERM, swz_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv);
+        put_split4_n<NT3>(gimg, TERM, swz_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv, sg);
         float4 uv;
         if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
         else uv = uq[i];
         if (a.act_in) {
           gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
         }
-        put_split4(aimg, TERM, off, uv);
+        put_split4_n<NT3>(aimg, TERM, off, uv, sa);
       }
     }
     const int zcount4 = zc4(px0);
@@ -234,13 +254,13 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
       for (int kq = 0; kq < PXK / 16; ++kq) {
         const int ch = dkp * (PXK / 8) + 2 * kq + half;
         const int og = swz_off(ro, ch), oa = swz_off(ri, ch);
-        bf16x8 af[3], bf[3];
+        bf16x8 af[NT3], bf[NT3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NT3; ++t) {
           af[t] = *reinterpret_cast<const bf16x8*>(gimg + t * TERM + og);
           bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * TERM + oa);
         }
-        dwtot = mfma_x3(af, bf, dwtot);
+        dwtot = mfma_split<NT3>(af, bf, dwtot);
       }
     }
     FNO_STAMP(tslot + 3);
@@ -269,15 +289,15 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
       const int orow = 8 * (quad >> 1) + tq;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {      // (full unroll: wfrag must be indexed statically)
-        bf16x8 af[3];
+        bf16x8 af[NT3];
         const int o0 = swz_off(kb * 16 + orow, px >> 3) + 2 * (px & 7);
         const int o1 = swz_off(kb * 16 + orow + 4, px >> 3) + 2 * (px & 7);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
-        mfma_x3s(af, wfrag[kb], hi, lo);
+        for (int t = 0; t < NT3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
+        mfma_split_s<NT3>(af, wfrag[kb], hi, lo);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+      for (int r = 0; r < 16; ++r) acc[r] = NT3 == 2 ? (hi[r] + lo[r]) * inv_gw : hi[r] + lo[r];
     }
     if constexpr (LOOSE) {
       if (a.zg && !chunked) acc = kext_loose_rows_t<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
@@ -316,6 +336,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
         }
         if (a.act_in) { v.x *= dg[i].x; v.y *= dg[i].y; v.z *= dg[i].z; v.w *= dg[i].w; }
         if (a.gout) st4(a.gout + ro + 8 * i, v);
+        if (a.gmax_out) vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
         if (a.x1g || a.xin) st4(r3p + 8 * i, v);
       }
     }
@@ -346,10 +367,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
   }
 
   // ---- write partial slabs ---------------------------------------------------
+  if (a.gmax_out) absmax_publish(vmax, a.gmax_out);
   {
     float* dst = a.dw_part + ((size_t)blockIdx.x * KSPLIT + dkp) * C * C;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dwtot[r];
+    for (int r = 0; r < 16; ++r) dst[(dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = NT3 == 2 ? dwtot[r] * inv_ga : dwtot[r];
   }
   __syncthreads();
 #pragma unroll
@@ -399,11 +421,11 @@ FNO_DEV void group_barrier(unsigned* cnt, unsigned& epoch, int lane) {
 
 // LIFT: block 0 of a model with a lifting layer (u_0 recomputed from the model input, lifting gradients instead of a row DFT);
 // GADD: a gradient addend is added to dx (fan-out chains); NJP: 16-output blocks of the row DFT per wave when a row spans both halves
-template <bool LIFT = false, bool GADD = false, int NJP = 1>
+template <bool LIFT = false, bool GADD = false, int NJP = 1, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   constexpr int C = 64, GPX = 64, KB = C / 16, PITCH = GPX + 4, XPITCH = GPX + 4;
   constexpr int TERM = C * 128;                  // bytes per term plane
-  constexpr int IMG = 3 * TERM;                  // one image
+  constexpr int IMG = NT3 * TERM;                // one image
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep tile / address math scalar
@@ -439,14 +461,31 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   __syncthreads();
   unsigned epoch = 0;
 
-  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i
-  bf16x8 wfrag[KB][3];
+  // operand scales of the two-term fp16 GEMMs (powers of two; 1 with three bf16 terms)
+  float sg = 1.f, sa = 1.f, sw = 1.f;
+  if constexpr (NT3 == 2) {
+    float mw = 0.f;
+    for (int i = tid; i < C * C; i += 512) mw = fmaxf(mw, fabsf(a.w[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    __shared__ float red[8];
+    if (lane == 0) red[tid >> 6] = mw;
+    __syncthreads();
+    mw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mw = fmaxf(mw, red[k]);
+    sw = h2_scale(mw); sg = h2_scale(*a.gmax_in); sa = h2_scale(*a.umax);
+  }
+  const float inv_gw = 1.f / (sg * sw), inv_ga = 1.f / (sg * sa);
+  float vmax = 0.f;                                     // max |gout| of this thread (a.gmax_out)
+  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i, split into terms
+  bf16x8 wfrag[KB][NT3];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
-    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+    split_n_x8<NT3>(v, sw, wfrag[kb]);
   }
   constexpr int NKL = 3;
   float wl[NKL];
@@ -530,14 +569,14 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
         for (int i = 0; i < 4; ++i) {
           const float4 gv = gq[i];
           dbsum[i] += (gv.x + gv.y) + (gv.z + gv.w);
-          put_split4(gimg, TERM, swz64_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv);
+          put_split4_n<NT3>(gimg, TERM, swz64_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), gv, sg);
           float4 uv;
           if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
           else uv = uq[i];
           if (a.act_in) {
             gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
           }
-          put_split4(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv);
+          put_split4_n<NT3>(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv, sa);
         }
       }
       if (h == 0) {
@@ -567,13 +606,13 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
         for (int kq = 0; kq < GPX / 16; ++kq) {
           const int ch = 2 * kq + half;
           const int og = swz64_off(ro, ch), oa = swz64_off(ri, ch);
-          bf16x8 af[3], bf[3];
+          bf16x8 af[NT3], bf[NT3];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
+          for (int t = 0; t < NT3; ++t) {
             af[t] = *reinterpret_cast<const bf16x8*>(gimg + t * TERM + og);
             bf[t] = *reinterpret_cast<const bf16x8*>(aimg + t * TERM + oa);
           }
-          dwtot = mfma_x3(af, bf, dwtot);
+          dwtot = mfma_split<NT3>(af, bf, dwtot);
         }
       }
       FNO_STAMP(tslot + 3);
@@ -588,15 +627,15 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
         const int orow = 8 * (quad >> 1) + tq;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-          bf16x8 af[3];
+          bf16x8 af[NT3];
           const int o0 = swz64_off(kb * 16 + orow, px >> 3) + 2 * (px & 7);
           const int o1 = swz64_off(kb * 16 + orow + 4, px >> 3) + 2 * (px & 7);
 #pragma unroll
-          for (int t = 0; t < 3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
-          mfma_x3s(af, wfrag[kb], hi, lo);
+          for (int t = 0; t < NT3; ++t) af[t] = cat4(lds_tr16(gimg + t * TERM + o0), lds_tr16(gimg + t * TERM + o1));
+          mfma_split_s<NT3>(af, wfrag[kb], hi, lo);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = hi[r] + lo[r];
+        for (int r = 0; r < 16; ++r) acc[r] = NT3 == 2 ? (hi[r] + lo[r]) * inv_gw : hi[r] + lo[r];
       }
       if (a.zg) {      // spectral K-extension: all table / spectrum values of a group of 4 modes are in flight together
         const int pl = 64 * h + n0;                    // position of this wave's 32 pixels in the 128-pixel tile
@@ -642,6 +681,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
 #elif !defined(FNO_EXP_NOSTORE)
           if (a.gout) st4(a.gout + ro + 8 * i, v);
 #endif
+          if (a.gmax_out) vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
           if (LIFT || a.x1g) st4(r3p + 8 * i, v);
         }
       }
@@ -731,10 +771,11 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   }
 
   // ---- partial slabs: one dW slab per group; bias and lifting gradients summed over both groups ---------------------------
+  if (a.gmax_out) absmax_publish(vmax, a.gmax_out);
   {
     float* dst = a.dw_part + ((size_t)blockIdx.x * 2 + grp) * C * C;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row32(r, half)) * C + nt * 32 + l31] = dwtot[r];
+    for (int r = 0; r < 16; ++r) dst[(mt * 32 + acc_row32(r, half)) * C + nt * 32 + l31] = NT3 == 2 ? dwtot[r] * inv_ga : dwtot[r];
   }
   __syncthreads();
 #pragma unroll

@@ -52,8 +52,10 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int 
 // ACT_IN: GELU on load (a.act_in).  EPI: 0 = store only, 1 = store + row DFT of the output, 2 = store + row DFT of gelu(output)
 // (a.x1 / a.act_out).  ADD: a tensor is added to the output before the store (a.add; EPI 0 only).  Compile-time so that the
 // unrolled commit / epilogue bodies carry no per-iteration branches.  KZ: 16-deep k blocks of the spectral extension
-// (0 = no spectral branch, 1 = up to 8 kept last-dim modes, 2 = up to 16).
-template <int C, bool LIFT, bool RELU, bool ACT_IN, int EPI, bool ADD, int KZ>
+// (0 = no spectral branch, 1 = up to 8 kept last-dim modes, 2 = up to 16).  NT3: terms of the channel GEMM's operands: 3 = bf16,
+// six products per k block; 2 = fp16 (fno_dev.h "h2"), three products, the activation scaled by the bound a.xmax of |x|
+// (LIFT: of the model input) and the weights by their own maximum; the spectral extension keeps three bf16 terms.
+template <int C, bool LIFT, bool RELU, bool ACT_IN, int EPI, bool ADD, int KZ, int NT3 = 3>
 __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a) {
   static_assert(!(LIFT && ACT_IN) && !(ADD && EPI != 0), "variants");
   constexpr int NPX = 128, MT = C / 32, NTG = 2, NTW = 2, NW = MT * NTG, NT = NW * 64, KB = C / 16;
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* xb = reinterpret_cast<unsigned char*>(smem);
   float* xs = smem;                                      // fp32 output tile C x PITCH for the row DFT: reuses the image
-  constexpr size_t REGION = (size_t)3 * TERM > (size_t)C * PITCH * 4 ? (size_t)3 * TERM : (size_t)C * PITCH * 4;
+  constexpr size_t REGION = (size_t)NT3 * TERM > (size_t)C * PITCH * 4 ? (size_t)NT3 * TERM : (size_t)C * PITCH * 4;
   const int R = NPX / a.W;
   const int TT = a.W * KZ * 32, ZT = R * C * KZ * 32;    // bytes per term plane of the table / spectral-row images
   unsigned char* timg = xb + REGION;                     // [3][W][KZ * 16] bf16: Tinv^T, k = 2 s + (re, im)
@@ -98,13 +100,47 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
 
   // B fragments of the transposed GEMM: B[k = c][n = o] = W[o][c], lane <-> output channel o, split into (h, m, l)
   const int orow = mt * 32 + l31;
-  bf16x8 wfrag[KB][3];
+  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
+  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
+  // operand scales of the two-term fp16 GEMM (powers of two; 1 with three bf16 terms)
+  float sx = 1.f, sw = 1.f;
+  if constexpr (NT3 == 2) {
+    __shared__ float red[NW];
+    auto wg_max = [&](float m) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      __syncthreads();
+      if (lane == 0) red[wave] = m;
+      __syncthreads();
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) r = fmaxf(r, red[k]);
+      return r;
+    };
+    float mw = 0.f;
+    for (int i = tid; i < C * C; i += NT) mw = fmaxf(mw, fabsf(a.w[i]));
+    sw = h2_scale(wg_max(mw));
+    float bx = *a.xmax;                                    // |x| <= bx; |gelu(x)| <= |x|
+    if constexpr (LIFT) {                                  // |u_0[c]| <= sum_k |lw[c][k]| bx + |lb[c]|
+      float m = 0.f;
+      for (int c = tid; c < C; c += NT) {
+        const float4 wv = ld4(lws + 4 * c);                // (staged above; the first wg_max barrier made it visible)
+        m = fmaxf(m, (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(wv.w)) * bx + fabsf(lws[4 * C + c]));
+      }
+      (void)wg_max(0.f);
+      bx = wg_max(m);
+      if (a.ubound && blockIdx.x == 0 && tid == 0) *a.ubound = bx;      // (the same value in every workgroup) for the backward pass
+    }
+    sx = h2_scale(bx);
+  }
+  const float inv_xw = 1.f / (sx * sw);
+  bf16x8 wfrag[KB][NT3];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = a.w[orow * C + kb * 16 + 8 * half + j];
-    split3x8(v, wfrag[kb][0], wfrag[kb][1], wfrag[kb][2]);
+    split_n_x8<NT3>(v, sw, wfrag[kb]);
   }
   // With a row-DFT epilogue (EPI != 0) the accumulators are TRANSPOSED (lane <-> channel, registers <-> 4-pixel runs: one bias
   // register, 16-byte LDS writes of the tile).  Without one the only consumer is the store, and the plain orientation
@@ -117,8 +153,6 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)] : 0.f;
   }
 
-  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
-  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
   __syncthreads();
 
   const int zc4 = KZ > 0 ? R * a.K2in * C / 2 : 0;          // float4 pieces of one tile's spectral rows
@@ -202,12 +236,11 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
         for (int j = 0; j < 8; ++j) v[j] = pv[i][j];
         if constexpr (ACT_IN) { if (!(elim & 2)) gelu8(v, six, inf); }
       }
-      bf16x8 h, m, l;
-      split3x8(v, h, m, l);
+      bf16x8 f[NT3];
+      split_n_x8<NT3>(v, sx, f);
       unsigned char* dst = xb + pimg_off<C>(opx, cg);
-      *reinterpret_cast<bf16x8*>(dst) = h;
-      *reinterpret_cast<bf16x8*>(dst + TERM) = m;
-      *reinterpret_cast<bf16x8*>(dst + 2 * TERM) = l;
+#pragma unroll
+      for (int t = 0; t < NT3; ++t) *reinterpret_cast<bf16x8*>(dst + t * TERM) = f[t];
     }
 #pragma unroll
     for (int k = 0; k < ZP; ++k)
@@ -219,22 +252,25 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     FNO_STAMP(tslot + 2);
 
     // ---- D^T[px][o] = sum_c act[px][c] W[o][c] + sum_k Tinv[k][w(px)] Z[row(px)][k][o] --------------------------------------
-    // Software-pipelined over the k blocks WITHOUT a second fragment buffer: the six products of a block are ordered so that
-    // each term's last use comes early (l: 1st product, m: 2nd + 3rd, h: 4th - 6th) and the term's registers are reloaded with
-    // the NEXT block's fragment right behind it - 3 to 5 MFMAs (100 - 160 cycles) before its first use.  Left to itself the
-    // compiler reads, waits for lgkmcnt(0) and multiplies: three exposed LDS latencies per block, 5.8 k cycles per tile for
-    // 1.9 k cycles of MFMAs.  (sched_group_barrier pins the MFMA / DS-read interleaving.)
+    // Software-pipelined over the k blocks: the fragments of block k + 1 are read into a SECOND register set while the
+    // products of block k run (left to itself the compiler reads, waits for lgkmcnt(0) and multiplies: three exposed LDS
+    // latencies per block, 5.8 k cycles per tile for 1.9 k cycles of MFMAs).  An earlier version reloaded each term's
+    // registers in place right behind the term's last product; with two workgroups per CU that corrupted single 32 x 32
+    // sub-tiles now and then (an MFMA queued behind the SIMD partner's MFMAs reads its operands later than it issues, and the
+    // LDS data had already landed in them) - so the sets alternate.  sched_group_barrier pins the MFMA / DS-read interleaving.
     f32x16 acc[NTW];
     {
       auto frag = [&](const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); };
       auto act_src = [&](int q, int kb) { return xb + pimg_off<C>((ng * NTW + q) * 32 + l31, 2 * kb + half); };
-      bf16x8 a0, a1, a2;                                   // h, m, l terms of the current A fragment
+      bf16x8 fa[2][3];                                     // two sets of A-fragment terms: (h, m, l) or (h, l, -)
       {
         const unsigned char* s0 = act_src(0, 0);
-        a0 = frag(s0); a1 = frag(s0 + TERM); a2 = frag(s0 + 2 * TERM);
+#pragma unroll
+        for (int t = 0; t < NT3; ++t) fa[0][t] = frag(s0 + t * TERM);
       }
-      auto qtile = [&](auto qc) {
+      auto qtile = [&](auto qc, auto set0) {
         constexpr int q = decltype(qc)::value;
+        constexpr int S0 = decltype(set0)::value;          // the register set that holds this tile's first fragment
         const int n0 = (ng * NTW + q) * 32;
         f32x16 hi, lo;                                     // hh products / cross terms of the split (fno_dev.h: mfma_x3s)
 #pragma unroll
@@ -246,66 +282,103 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
         for (int kz = 0; kz < KZ; ++kz)
 #pragma unroll
           for (int t = 0; t < 3; ++t) zb[kz][t] = frag(zsrc + t * ZT + kz * 32);
-        // one block: six products against B = (b0, b1, b2); the A terms are replaced by the fragment at `nx` (stride `ns`)
-        auto block = [&](const bf16x8& b0, const bf16x8& b1, const bf16x8& b2, const unsigned char* nx, int ns, auto has_next) {
-          constexpr bool HN = decltype(has_next)::value;
+        // One k block with NB terms per operand: A from register set S, channel-side fragments b[]; meanwhile the NEXT
+        // block's fragment (NN terms at `nx`, plane stride `ns`; NN = 0: nothing follows) is read into set 1 - S.
+        auto block = [&](auto sc, auto nbc, auto nnc, const bf16x8* b, const unsigned char* nx, int ns) {
+          constexpr int S = decltype(sc)::value, NB = decltype(nbc)::value, NN = decltype(nnc)::value;
           // (pixel-side fragment x, channel-side fragment y) -> D^T[px][o] (TR) or D[o][px]: the same registers, swapped operands
           auto mm = [&](const bf16x8& x, const bf16x8& y, const f32x16& c) {
-            if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
+            if constexpr (NB == 3) {
+              if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+              else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);
+            } else {
+              const f16x8 xh = __builtin_bit_cast(f16x8, x), yh = __builtin_bit_cast(f16x8, y);
+              if constexpr (TR) return __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, c, 0, 0, 0);
+              else return __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xh, c, 0, 0, 0);
+            }
           };
-#ifndef FNO_EXP_HALF_MFMA
-          lo = mm(a2, b0, lo);
-#endif
-          if constexpr (HN) a2 = frag(nx + 2 * ns);
-#ifndef FNO_EXP_HALF_MFMA
-          lo = mm(a1, b1, lo);
-#endif
-          lo = mm(a1, b0, lo);
-          if constexpr (HN) a1 = frag(nx + ns);
-#ifndef FNO_EXP_HALF_MFMA
-          lo = mm(a0, b2, lo);
-#endif
-          lo = mm(a0, b1, lo);
-          hi = mm(a0, b0, hi);
-          if constexpr (HN) a0 = frag(nx);
-#ifndef FNO_EXP_HALF_MFMA
-          if constexpr (HN) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          const bf16x8 (&cur)[3] = fa[S];
+          bf16x8 (&nxt)[3] = fa[1 - S];
+          if constexpr (NB == 3) {
+            lo = mm(cur[2], b[0], lo);
+            if constexpr (NN >= 1) nxt[0] = frag(nx);
+            lo = mm(cur[1], b[1], lo);
+            lo = mm(cur[1], b[0], lo);
+            if constexpr (NN >= 2) nxt[1] = frag(nx + ns);
+            lo = mm(cur[0], b[2], lo);
+            lo = mm(cur[0], b[1], lo);
+            hi = mm(cur[0], b[0], hi);
+            if constexpr (NN == 3) nxt[2] = frag(nx + 2 * ns);
+            if constexpr (NN == 3) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          } else {
+            lo = mm(cur[1], b[0], lo);
+            if constexpr (NN >= 1) nxt[0] = frag(nx);
+            lo = mm(cur[0], b[1], lo);
+            if constexpr (NN >= 2) nxt[1] = frag(nx + ns);
+            hi = mm(cur[0], b[0], hi);
+            if constexpr (NN == 3) nxt[2] = frag(nx + 2 * ns);
+            if constexpr (NN == 2) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
           }
-#endif
         };
-        using yes = std::integral_constant<bool, true>;
-        using no = std::integral_constant<bool, false>;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I3 = std::integral_constant<int, 3>;
+        using IT = std::integral_constant<int, NT3>;
         constexpr bool LASTQ = q + 1 == NTW;
         const unsigned char* qnext = act_src(LASTQ ? q : q + 1, 0);
+        // block j of this tile (j = 0 .. KB + KZ - 1) reads set (S0 + j) % 2
+        auto run = [&](auto jc, auto nbc, auto nnc, const bf16x8* b, const unsigned char* nx, int ns) {
+          constexpr int J = decltype(jc)::value;
+          if constexpr ((S0 + J) % 2 == 0) block(I0{}, nbc, nnc, b, nx, ns);
+          else block(I1{}, nbc, nnc, b, nx, ns);
+        };
+        auto act_blocks = [&](auto self, auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+          if constexpr (kb < KB) {
+            using J = std::integral_constant<int, kb>;
+            if constexpr (kb + 1 < KB) run(J{}, IT{}, IT{}, wfrag[kb], act_src(q, kb + 1), TERM);
+            else if constexpr (KZ > 0) run(J{}, IT{}, I3{}, wfrag[kb], tsrc, TT);
+            else if constexpr (!LASTQ) run(J{}, IT{}, IT{}, wfrag[kb], qnext, TERM);
+            else run(J{}, IT{}, I0{}, wfrag[kb], nullptr, 0);
+            self(self, std::integral_constant<int, kb + 1>{});
+          }
+        };
+        act_blocks(act_blocks, I0{});
+        if constexpr (NT3 == 2) {      // undo the operand scales (exact) before the unscaled extension products are added
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          if (kb + 1 < KB) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], act_src(q, kb + 1), TERM, yes{});
-          else if constexpr (KZ > 0) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], tsrc, TT, yes{});
-          else if constexpr (!LASTQ) block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], qnext, TERM, yes{});
-          else block(wfrag[kb][0], wfrag[kb][1], wfrag[kb][2], nullptr, 0, no{});
+          for (int r = 0; r < 16; ++r) { hi[r] = (hi[r] + lo[r]) * inv_xw; lo[r] = 0.f; }
         }
-#pragma unroll
-        for (int kz = 0; kz < KZ; ++kz) {
-          if (kz + 1 < KZ) block(zb[kz][0], zb[kz][1], zb[kz][2], tsrc + (kz + 1) * 32, TT, yes{});
-          else if constexpr (!LASTQ) block(zb[kz][0], zb[kz][1], zb[kz][2], qnext, TERM, yes{});
-          else block(zb[kz][0], zb[kz][1], zb[kz][2], nullptr, 0, no{});
-        }
+        auto ext_blocks = [&](auto self, auto kzc) {
+          constexpr int kz = decltype(kzc)::value;
+          if constexpr (kz < KZ) {
+            using J = std::integral_constant<int, KB + kz>;
+            if constexpr (kz + 1 < KZ) run(J{}, I3{}, I3{}, zb[kz], tsrc + (kz + 1) * 32, TT);
+            else if constexpr (!LASTQ) run(J{}, I3{}, IT{}, zb[kz], qnext, TERM);
+            else run(J{}, I3{}, I0{}, zb[kz], nullptr, 0);
+            self(self, std::integral_constant<int, kz + 1>{});
+          }
+        };
+        ext_blocks(ext_blocks, I0{});
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = hi[r] + lo[r];
       };
       static_assert(NTW == 2, "two 32-pixel column tiles per wave");
       if (!(elim & 1)) {
-        qtile(std::integral_constant<int, 0>{});
-        qtile(std::integral_constant<int, 1>{});
+        qtile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        qtile(std::integral_constant<int, 1>{}, std::integral_constant<int, (KB + KZ) % 2>{});      // q = 0 left its successor's first fragment there
       } else {
 #pragma unroll
         for (int q = 0; q < NTW; ++q)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[q][r] = (float)a0[r & 3];
+          for (int r = 0; r < 16; ++r) acc[q][r] = (float)fa[0][0][r & 3];
       }
     }
     // the next tile's loads go out behind the GEMM (their 32 registers must not be live beside the weight fragments, the

@@ -49,6 +49,8 @@ struct PwFwdArgs {
   const float* lb;    // ... and bias (C); x is then the (B, CL, PW) model input
   int CL;
   int tiles_per_plane, ntiles;
+  const float* xmax;  // k_blk_fwd_t<.., NT3 = 2>: device scalar, a bound of |x| (of the model input with a fused lifting)
+  float* ubound;      // k_blk_fwd_t<LIFT, NT3 = 2>: the bound of |u_0| it derived from xmax and the lifting parameters is left here
   float* umax;        // if set: max |u| of what this launch stores is published here (atomic max of the float pattern; the
                       // two-term fp16 GEMMs of the consumer scale their operand by it: fno_dev.h, "h2")
 };
@@ -429,7 +431,7 @@ constexpr int LR_ROWS = 8;
 __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x, const float* __restrict__ lw,
                                                      const float* __restrict__ lb, const float* __restrict__ tfwd,
                                                      float2* __restrict__ x1, int CL, int C, int PW, int W, int P, int K2,
-                                                     int nrows) {
+                                                     int nrows, float* __restrict__ xmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int WP = W + 1;                               // row pitch: threads of a wave read different rows at the same w
   float* ts = smem;                                   // [2 K2][WP]
@@ -438,6 +440,7 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * LR_ROWS;              // rows are (b, prow) pairs, b-major
   const int nr = min(LR_ROWS, nrows - row0);
+  float vmax = 0.f;
   // (loops over whole rows per wave: no per-element index divisions)
   for (int j = wave; j < 2 * K2; j += 4)
     for (int w = lane; w < W; w += 64) ts[j * WP + w] = tfwd[j * W + w];
@@ -446,7 +449,19 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
     const int row = row0 + r;
     const int b = row / P, prow = row - b * P;
     const float* src = x + ((size_t)b * CL + k) * PW + (size_t)prow * W;
-    for (int w = lane; w < W; w += 64) xs[rk * WP + w] = r < nr ? src[w] : 0.f;
+    for (int w = lane; w < W; w += 64) {
+      const float xv = r < nr ? src[w] : 0.f;
+      xs[rk * WP + w] = xv;
+      vmax = fmaxf(vmax, fabsf(xv));
+    }
+  }
+  if (xmax) {      // max |x| of the model input (bound for the fused block 0's fp16 operand scale): one publish per workgroup
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    __shared__ float wmax[4];
+    if (lane == 0) wmax[wave] = vmax;
+    __syncthreads();
+    if (wave == 0) absmax_publish(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), xmax);
   }
   __syncthreads();
   for (int i = tid; i < LR_ROWS * K2 * (CL + 1); i += 256) {

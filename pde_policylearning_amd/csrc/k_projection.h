@@ -120,7 +120,9 @@ struct ProjBwdArgs {
   float* db1_part;    // (gridDim * NPX/32, HID)
   float* dw2_part;    // (gridDim * NPX/32, CO, HID)
   int PW, W, P, K2out, NJ, CO, act_in, tiles_per_plane, ntiles;
-  const float* amax;  // k_proj_bwd_t<.., 2>: {max |x|, max |dy|, max |W1|, max |w2|} (device scalars)
+  const float* amax;  // k_proj_bwd_t<.., 2>: {-, max |dy|, max |W1|, max |w2|} (device scalars)
+  const float* xmax;  // ... and the bound of |x| the forward pass published
+  float* gmax_out;    // k_proj_bwd_t: max |gout| is published here (bound for the next kernel's fp16 operand scale)
 };
 
 template <int C, int HID, int NPX>

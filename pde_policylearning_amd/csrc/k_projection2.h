@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   // operand scales of the fp16 form (powers of two; 1 for bf16x3): a = act(u_L), W1, dP1 = act'(P1) w2 dy
   float sa = 1.f, sw = 1.f, sd = 1.f;
   if constexpr (NT3 == 2) {
-    sa = h2_scale(a.amax[0]); sw = h2_scale(a.amax[2]);
+    sa = h2_scale(*a.xmax); sw = h2_scale(a.amax[2]);
     sd = h2_scale(1.13f * a.amax[3] * a.amax[1]);         // |gelu'| <= 1.13 (ReLU: 1)
   }
   const float inv_aw = 1.f / (sa * sw), inv_dw = 1.f / (sd * sw), inv_da = 1.f / (sd * sa);
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   float sdb1[NCH], sdw2[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) { sdb1[ch] = 0.f; sdw2[ch] = 0.f; }
+  float gvmax = 0.f;      // max |gout| of this thread (a.gmax_out)
 
   // ONE set of weight fragments, time-shared: the recompute's (wa1) during A1, the dx product's (wb3) during A3.  Buffer loads:
   // descriptor + fragment offset in SGPRs, one 32-bit lane offset
@@ -312,6 +313,10 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) st4(a.gout + ro + 8 * i, v[i]);
+      if (a.gmax_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gvmax = fmaxf(fmaxf(gvmax, fabsf(v[i].x)), fmaxf(fmaxf(fabsf(v[i].y), fabsf(v[i].z)), fabsf(v[i].w)));
+      }
       FNO_STAMP(tslot + 10);
       __syncthreads();       // every wave is done with dP1 buffer 0 (= r3) and with the a image
       if (a.x1g) {
@@ -367,6 +372,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
           { float4 uu = uq[j], dd; gelu_both4(uu, dd); v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w; }
         }
         st4(a.gout + ro + 8 * i, v);
+        if (a.gmax_out) gvmax = fmaxf(fmaxf(gvmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
         if (a.x1g) st4(r3p + 8 * i, v);
       }
     }
@@ -382,6 +388,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   }
 
   // ---- partial slabs ---------------------------------------------------------------------------------------------------------
+  if (a.gmax_out) absmax_publish(gvmax, a.gmax_out);
   if constexpr (NT3 == 2) {
 #pragma unroll
     for (int k = 0; k < CPW; ++k)

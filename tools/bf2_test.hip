@@ -37,12 +37,14 @@ static void run(int B, int W, int K2, int reps) {
   a.PW = PW; a.W = W; a.P = P; a.K2in = K2; a.K2out = K2; a.NJ = NJ; a.act_in = AIN; a.act_out = EPI == 2;
   a.tiles_per_plane = PW / 128; a.ntiles = B * a.tiles_per_plane;
   a.loose = getenv("STAG") ? atoi(getenv("STAG")) : 0;
+  { float mx = 0.f; for (auto v : x) mx = std::max(mx, std::fabs(v)); std::vector<float> m1(4, mx); a.xmax = dev(m1); std::vector<float> z4(4, 0.f); a.umax = dev(z4); a.ubound = a.umax + 2; }
   if (LIFT) { a.lw = dev(lw); a.lb = dev(lb); a.CL = CL; }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
   const size_t lds_old = pw_fwd_x3_lds_bytes(C, 128, W, K2, NJ, true, EPI != 0), lds_new = blk_fwd_t_lds_bytes(C, W, K2, NJ, true, EPI != 0);
   auto kold = k_pw_fwd_x3<C, 128, 2, false, LIFT, false>;
-  auto knew = K2 <= 8 ? k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 1> : k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 2>;
+  auto knew = getenv("H2") ? (K2 <= 8 ? k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 1, 2> : k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 2, 2>)
+                           : (K2 <= 8 ? k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 1> : k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 2>);
   CK(hipFuncSetAttribute((const void*)kold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
   CK(hipFuncSetAttribute((const void*)knew, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
   const int nthr = (C / 32) * 2 * 64;
