@@ -36,7 +36,8 @@ CONFIGS = {
     # legs, kernel model at their own batch / plane size).
     "rno2d_128x128_w64_m12_b32": dict(kind="rno2d", batch=32, size=(128, 128)),            # cfg 3 as named (256 / 8 GPUs)
     "rno2d_32x32_w34_m12_b32": dict(kind="rno2d_shipped", batch=32, size=(32, 32), graph=True),   # configs/matlab_rno.yaml values; launch-bound
-    "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32)),     # the YAML's active model
+    # the YAML's active model; launch-bound since its optimizer skips the dead weight slices (round 3): hipGraph replay
+    "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32), graph=True),
     # the same model with the loop's loss: decode + LpLoss on the planes + pde_loss_weight 1.0 * channel-flow term (matlab_rno.yaml:56,62)
     "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32)),
     "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
@@ -371,7 +372,8 @@ def main():
         # (PINObserverFullField at T = 1: 11/12 of 906 MB) are never exchanged.  Single GPU: the plan is only reported.
         from pde_policylearning_amd.trainer import enable_dp_exchange
         enable_dp_exchange(bucket, model, tuple(t[:1] for t in inputs))
-    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph)       # run_pde_observers.py:134
+    # run_pde_observers.py:134; dead last-dim slices of dialect-C weights replayed instead of stepped (as train_observer does)
+    opt = FusedAdam(bucket, lr=1e-3, weight_decay=1e-4, capturable=args.graph, skip_dead_slices=True)
     loss_fn = FusedLpLoss(size_average=False)                  # run_pde_observers.py:138
     if cfg["kind"] == "pino2d_train":
         from pde_policylearning_amd.libs.pino_utils.losses import get_forcing
@@ -382,6 +384,7 @@ def main():
         from pde_policylearning_amd.libs.envs.control_env import ChannelFlowRHS
         from pde_policylearning_amd.trainer import FullFieldObjective, MeanStdDecoder
         env = ChannelFlowRHS.tanh_channel(32, 130, 32)
+        gen = torch.Generator(device="cpu").manual_seed(4321 + rank)
         rnd = lambda *sh: torch.randn(sh, generator=gen).to(dev)
         decoder = MeanStdDecoder(0.1 * rnd(32, 32), 0.5 + torch.rand((32, 32), generator=gen).to(dev), device=dev)
         loss_fn = FullFieldObjective(decoder, [-10, -8, -6], env, 1.0)

@@ -73,6 +73,12 @@ typedef struct FnoSpecDesc {
   int input_gelu;          /* 1: the input is a PRE-activation tensor u and the convolution acts on gelu(u) (applied while
                               the rows are staged; <= 64 channels, rows <= 320 floats, <= 32 kept last-dim bins).  backward
                               then returns dL/d gelu(u); the caller (fno_pointwise_backward) applies gelu'(u). */
+  int weight_planes;       /* 1: the corner weights (and their gradients) are stored PLANE-MAJOR - the memory order is
+                              (weight_last_extent, Cin, Cout, modes[0], [modes[1]]), i.e. the reference's tensor permuted so
+                              that its last dim is outermost.  The live last-dim slices [0, modes[ndim-1]) of a dialect-C
+                              weight are then one contiguous prefix (what the layout kernels, the optimizer and the gradient
+                              exchange touch: PINObserverFullField at T = 1 uses 1 plane of 12).  fno_spec_backward then
+                              writes the live planes of dw_corners only: the caller keeps the others zero. */
 } FnoSpecDesc;
 
 typedef struct FnoSpecPlan FnoSpecPlan;
@@ -112,6 +118,7 @@ typedef struct FnoModelDesc {
   int modes[3];        /* kept per corner per dim = n_modes[d] // 2 (spectral_convolution.py:202-203) */
   int norm;            /* FNO_NORM_* (FNO default: FORWARD) */
   unsigned gelu_mask;  /* bit l set <=> GELU after block l (fno_block.py:149) */
+  int weight_planes;   /* 1: spec_w tensors (and their gradients) are stored plane-major, see FnoSpecDesc */
 } FnoModelDesc;
 
 typedef struct FnoModelParams {       /* all fp32 device pointers, reference parameter layouts */
@@ -226,14 +233,42 @@ int fno_lploss_rel_backward(int batch, size_t n_per_sample, const float* pred, c
                             size_t ws_bytes, void* stream);
 /* torch.optim.Adam (run_pde_observers.py:134: lr, weight_decay as L2 added to the gradient; no amsgrad)
  * on ONE flat fp32 bucket of n elements: param / grad / exp_avg / exp_avg_sq, 16-byte aligned.
- * `step` is the 1-based step count (bias corrections are computed on the host in double). */
-int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, void* stream);
+ * `step` is the 1-based step count.  The hyperparameters are DOUBLES, as torch.optim.Adam holds them: step size, bias
+ * corrections and the (1 - beta) weights are formed in double and rounded once, as torch's scalar arguments are
+ * (1.0f - 0.999f is 1.3e-5 away from the 0.001 torch hands to addcmul_). */
+int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, void* stream);
 /* Same update with the step count on the DEVICE: *step_counter is incremented and the bias corrections are
  * derived from it by a one-thread kernel, so a captured hipGraph of the whole training step can be
  * replayed (no host-side scalar changes between replays).  scratch2: two device floats. */
-int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                      float beta2, float eps, float weight_decay, int* step_counter, float* scratch2, void* stream);
+int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                      double beta2, double eps, double weight_decay, int* step_counter, float* scratch2, void* stream);
+/* The same update for a bucket that holds dialect-C spectral weights of which only the last-dim slice [..., :k] ever sees
+ * data (libs/models/pino_models/basics.py:119-139 cuts the spectrum at min(Nz/2+1, modes3): PINObserverFullField at T = 1
+ * uses 1/12 of its 906 MB).  The gradient of the rest is exactly zero, so what torch.optim.Adam (run_pde_observers.py:134)
+ * does to such an element is a recurrence on (p, m, v) alone - g = weight_decay * p.  It is skipped per step and REPLAYED in
+ * one pass when the slice is needed; results are bit-identical to stepping it every time.
+ *   A sliced block is rows x row_len floats, the first live_len floats of each row live (both even: complex pairs);
+ *   a plane-major weight (FnoSpecDesc.weight_planes) is ONE row whose live planes are its head.
+ *   fno_adam_step_range: fno_adam_step on a sub-range; `dyn` (device, 2 floats: fno_adam_prep_dev) replaces `step`.
+ *   fno_adam_prep_dev:   ++*step_counter and the step's two scalars into scratch2 (graph-replayable, once per step).
+ *   fno_adam_step_live:  the live part of a block; param / grad in the full layout, moments compact (rows x live_len).
+ *   fno_adam_scalars:    host: {lr / (1 - beta1^step), sqrt(1 - beta2^step)} exactly as fno_adam_step derives them.
+ *   fno_adam_replay_prep: the same two scalars for steps step_from .. step_from + nsteps - 1 on the device
+ *                        (scal: 2 * nsteps floats), as fno_adam_step_dev derives them.
+ *   fno_adam_replay_dead: takes the dead part of a block through the nsteps steps described by `scal`; dead moments
+ *                        compact (rows x (row_len - live_len)), read unless moments_zero, always written. */
+void fno_adam_scalars(double lr, double beta1, double beta2, int step, float* out2);
+int fno_adam_prep_dev(int* step_counter, float* scratch2, double lr, double beta1, double beta2, void* stream);
+int fno_adam_step_range(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, int step, const float* dyn, void* stream);
+int fno_adam_step_live(size_t rows, int row_len, int live_len, float* param, const float* grad, float* exp_avg_live,
+                       float* exp_avg_sq_live, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                       const float* dyn, void* stream);
+int fno_adam_replay_prep(float* scal, int step_from, int nsteps, double lr, double beta1, double beta2, void* stream);
+int fno_adam_replay_dead(size_t rows, int row_len, int live_len, float* param, float* dead_exp_avg, float* dead_exp_avg_sq,
+                         int moments_zero, const float* scal, int nsteps, double beta1, double beta2, double eps,
+                         double weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------
  * PINO residual loss, SURVEY.md section 8(f) rank 1: FDM_NS_vorticity + Channelflow_PINO_loss
@@ -263,18 +298,19 @@ int fno_pino_loss_backward(int batch, int n, int nt, const float* u, const float
  *                h_new = (1 - z) * h + z2 * selu(s3)                                     (:254-255, :257-260)
  * a_i = f_i(.) are the cell's Fourier layers.  backward returns the gradient of each pre-activation sum
  * (shared by its two addends), the direct gradient to h, and fno_rno_gate_partials() per-workgroup partial
- * sums of every bias gradient (reset: [P]; output: [3][P] for b1, b4, b3) to be summed by the caller.
+ * sums of every bias gradient (reset: [P]; output: [3][P] for b1, b4, b3), accumulated and stored in DOUBLE
+ * (tens of millions of terms of either sign per scalar), to be summed by the caller.
  * ---------------------------------------------------------------------- */
 int fno_rno_gate_partials(void);
 int fno_rno_reset_gate_forward(size_t n, const float* a3, const float* a4, const float* b2, const float* h, float* r,
                                float* rh, void* stream);
 int fno_rno_reset_gate_backward(size_t n, const float* d_rh, const float* r, const float* h, float* d_s, float* d_h,
-                                float* db_partials, void* stream);
+                                double* db_partials, void* stream);
 int fno_rno_output_gate_forward(size_t n, const float* a1, const float* a2, const float* b1, const float* a7,
                                 const float* a8, const float* b4, const float* a5, const float* a6, const float* b3,
                                 const float* h, float* z, float* z2, float* s3, float* h_new, void* stream);
 int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const float* z2, const float* s3,
-                                 const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h, float* db_partials,
+                                 const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h, double* db_partials,
                                  void* stream);
 
 /* ------------------------------------------------------------------------

@@ -19,14 +19,15 @@ c_float_p = C.POINTER(C.c_float)
 class FnoSpecDesc(C.Structure):
     _fields_ = [("ndim", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("dims", C.c_int * 3), ("modes", C.c_int * 3),
-                ("weight_last_extent", C.c_int), ("norm", C.c_int), ("input_gelu", C.c_int)]
+                ("weight_last_extent", C.c_int), ("norm", C.c_int), ("input_gelu", C.c_int),
+                ("weight_planes", C.c_int)]
 
 
 class FnoModelDesc(C.Structure):
     _fields_ = [("ndim", C.c_int), ("Cin", C.c_int), ("C", C.c_int), ("Cout", C.c_int),
                 ("hidden_proj", C.c_int), ("n_layers", C.c_int),
                 ("dims", C.c_int * 3), ("modes", C.c_int * 3),
-                ("norm", C.c_int), ("gelu_mask", C.c_uint)]
+                ("norm", C.c_int), ("gelu_mask", C.c_uint), ("weight_planes", C.c_int)]
 
 
 class FnoBlockTail(C.Structure):        # include/fnoengine.h: one-layer block stacks with a tail (RNO regressor layers)
@@ -104,8 +105,16 @@ def lib():
     L.fno_lploss_workspace_bytes.restype = sz
     L.fno_lploss_rel_forward.argtypes = [ci, sz, vp, vp, vp, vp, ci, fl, ci, vp, vp, sz, vp]
     L.fno_lploss_rel_backward.argtypes = [ci, sz, vp, vp, vp, ci, fl, vp, vp, vp, sz, vp]
-    L.fno_adam_step.argtypes = [sz, vp, vp, vp, vp, fl, fl, fl, fl, fl, ci, vp]
-    L.fno_adam_step_dev.argtypes = [sz, vp, vp, vp, vp, fl, fl, fl, fl, fl, vp, vp, vp]
+    db = C.c_double       # Adam hyperparameters cross the ABI as the doubles torch.optim.Adam holds
+    L.fno_adam_step.argtypes = [sz, vp, vp, vp, vp, db, db, db, db, db, ci, vp]
+    L.fno_adam_step_dev.argtypes = [sz, vp, vp, vp, vp, db, db, db, db, db, vp, vp, vp]
+    L.fno_adam_scalars.argtypes = [db, db, db, ci, vp]
+    L.fno_adam_scalars.restype = None
+    L.fno_adam_prep_dev.argtypes = [vp, vp, db, db, db, vp]
+    L.fno_adam_step_range.argtypes = [sz, vp, vp, vp, vp, db, db, db, db, db, ci, vp, vp]
+    L.fno_adam_step_live.argtypes = [sz, ci, ci, vp, vp, vp, vp, db, db, db, db, db, ci, vp, vp]
+    L.fno_adam_replay_prep.argtypes = [vp, ci, ci, db, db, db, vp]
+    L.fno_adam_replay_dead.argtypes = [sz, ci, ci, vp, vp, vp, ci, vp, ci, db, db, db, db, vp]
     L.fno_pointwise_workspace_bytes.argtypes = [ci]
     L.fno_pointwise_workspace_bytes.restype = sz
     L.fno_pointwise_forward.argtypes = [ci, ci, sz, vp, vp, vp, vp, ci, vp, vp]
@@ -171,6 +180,8 @@ EXPORTED_SYMBOLS = [
     "fno_model_forward_tail", "fno_model_backward_tail", "fno_dropout_scale",
     "fno_fanout_saved_bytes", "fno_fanout_workspace_bytes", "fno_fanout_forward", "fno_fanout_backward",
     "fno_lploss_workspace_bytes", "fno_lploss_rel_forward", "fno_lploss_rel_backward", "fno_adam_step", "fno_adam_step_dev",
+    "fno_adam_scalars", "fno_adam_prep_dev", "fno_adam_step_range", "fno_adam_step_live", "fno_adam_replay_prep",
+    "fno_adam_replay_dead",
     "fno_pointwise_workspace_bytes", "fno_pointwise_forward", "fno_pointwise_backward",
     "fno_projection_workspace_bytes", "fno_projection_forward", "fno_projection_backward",
     "fno_projection_forward_act", "fno_projection_backward_act",

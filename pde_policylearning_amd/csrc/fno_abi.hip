@@ -180,6 +180,7 @@ struct Geom {
   int Klast, J, NJ;
   int Ktot;
   int wl_stride;
+  int w_planes;      // corner weights stored plane-major ([wl][Cin][Cout][rest], k_spectral_mid.h)
   double s_f, s_i;
 };
 
@@ -204,7 +205,8 @@ static int upload(Tables& t, const void* host, size_t bytes, void** dev) {
   return FNO_OK;
 }
 
-static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int wl_stride, int norm) {
+static int g_pack_flat_early();
+static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int wl_stride, int norm, int w_planes = 0) {
   if (ndim != 2 && ndim != 3) return fail(FNO_EUNSUPPORTED, "ndim=%d (2 or 3 supported)", ndim);
   g.ndim = ndim;
   g.nlead = ndim - 1;
@@ -230,6 +232,8 @@ static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int w
   g.NJ = (g.J + 15) / 16;
   g.wl_stride = wl_stride > 0 ? wl_stride : g.Klast;
   if (g.wl_stride < g.Klast) return fail(FNO_EINVAL, "weight_last_extent < modes[last]");
+  g.w_planes = w_planes ? 1 : 0;
+  if (g.w_planes && g_pack_flat_early()) return fail(FNO_EUNSUPPORTED, "FNO_PACK_FLAT has no plane-major layout kernels");
   const double n = (double)g.PW;
   if (norm == FNO_NORM_FORWARD) { g.s_f = 1.0 / n; g.s_i = 1.0; }
   else if (norm == FNO_NORM_ORTHO) { g.s_f = 1.0 / std::sqrt(n); g.s_i = g.s_f; }
@@ -521,10 +525,21 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
 static const int g_pack_flat = getenv("FNO_PACK_FLAT") ? 1 : 0;      // A/B switch: thread-per-element layout kernels
 // all layers of a stack in one launch each way (blockIdx.y = layer); wp / wpt nullable; `stride` = floats between layers
 static int nrest_of(const Geom& g) { return g.nlead == 2 ? g.modes[0] * g.modes[1] : g.modes[0]; }
+static int plane_rc(int nrest) { int rc = 64; while (rc > 8 && rc / 2 >= nrest) rc >>= 1; return rc; }      // rest positions per tile
+static size_t plane_blocks(const Geom& g, int Cin, int Cout, int nrest, int rc) {
+  return (size_t)(1 << g.nlead) * g.Klast * ((Cin + 7) / 8) * ((Cout + 7) / 8) * ((nrest + rc - 1) / rc);
+}
 static int pack_w_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const CornerPtrsL& cp, int L, float* wp, float* wpt,
                          size_t stride) {
   const ModeMap mm = make_modemap(g, Cin, Cout);
   const int nrest = nrest_of(g);
+  if (g.w_planes) {
+    const int rc = plane_rc(nrest);
+    const size_t blocks = plane_blocks(g, Cin, Cout, nrest, rc);
+    if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight pack grid too large");
+    return launch("k_pack_w", k_pack_w_planes, dim3((unsigned)blocks, L), dim3(256), (size_t)64 * (rc + 1) * 8, st, cp, (float2*)wp,
+                  (float2*)wpt, mm, stride / 2, nrest, rc);
+  }
   int ti = 8;                                  // input channels per workgroup: whole sectors of the transposed copy
   while (ti > 1 && (Cin % ti != 0 || (size_t)ti * Cout * (g.wl_stride + 1) * 8 > 48 * 1024)) ti >>= 1;   // >= 3 workgroups per CU
   const size_t blocks = (size_t)(1 << g.nlead) * nrest * (Cin / ti);
@@ -536,6 +551,13 @@ static int unpack_dw_layers(hipStream_t st, const Geom& g, int Cin, int Cout, co
                             size_t stride) {
   const ModeMap mm = make_modemap(g, Cin, Cout);
   const int nrest = nrest_of(g);
+  if (g.w_planes) {
+    const int rc = plane_rc(nrest);
+    const size_t pblocks = plane_blocks(g, Cin, Cout, nrest, rc);
+    if (pblocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight unpack grid too large");
+    return launch("k_unpack_dw", k_unpack_dw_planes, dim3((unsigned)pblocks, L), dim3(256), (size_t)64 * (rc + 1) * 8, st,
+                  (const float2*)dwp, cp, mm, stride / 2, nrest, rc);
+  }
   const size_t blocks = (size_t)(1 << g.nlead) * nrest * Cin;
   if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight unpack grid too large");
   return launch("k_unpack_dw", k_unpack_dw_tiled, dim3((unsigned)blocks, L), dim3(256), (size_t)Cout * (g.wl_stride + 1) * 8, st,
@@ -608,7 +630,7 @@ extern "C" int fno_spec_plan_create(const FnoSpecDesc* d, FnoSpecPlan** out) {
   if (!d || !out) return fail(FNO_EINVAL, "null argument");
   FnoSpecPlan* p = new FnoSpecPlan();
   p->d = *d;
-  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, d->weight_last_extent, d->norm);
+  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, d->weight_last_extent, d->norm, d->weight_planes);
   if (rc == FNO_OK && (d->Cin < 1 || d->Cout < 1 || d->Cin > 256 || d->Cout > 256))
     rc = fail(FNO_EUNSUPPORTED, "channels must be in [1, 256]");
   if (rc == FNO_OK) {
@@ -929,7 +951,7 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
     return fail(FNO_EUNSUPPORTED, "a block stack without projection must end without activation");
   FnoModelPlan* p = new FnoModelPlan();
   p->d = *d;
-  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, 0, d->norm);
+  int rc = make_geom(p->g, d->ndim, d->dims, d->modes, 0, d->norm, d->weight_planes);
   if (rc == FNO_OK) {
     const int W = p->g.W;
     p->loose = false;
@@ -1097,7 +1119,8 @@ template <int C>
 static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds) {
   if (g_bfwd_v1 || p->NPX != 128 || p->loose || !a.x) return false;
   if ((size_t)a.PW * 4 * C >= (size_t)1 << 31) return false;          // 32-bit buffer offsets within one sample
-  if (a.z && a.K2in > 16) return false;                                // spectral extension: at most two 16-deep k blocks
+  if (a.z && a.K2in > 8) return false;      // more than 8 kept last-dim modes (two extension k blocks, e.g. RNO2d at 12): k_pw_fwd_x3
+                                            // is as fast or faster (RNO2d 128^2: 0.085 vs 0.108 ms per launch)
   if (C == 32 && !a.x1) return false;      // 32 channels without a row-DFT epilogue: k_pw_fwd_x3 is faster (59 vs 70 us at config-2 size)
   *lds = blk_fwd_t_lds_bytes(C, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   return *lds + 2048 <= 160 * 1024;
@@ -1112,12 +1135,10 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
     const int kz = a.z ? (2 * a.K2in + 15) / 16 : 0;
     const bool h2k = g_h2 && g_h2_blocks && g_h2_fwd_blocks && a.xmax && kz > 0 && !a.add && !a.relu_out;      // two-term fp16 variants: the model path's combinations
 #define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
-    if (h2k && !(RELU_) && !(ADD_)) { \
-      if (kz == 1) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
-      return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 2, 2>, g2, blk, lds2, st, a); } \
+    if (h2k && !(RELU_) && !(ADD_)) \
+      return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
     if (kz == 0) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
-    if (kz == 1) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); \
-    return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 2>, g2, blk, lds2, st, a); } while (0)
+    return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
     if (a.lw && !a.relu_out && !a.add) {
       if (epi == 2) BF2(true, false, false, 2, false);
       if (epi == 1) BF2(true, false, false, 1, false);
@@ -1889,40 +1910,96 @@ extern "C" int fno_lploss_rel_backward(int batch, size_t n, const float* pred, c
                    stat_len, eps, n, coef, grad_loss, dpred));
   return FNO_OK;
 }
-static int adam_launch(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int step, int* step_dev, float* dyn, hipStream_t st) {
+// Hyperparameters arrive as DOUBLES (the Python floats torch.optim.Adam holds): the step size, the bias corrections and the
+// two (1 - beta) weights are formed in double and rounded once, as torch's scalar arguments are.
+struct AdamHyper { float lr, beta1, beta2, eps, wd, omb1, omb2; };
+static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, double wd) {
+  AdamHyper h;
+  h.lr = (float)lr; h.beta1 = (float)beta1; h.beta2 = (float)beta2; h.eps = (float)eps; h.wd = (float)wd;
+  h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);
+  return h;
+}
+extern "C" void fno_adam_scalars(double lr, double beta1, double beta2, int step, float* out2) {
+  const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+  out2[0] = (float)(lr / bc1);
+  out2[1] = (float)std::sqrt(bc2);
+}
+extern "C" int fno_adam_prep_dev(int* step_counter, float* scratch2, double lr, double beta1, double beta2, void* stream) {
+  if (!step_counter || !scratch2) return fail(FNO_EINVAL, "fno_adam_prep_dev: null step counter / scratch");
+  return launch("k_adam_prep", k_adam_prep, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter, scratch2, lr, beta1, beta2);
+}
+extern "C" int fno_adam_step_range(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                                   double beta1, double beta2, double eps, double weight_decay, int step, const float* dyn,
+                                   void* stream) {
   if (!n) return FNO_OK;
+  if (!dyn && step < 1) return fail(FNO_EINVAL, "fno_adam_step: step must be >= 1 (or pass the prepared scalars)");
   if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(FNO_EINVAL, "fno_adam_step: bad argument");
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
     return fail(FNO_EINVAL, "fno_adam_step: buffers must be 16-byte aligned");
+  const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay);
   AdamArgs a;
   a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-  a.dyn = nullptr; a.step_size = 0.f; a.bc2_sqrt = 1.f;
-  if (step_dev) {
-    LAUNCHCHK(launch("k_adam_prep", k_adam_prep, dim3(1), dim3(1), 0, st, step_dev, dyn, lr, beta1, beta2));
-    a.dyn = dyn;
-  } else {
-    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
-    a.step_size = (float)((double)lr / bc1);
-    a.bc2_sqrt = (float)std::sqrt(bc2);
-  }
+  a.lr = h.lr; a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps; a.wd = h.wd; a.omb1 = h.omb1; a.omb2 = h.omb2;
+  a.dyn = dyn; a.step_size = 0.f; a.bc2_sqrt = 1.f;
+  if (!dyn) { float sc[2]; fno_adam_scalars(lr, beta1, beta2, step, sc); a.step_size = sc[0]; a.bc2_sqrt = sc[1]; }
   const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, (size_t)dev_ncu() * 8);
-  LAUNCHCHK(launch("k_adam", k_adam, dim3(grid), dim3(256), 0, st, a));
+  return launch("k_adam", k_adam, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+}
+extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int step, void* stream) {
+  if (step < 1) return fail(FNO_EINVAL, "fno_adam_step: step must be >= 1");
+  return fno_adam_step_range(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream);
+}
+extern "C" int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay, int* step_counter,
+                                 float* scratch2, void* stream) {
+  if (!n) return FNO_OK;
+  LAUNCHCHK(fno_adam_prep_dev(step_counter, scratch2, lr, beta1, beta2, stream));
+  return fno_adam_step_range(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 0, scratch2, stream);
+}
+// ---- the same update on a bucket whose dialect-C weights are sliced (dead last-dim slices skipped and replayed later) ----
+static int rows_check(const char* who, size_t rows, int row_len, int live_len) {
+  if (!rows || row_len < 2 || live_len < 2 || live_len >= row_len || (row_len & 1) || (live_len & 1))
+    return fail(FNO_EINVAL, "%s: need rows >= 1 and even 2 <= live_len < row_len (got %zu, %d, %d)", who, rows, live_len, row_len);
   return FNO_OK;
 }
-extern "C" int fno_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
-  if (step < 1) return fail(FNO_EINVAL, "fno_adam_step: step must be >= 1");
-  return adam_launch(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr,
-                     (hipStream_t)stream);
+extern "C" int fno_adam_step_live(size_t rows, int row_len, int live_len, float* param, const float* grad, float* exp_avg_live,
+                                  float* exp_avg_sq_live, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                  int step, const float* dyn, void* stream) {
+  LAUNCHCHK(rows_check("fno_adam_step_live", rows, row_len, live_len));
+  if (!dyn && step < 1) return fail(FNO_EINVAL, "fno_adam_step_live: step must be >= 1 (or pass the prepared scalars)");
+  if (!param || !grad || !exp_avg_live || !exp_avg_sq_live) return fail(FNO_EINVAL, "fno_adam_step_live: bad argument");
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg_live | (uintptr_t)exp_avg_sq_live) & 7)
+    return fail(FNO_EINVAL, "fno_adam_step_live: buffers must be 8-byte aligned");
+  const AdamHyper h = adam_hyper(lr, beta1, beta2, eps, weight_decay);
+  AdamLiveArgs a;
+  a.p = param; a.g = grad; a.m = exp_avg_live; a.v = exp_avg_sq_live; a.rows = rows; a.row_len = row_len; a.live_len = live_len;
+  a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps; a.wd = h.wd; a.omb1 = h.omb1; a.omb2 = h.omb2;
+  a.dyn = dyn; a.step_size = 0.f; a.bc2_sqrt = 1.f;
+  if (!dyn) { float sc[2]; fno_adam_scalars(lr, beta1, beta2, step, sc); a.step_size = sc[0]; a.bc2_sqrt = sc[1]; }
+  const size_t n2 = rows * (size_t)(live_len / 2);
+  const int grid = (int)std::min<size_t>((n2 + 255) / 256, (size_t)dev_ncu() * 8);
+  return launch("k_adam_live", k_adam_live, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
 }
-extern "C" int fno_adam_step_dev(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                                 float beta1, float beta2, float eps, float weight_decay, int* step_counter,
-                                 float* scratch2, void* stream) {
-  if (!step_counter || !scratch2) return fail(FNO_EINVAL, "fno_adam_step_dev: null step counter / scratch");
-  return adam_launch(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, 0, step_counter, scratch2,
-                     (hipStream_t)stream);
+extern "C" int fno_adam_replay_prep(float* scal, int step_from, int nsteps, double lr, double beta1, double beta2, void* stream) {
+  if (!scal || step_from < 1 || nsteps < 1) return fail(FNO_EINVAL, "fno_adam_replay_prep: bad argument");
+  return launch("k_adam_replay_prep", k_adam_replay_prep, dim3(std::min(64, (nsteps + 255) / 256)), dim3(256), 0,
+                (hipStream_t)stream, scal, step_from, nsteps, lr, beta1, beta2);
+}
+extern "C" int fno_adam_replay_dead(size_t rows, int row_len, int live_len, float* param, float* dead_exp_avg,
+                                    float* dead_exp_avg_sq, int moments_zero, const float* scal, int nsteps, double beta1,
+                                    double beta2, double eps, double weight_decay, void* stream) {
+  LAUNCHCHK(rows_check("fno_adam_replay_dead", rows, row_len, live_len));
+  if (!param || !dead_exp_avg || !dead_exp_avg_sq || !scal || nsteps < 1)
+    return fail(FNO_EINVAL, "fno_adam_replay_dead: bad argument");
+  const AdamHyper h = adam_hyper(0.0, beta1, beta2, eps, weight_decay);
+  AdamReplayArgs a;
+  a.p = param; a.dm = dead_exp_avg; a.dv = dead_exp_avg_sq; a.rows = rows; a.row_len = row_len; a.live_len = live_len;
+  a.moments_zero = moments_zero; a.scal = scal; a.nsteps = nsteps; a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps;
+  a.wd = h.wd; a.omb1 = h.omb1; a.omb2 = h.omb2;
+  const size_t n = rows * (size_t)(row_len - live_len);
+  const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)dev_ncu() * 16);
+  return launch("k_adam_replay_dead", k_adam_replay_dead, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
 }
 
 // ===========================================================================
@@ -2161,7 +2238,7 @@ extern "C" int fno_rno_reset_gate_forward(size_t n, const float* a3, const float
                 (const float4*)a4, b2, (const float4*)h, (float4*)r, (float4*)rh, n / 4);
 }
 extern "C" int fno_rno_reset_gate_backward(size_t n, const float* d_rh, const float* r, const float* h, float* d_s,
-                                           float* d_h, float* db_partials, void* stream) {
+                                           float* d_h, double* db_partials, void* stream) {
   LAUNCHCHK(gate_check(n, {d_rh, r, h, d_s, d_h}));
   if (!db_partials) return fail(FNO_EINVAL, "rno gates: null partial buffer");
   return launch("k_rno_reset_bwd", k_rno_reset_bwd, dim3(kGateGrid), dim3(256), 0, (hipStream_t)stream, (const float4*)d_rh,
@@ -2181,7 +2258,7 @@ extern "C" int fno_rno_output_gate_forward(size_t n, const float* a1, const floa
 }
 extern "C" int fno_rno_output_gate_backward(size_t n, const float* g, const float* z, const float* z2, const float* s3,
                                             const float* h, float* d_s1, float* d_s7, float* d_s3, float* d_h,
-                                            float* db_partials, void* stream) {
+                                            double* db_partials, void* stream) {
   LAUNCHCHK(gate_check(n, {g, z, z2, s3, h, d_s1, d_s7, d_s3, d_h}));
   if (!db_partials) return fail(FNO_EINVAL, "rno gates: null partial buffer");
   RnoOutBwdArgs a;

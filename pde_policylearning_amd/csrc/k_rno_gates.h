@@ -5,7 +5,9 @@
 // The eight f_i are Fourier layers (fused engine layers); what is left between them is streaming
 // elementwise work on (B, C, X, Y) tensors with four SCALAR biases.  Two kernels forward (reset gate,
 // output gate), two backward; every tensor is read / written once with 16-B accesses and the scalar-bias
-// gradients are reduced per workgroup (partials summed by the caller in a fixed order).
+// gradients are reduced per workgroup IN DOUBLE (33 M terms of either sign at BASELINE config 3: float32 partial sums cost
+// the four scalars 3 - 14x the error of the rest of the gradient; the adds hide behind the memory traffic), partials
+// (double) summed by the caller in a fixed order.
 #pragma once
 #include "fno_dev.h"
 
@@ -31,8 +33,8 @@ __global__ void __launch_bounds__(256) k_rno_reset_fwd(const float4* __restrict_
 // given d(rh): ds = d(rh) h r (1 - r) (gradient of a3, a4 and, summed, of b2); dh = d(rh) r
 __global__ void __launch_bounds__(256) k_rno_reset_bwd(const float4* __restrict__ drh, const float4* __restrict__ r,
                                                        const float4* __restrict__ h, float4* __restrict__ ds,
-                                                       float4* __restrict__ dh, float* __restrict__ db_part, size_t n4) {
-  float acc = 0.f;
+                                                       float4* __restrict__ dh, double* __restrict__ db_part, size_t n4) {
+  double acc = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 g = drh[i], rv = r[i], hv = h[i];
     float4 s;
@@ -40,10 +42,10 @@ __global__ void __launch_bounds__(256) k_rno_reset_bwd(const float4* __restrict_
     s.z = g.z * hv.z * rv.z * (1.f - rv.z); s.w = g.w * hv.w * rv.w * (1.f - rv.w);
     ds[i] = s;
     dh[i] = make_float4(g.x * rv.x, g.y * rv.y, g.z * rv.z, g.w * rv.w);
-    acc += (s.x + s.y) + (s.z + s.w);
+    acc += (double)((s.x + s.y) + (s.z + s.w));
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  __shared__ float sh[4];
+  __shared__ double sh[4];
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) db_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
@@ -77,11 +79,11 @@ __global__ void __launch_bounds__(256) k_rno_out_fwd(RnoOutArgs a) {
 struct RnoOutBwdArgs {
   const float4 *g, *z, *z2, *s3, *h;
   float4 *ds1, *ds7, *ds3, *dh;     // gradients of (a1, a2), (a7, a8), (a5, a6) and the direct path to h
-  float* db_part;                   // [3][gridDim]: b1, b4, b3 partial sums
+  double* db_part;                  // [3][gridDim]: b1, b4, b3 partial sums
   size_t n4;
 };
 __global__ void __launch_bounds__(256) k_rno_out_bwd(RnoOutBwdArgs a) {
-  float acc1 = 0.f, acc7 = 0.f, acc3 = 0.f;
+  double acc1 = 0.0, acc7 = 0.0, acc3 = 0.0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 gv = a.g[i], zv = a.z[i], z2v = a.z2[i], sv = a.s3[i], hv = a.h[i];
     float4 d1, d7, d3, dh;
@@ -96,14 +98,16 @@ __global__ void __launch_bounds__(256) k_rno_out_bwd(RnoOutBwdArgs a) {
       o7[j] = g[j] * hh * z2[j] * (1.0f - z2[j]);
       o3[j] = g[j] * z2[j] * dsel;
       oh[j] = g[j] * (1.0f - z[j]);
-      acc1 += o1[j]; acc7 += o7[j]; acc3 += o3[j];
     }
+    acc1 += (double)((o1[0] + o1[1]) + (o1[2] + o1[3]));
+    acc7 += (double)((o7[0] + o7[1]) + (o7[2] + o7[3]));
+    acc3 += (double)((o3[0] + o3[1]) + (o3[2] + o3[3]));
     a.ds1[i] = d1; a.ds7[i] = d7; a.ds3[i] = d3; a.dh[i] = dh;
   }
   for (int off = 32; off > 0; off >>= 1) {
     acc1 += __shfl_xor(acc1, off, 64); acc7 += __shfl_xor(acc7, off, 64); acc3 += __shfl_xor(acc3, off, 64);
   }
-  __shared__ float sh[12];
+  __shared__ double sh[12];
   if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = acc1; sh[4 + (threadIdx.x >> 6)] = acc7; sh[8 + (threadIdx.x >> 6)] = acc3; }
   __syncthreads();
   if (threadIdx.x == 0) {

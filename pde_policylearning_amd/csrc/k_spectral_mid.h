@@ -324,6 +324,70 @@ __global__ void __launch_bounds__(256) k_unpack_dw_tiled(const float2* __restric
   }
 }
 
+// PLANE-MAJOR corner weights (FnoSpecDesc / FnoModelDesc .weight_planes): the stored tensor is [wl][Cin][Cout][rest]
+// (rest = the leading per-corner mode positions, innermost) instead of [Cin][Cout][rest][wl] - the live last-dim slices
+// [0, klive) of a dialect-C weight are then ONE contiguous prefix of every tensor (PINObserverFullField at T = 1: 1 plane
+// of 12), which is what the layout kernels, the optimizer and the gradient exchange each touch.  A workgroup owns a tile of
+// TI input x TO output channels x RC rest positions of one (layer, corner, live plane): read along rest (RC * 8 bytes
+// contiguous), written with o innermost (wp) and with i innermost (wpt): whole 64-byte sectors at TI = TO = 8.
+//   grid (ncorner * klive * ceil(Cin / 8) * ceil(Cout / 8) * ceil(nrest / RC), layers), block 256, LDS 64 (RC + 1) float2
+#define PL_T 8
+FNO_DEV void plane_tile(const ModeMap& mm, int nrest, int RC, int bx, int& corner, int& kl, int& i0, int& o0, int& r0) {
+  const int nrc = (nrest + RC - 1) / RC, nob = (mm.Cout + PL_T - 1) / PL_T, nib = (mm.Cin + PL_T - 1) / PL_T;
+  r0 = (bx % nrc) * RC; bx /= nrc;
+  o0 = (bx % nob) * PL_T; bx /= nob;
+  i0 = (bx % nib) * PL_T; bx /= nib;
+  const int klive = mm.K[mm.nlead];
+  kl = bx % klive; corner = bx / klive;
+}
+__global__ void __launch_bounds__(256) k_pack_w_planes(CornerPtrsL cw, float2* __restrict__ wp, float2* __restrict__ wpt,
+                                                       ModeMap mm, size_t stride, int nrest, int RC) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* t = reinterpret_cast<float2*>(smem);     // [PL_T i][PL_T o][RC + 1]
+  const int RCP = RC + 1, l = blockIdx.y;
+  int corner, kl, i0, o0, r0;
+  plane_tile(mm, nrest, RC, blockIdx.x, corner, kl, i0, o0, r0);
+  const int nr = min(RC, nrest - r0);
+  const float2* src = cw.p[l][corner] + (size_t)kl * mm.Cin * mm.Cout * nrest;
+  for (int idx = threadIdx.x; idx < PL_T * PL_T * RC; idx += 256) {
+    const int r = idx % RC, io = idx / RC, ii = io / PL_T, oo = io - ii * PL_T;
+    if (r < nr && i0 + ii < mm.Cin && o0 + oo < mm.Cout)
+      t[io * RCP + r] = src[((size_t)(i0 + ii) * mm.Cout + o0 + oo) * nrest + r0 + r];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < PL_T * PL_T * nr; idx += 256) {
+    const int a = idx % PL_T, b = (idx / PL_T) % PL_T, r = idx / (PL_T * PL_T);
+    const size_t k = (size_t)tile_mode_base(mm, corner, r0 + r) + kl;
+    if (wp && i0 + b < mm.Cin && o0 + a < mm.Cout)           // a = o innermost
+      wp[l * stride + (k * mm.Cin + i0 + b) * mm.Cout + o0 + a] = t[(b * PL_T + a) * RCP + r];
+    if (wpt && i0 + a < mm.Cin && o0 + b < mm.Cout)          // a = i innermost
+      wpt[l * stride + (k * mm.Cout + o0 + b) * mm.Cin + i0 + a] = t[(a * PL_T + b) * RCP + r];
+  }
+}
+// plane-major corner gradients from mode-major dWp[k][i][o]: the live planes only (the caller keeps the dead ones zero)
+__global__ void __launch_bounds__(256) k_unpack_dw_planes(const float2* __restrict__ dwp, CornerPtrsMutL gw, ModeMap mm,
+                                                          size_t stride, int nrest, int RC) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* t = reinterpret_cast<float2*>(smem);
+  const int RCP = RC + 1, l = blockIdx.y;
+  int corner, kl, i0, o0, r0;
+  plane_tile(mm, nrest, RC, blockIdx.x, corner, kl, i0, o0, r0);
+  const int nr = min(RC, nrest - r0);
+  for (int idx = threadIdx.x; idx < PL_T * PL_T * nr; idx += 256) {
+    const int oo = idx % PL_T, ii = (idx / PL_T) % PL_T, r = idx / (PL_T * PL_T);
+    const size_t k = (size_t)tile_mode_base(mm, corner, r0 + r) + kl;
+    if (i0 + ii < mm.Cin && o0 + oo < mm.Cout)
+      t[(ii * PL_T + oo) * RCP + r] = dwp[l * stride + (k * mm.Cin + i0 + ii) * mm.Cout + o0 + oo];
+  }
+  __syncthreads();
+  float2* dst = gw.p[l][corner] + (size_t)kl * mm.Cin * mm.Cout * nrest;
+  for (int idx = threadIdx.x; idx < PL_T * PL_T * RC; idx += 256) {
+    const int r = idx % RC, io = idx / RC, ii = io / PL_T, oo = io - ii * PL_T;
+    if (r < nr && i0 + ii < mm.Cin && o0 + oo < mm.Cout)
+      dst[((size_t)(i0 + ii) * mm.Cout + o0 + oo) * nrest + r0 + r] = t[io * RCP + r];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // O[b][k][o] = sum_i X[b][k][i] * W[k][i][o]          (conj_w: use conj(W), for the adjoint
 // with wpt[k][o][i] passed as w and Cin/Cout swapped)

@@ -79,13 +79,15 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v;
   size_t n;
   float lr, beta1, beta2, eps, wd, step_size, bc2_sqrt;
+  float omb1, omb2;   // 1 - beta in DOUBLE, then rounded (torch passes the Python double 1 - beta2 = 0.001 to addcmul_: 1.0f - 0.999f
+                      // is 1.3e-5 away from it, and exp_avg_sq with it)
   const float* dyn;   // graph mode: {step_size, bc2_sqrt} written by k_adam_prep on the device, else null
 };
 // graph-replayable step counter: ++*step, then the two bias-correction scalars of that step (double arithmetic)
-__global__ void k_adam_prep(int* step, float* dyn, float lr, float beta1, float beta2) {
+__global__ void k_adam_prep(int* step, float* dyn, double lr, double beta1, double beta2) {
   const int t = ++step[0];
-  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-  dyn[0] = (float)((double)lr / bc1);
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  dyn[0] = (float)(lr / bc1);
   dyn[1] = (float)sqrt(bc2);
 }
 #ifndef FNO_ADAM_NT
@@ -106,8 +108,8 @@ FNO_DEV void adam4(const AdamArgs& a, size_t i) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float gg = fmaf(a.wd, pp[j], gp[j]);
-    mp[j] = fmaf(gg - mp[j], 1.0f - a.beta1, mp[j]);
-    vp[j] = fmaf(gg * gg, 1.0f - a.beta2, a.beta2 * vp[j]);
+    mp[j] = fmaf(gg - mp[j], a.omb1, mp[j]);
+    vp[j] = fmaf(gg * gg, a.omb2, a.beta2 * vp[j]);
     const float denom = sqrtf(vp[j]) / a.bc2_sqrt + a.eps;
     pp[j] = fmaf(-a.step_size, mp[j] / denom, pp[j]);
   }
@@ -132,9 +134,80 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
   if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
     const size_t i = n4 * 4 + threadIdx.x;
     const float gg = fmaf(a.wd, a.p[i], a.g[i]);
-    const float m = fmaf(gg - a.m[i], 1.0f - a.beta1, a.m[i]);
-    const float v = fmaf(gg * gg, 1.0f - a.beta2, a.beta2 * a.v[i]);
+    const float m = fmaf(gg - a.m[i], a.omb1, a.m[i]);
+    const float v = fmaf(gg * gg, a.omb2, a.beta2 * a.v[i]);
     a.m[i] = m; a.v[i] = v;
     a.p[i] = fmaf(-a.step_size, m / (sqrtf(v) / a.bc2_sqrt + a.eps), a.p[i]);
+  }
+}
+
+// ---- row-sliced parameter blocks (dialect-C spectral weights of which only [..., :k] ever sees data) --------------------
+// A block is rows x row_len floats; the first live_len floats of every row are live, the rest ("dead") receive an exactly
+// zero gradient every step.  k_adam_live steps the live part only (param / grad in the full layout, moments compact:
+// rows x live_len); what Adam does to a dead element is a recurrence on (p, m, v) alone (g = wd p), so it is not stepped
+// but REPLAYED - k_adam_replay_dead takes it through any number of skipped steps in registers, one read and one write -
+// when somebody needs the slice (checkpoint, state_dict, a longer last dimension).  Same operations in the same order
+// as adam4 with g = 0: bit-identical to stepping it every time.
+struct AdamLiveArgs {
+  float* p; const float* g; float* m; float* v;      // p, g: full layout; m, v: compact live moments
+  size_t rows; int row_len, live_len;
+  float beta1, beta2, eps, wd, step_size, bc2_sqrt, omb1, omb2;
+  const float* dyn;
+};
+__global__ void __launch_bounds__(256) k_adam_live(AdamLiveArgs a) {
+  if (a.dyn) { a.step_size = a.dyn[0]; a.bc2_sqrt = a.dyn[1]; }
+  const int lp = a.live_len / 2;                       // float2 (one complex number) per thread and trip
+  const size_t n2 = a.rows * (size_t)lp;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = lp == 1 ? e : e / (size_t)lp;
+    const size_t full = row * (size_t)a.row_len + 2 * (e - row * (size_t)lp);
+    float2 p = *reinterpret_cast<const float2*>(a.p + full), g = *reinterpret_cast<const float2*>(a.g + full);
+    float2 m = *reinterpret_cast<const float2*>(a.m + 2 * e), v = *reinterpret_cast<const float2*>(a.v + 2 * e);
+    float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float gg = fmaf(a.wd, pp[j], gp[j]);
+      mp[j] = fmaf(gg - mp[j], a.omb1, mp[j]);
+      vp[j] = fmaf(gg * gg, a.omb2, a.beta2 * vp[j]);
+      const float denom = sqrtf(vp[j]) / a.bc2_sqrt + a.eps;
+      pp[j] = fmaf(-a.step_size, mp[j] / denom, pp[j]);
+    }
+    *reinterpret_cast<float2*>(a.p + full) = p;
+    *reinterpret_cast<float2*>(a.m + 2 * e) = m;
+    *reinterpret_cast<float2*>(a.v + 2 * e) = v;
+  }
+}
+// scal[2 j] = step_size, scal[2 j + 1] = sqrt(bias correction 2) of step step_from + j (k_adam_prep's arithmetic)
+__global__ void k_adam_replay_prep(float* scal, int step_from, int nsteps, double lr, double beta1, double beta2) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nsteps; j += gridDim.x * blockDim.x) {
+    const int t = step_from + j;
+    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+    scal[2 * j] = (float)(lr / bc1);
+    scal[2 * j + 1] = (float)sqrt(bc2);
+  }
+}
+struct AdamReplayArgs {
+  float* p;                 // full layout
+  float* dm; float* dv;     // compact dead moments (rows x (row_len - live_len)): read unless moments_zero, always written
+  size_t rows; int row_len, live_len, moments_zero;
+  const float* scal; int nsteps;
+  float beta1, beta2, eps, wd, omb1, omb2;
+};
+__global__ void __launch_bounds__(256) k_adam_replay_dead(AdamReplayArgs a) {
+  const int dl = a.row_len - a.live_len;
+  const size_t n = a.rows * (size_t)dl;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = e / (size_t)dl;
+    const size_t full = row * (size_t)a.row_len + a.live_len + (e - row * (size_t)dl);
+    float p = a.p[full], m = a.moments_zero ? 0.f : a.dm[e], v = a.moments_zero ? 0.f : a.dv[e];
+    for (int j = 0; j < a.nsteps; ++j) {
+      const float step_size = a.scal[2 * j], bc2_sqrt = a.scal[2 * j + 1];      // (uniform: scalar loads)
+      const float gg = fmaf(a.wd, p, 0.0f);
+      m = fmaf(gg - m, a.omb1, m);
+      v = fmaf(gg * gg, a.omb2, a.beta2 * v);
+      const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+      p = fmaf(-step_size, m / denom, p);
+    }
+    a.p[full] = p; a.dm[e] = m; a.dv[e] = v;
   }
 }

@@ -38,8 +38,9 @@ def _bytes(n, device):
 # ----------------------------------------------------------------------------
 # standalone spectral convolution
 # ----------------------------------------------------------------------------
-def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, input_gelu=False):
-    key = (ndim, cin, cout, tuple(dims), tuple(modes), weight_last_extent, norm, device.index, bool(input_gelu))
+def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, input_gelu=False, weight_planes=False):
+    key = (ndim, cin, cout, tuple(dims), tuple(modes), weight_last_extent, norm, device.index, bool(input_gelu),
+           bool(weight_planes))
     plan = _spec_plans.get(key)
     if plan is None:
         d = _lib.FnoSpecDesc()
@@ -49,6 +50,7 @@ def spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, device, in
         d.weight_last_extent = int(weight_last_extent)
         d.norm = _lib.NORM_CODES[norm]
         d.input_gelu = 1 if input_gelu else 0
+        d.weight_planes = 1 if weight_planes else 0
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().fno_spec_plan_create(C.byref(d), C.byref(h)), "spec_plan_create")
@@ -84,10 +86,44 @@ class single_use(object):
         _SINGLE_USE.pop()
 
 
+def plane_major(w):
+    """True when a corner weight (complex (Cin, Cout, m.., wl) or its real view (.., wl, 2)) is stored PLANE-MAJOR: the last
+    mode dim outermost in memory, everything else contiguous behind it (include/fnoengine.h, weight_planes) - the layout
+    libs.models.pino_models.basics.SpectralConv3d gives its parameters, so that the live last-dim slices are one
+    contiguous prefix.  A tensor that is also contiguous in the ordinary sense (wl = 1) counts as ordinary."""
+    r = torch.view_as_real(w) if w.is_complex() else w
+    if r.dim() < 4 or r.is_contiguous() or r.stride(-1) != 1:
+        return False
+    plane = r[..., 0, :]
+    return plane.is_contiguous() and r.stride(-2) == plane.numel()
+
+
+def to_plane_major(w):
+    """The same values with the last dim outermost in memory (shape unchanged)."""
+    nd = w.dim()
+    return w.permute(nd - 1, *range(nd - 1)).contiguous().permute(*range(1, nd), 0)
+
+
+def _weights_ready(ws):
+    """(tensors the engine can read in place, weight_planes flag): all plane-major -> as they are; otherwise contiguous"""
+    if ws and all(plane_major(t) for t in ws):
+        return list(ws), True
+    return [t.contiguous() for t in ws], False
+
+
+def _same_layout(g, w):
+    return g is not None and g.shape == w.shape and g.stride() == w.stride() and (g.is_contiguous() or plane_major(g))
+
+
+def _fresh_grads(ws, planes):
+    """gradient tensors laid out like the weights; plane-major: zeros (the engine writes the live planes only)"""
+    return [torch.zeros_like(t) if planes else torch.empty_like(t) for t in ws]
+
+
 def _direct_views(direct_grads, spec_ws):
     """the weights' own .grad storage as real views, or None when direct writes are off / not possible"""
     if not (direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled()
-            and all(t.grad is not None and t.grad.is_contiguous() for t in spec_ws)):
+            and all(_same_layout(t.grad, t) for t in spec_ws)):
         return None
     return [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
 
@@ -111,7 +147,7 @@ class _SpectralConvFn(torch.autograd.Function):
     def forward(ctx, x, bias, modes, norm, weight_last_extent, direct, *weights):
         _require_cuda(x, "x")
         x = x.contiguous()
-        ws_list = [w.contiguous() for w in weights]          # real views (.., 2)
+        ws_list, planes = _weights_ready(weights)            # real views (.., 2)
         for w in ws_list:
             _require_cuda(w, "weight")
         B, cin = x.shape[0], x.shape[1]
@@ -119,7 +155,8 @@ class _SpectralConvFn(torch.autograd.Function):
         ndim = len(dims)
         cout = ws_list[0].shape[1]
         L = _lib.lib()
-        plan = spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, x.device)
+        plan = spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, x.device, weight_planes=planes)
+        ctx.planes = planes
         y = torch.empty((B, cout) + dims, dtype=torch.float32, device=x.device)
         xhat = _bytes(L.fno_spec_xhat_bytes(plan, B), x.device)
         nws = L.fno_spec_workspace_bytes(plan, B)
@@ -145,7 +182,7 @@ class _SpectralConvFn(torch.autograd.Function):
         need_dw = any(ctx.needs_input_grad[6:])
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dy.device) if need_dx else None
         direct = ctx.direct if need_dw else None
-        dws = (direct if direct is not None else [torch.empty_like(w) for w in ws_list]) if need_dw else None
+        dws = (direct if direct is not None else _fresh_grads(ws_list, ctx.planes)) if need_dw else None
         db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device) if need_db else None
         nws = L.fno_spec_workspace_bytes(ctx.plan, ctx.B)
         ws = _bytes(nws, dy.device)
@@ -173,7 +210,7 @@ def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=N
     wle = int(weight_last_extent) if weight_last_extent is not None else int(ws[0].shape[-2])
     b = bias.reshape(-1) if bias is not None else None
     direct = None
-    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(w.grad is not None and w.grad.is_contiguous() for w in weights):
+    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(_same_layout(w.grad, w) for w in weights):
         direct = [torch.view_as_real(w.grad) if w.grad.is_complex() else w.grad for w in weights]
     return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, direct, *ws)
 
@@ -181,8 +218,9 @@ def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=N
 # ----------------------------------------------------------------------------
 # fused FNO model
 # ----------------------------------------------------------------------------
-def model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gelu_mask, device):
-    key = (ndim, cin, c, cout, hidden_proj, n_layers, tuple(dims), tuple(modes), norm, gelu_mask, device.index)
+def model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gelu_mask, device, weight_planes=False):
+    key = (ndim, cin, c, cout, hidden_proj, n_layers, tuple(dims), tuple(modes), norm, gelu_mask, device.index) \
+        + ((True,) if weight_planes else ())
     plan = _model_plans.get(key)
     if plan is None:
         d = _lib.FnoModelDesc()
@@ -192,6 +230,7 @@ def model_plan(ndim, cin, c, cout, hidden_proj, n_layers, dims, modes, norm, gel
             d.dims[i], d.modes[i] = int(dims[i]), int(modes[i])
         d.norm = _lib.NORM_CODES[norm]
         d.gelu_mask = gelu_mask
+        d.weight_planes = 1 if weight_planes else 0
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().fno_model_plan_create(C.byref(d), C.byref(h)), "model_plan_create")
@@ -411,6 +450,77 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
                                         int(step), _stream()), "adam_step")
 
 
+def adam_step_runs(runs, param, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, step_counter=None,
+                   scratch=None):
+    """One Adam update of a bucket planned around dead last-dim slices (trainer.FusedAdam.skip_dead_slices): `runs` lists
+    ("dense", offset, n, compact offset) ranges and ("rows", offset, rows, row_len, live_len, compact offset) blocks of
+    `param` / `grad` (full layout); exp_avg / exp_avg_sq are compact.  One kernel per run, the dead part of a block untouched."""
+    L = _lib.lib()
+    for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _require_cuda(t, name)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise RuntimeError(f"fnoengine adam_step_runs: `{name}` must be contiguous float32")
+    if grad.numel() != param.numel() or exp_avg.numel() != exp_avg_sq.numel():
+        raise RuntimeError("fnoengine adam_step_runs: param / grad and exp_avg / exp_avg_sq must pair up")
+    dyn = None
+    if step_counter is not None:
+        _lib.check(L.fno_adam_prep_dev(_ptr(step_counter), _ptr(scratch), float(lr), float(betas[0]), float(betas[1]),
+                                       _stream()), "adam_prep_dev")
+        dyn = _ptr(scratch)
+    hp = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step))
+    P, G, M, V = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+    for run in runs:
+        if run[0] == "dense":
+            _, off, n, coff = run
+            if off + n > param.numel() or coff + n > exp_avg.numel():
+                raise RuntimeError("fnoengine adam_step_runs: run outside the buffers")
+            _lib.check(L.fno_adam_step_range(n, P + 4 * off, G + 4 * off, M + 4 * coff, V + 4 * coff, *hp, dyn, _stream()),
+                       "adam_step_range")
+        else:
+            _, off, rows, row_len, live_len, coff = run
+            if off + rows * row_len > param.numel() or coff + rows * live_len > exp_avg.numel():
+                raise RuntimeError("fnoengine adam_step_runs: block outside the buffers")
+            _lib.check(L.fno_adam_step_live(rows, row_len, live_len, P + 4 * off, G + 4 * off, M + 4 * coff, V + 4 * coff, *hp,
+                                            dyn, _stream()), "adam_step_live")
+
+
+def adam_replay_scalars(step_from, nsteps, lr, betas, device, on_device=False):
+    """(2 * nsteps,) device tensor: {lr / (1 - beta1^t), sqrt(1 - beta2^t)} for t = step_from .. step_from + nsteps - 1,
+    derived as the stepping kernels' callers derive them: on the host in double (fno_adam_step), or - on_device - by the
+    device arithmetic of the graph-replayable path (fno_adam_step_dev)."""
+    L = _lib.lib()
+    if on_device:
+        scal = torch.empty(2 * nsteps, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.fno_adam_replay_prep(_ptr(scal), int(step_from), int(nsteps), float(lr), float(betas[0]),
+                                              float(betas[1]), _stream()), "adam_replay_prep")
+        return scal
+    import ctypes
+    host = torch.empty(2 * nsteps, dtype=torch.float32)
+    base = host.data_ptr()
+    for j in range(nsteps):
+        L.fno_adam_scalars(float(lr), float(betas[0]), float(betas[1]), int(step_from + j), ctypes.c_void_p(base + 8 * j))
+    return host.to(device)
+
+
+def adam_replay_dead(rows, row_len, live_len, param_block, dead_m, dead_v, moments_zero, scal, betas, eps, weight_decay):
+    """Take the dead part of a row-sliced block (rows x row_len floats of `param_block`, dead = [live_len, row_len) of each
+    row) through the Adam steps described by `scal` (adam_replay_scalars) with a zero gradient; dead_m / dead_v: compact
+    dead moments, read unless moments_zero, always written."""
+    for t, name in ((param_block, "param"), (dead_m, "dead exp_avg"), (dead_v, "dead exp_avg_sq"), (scal, "scalars")):
+        _require_cuda(t, name)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise RuntimeError(f"fnoengine adam_replay_dead: `{name}` must be contiguous float32")
+    nd = rows * (row_len - live_len)
+    if param_block.numel() != rows * row_len or dead_m.numel() != nd or dead_v.numel() != nd or scal.numel() % 2:
+        raise RuntimeError("fnoengine adam_replay_dead: buffer sizes do not match the block")
+    with torch.cuda.device(param_block.device):
+        _lib.check(_lib.lib().fno_adam_replay_dead(rows, row_len, live_len, _ptr(param_block), _ptr(dead_m), _ptr(dead_v),
+                                                   1 if moments_zero else 0, _ptr(scal), scal.numel() // 2, float(betas[0]),
+                                                   float(betas[1]), float(eps), float(weight_decay), _stream()),
+                   "adam_replay_dead")
+
+
 # ----------------------------------------------------------------------------
 # fused block stack: y = B_{L-1}(...B_0(x)),  B_l(u) = [gelu](specconv_l(u) + conv1x1_l(u) + bias_l)
 # ----------------------------------------------------------------------------
@@ -428,14 +538,15 @@ class _FNOBlocksFn(torch.autograd.Function):
         ndim = len(dims)
         ncorner = 2 ** (ndim - 1)
         skip_ws = [t.contiguous() for t in rest[:n_layers]]
-        spec_ws = [t.contiguous() for t in rest[n_layers:]]
+        spec_ws, planes = _weights_ready(rest[n_layers:])
+        ctx.planes = planes
         assert len(spec_ws) == n_layers * ncorner
         for t in skip_ws + spec_ws + ([bias] if bias is not None else []):
             _require_cuda(t, "parameter")
         sb = bias.contiguous() if bias is not None else None
         B, c = x.shape[0], x.shape[1]
         L = _lib.lib()
-        plan = model_plan(ndim, 0, c, 0, 0, n_layers, dims, modes, norm, gelu_mask, x.device)
+        plan = model_plan(ndim, 0, c, 0, 0, n_layers, dims, modes, norm, gelu_mask, x.device, weight_planes=planes)
         prm = _lib.FnoModelParams()
         for l in range(n_layers):
             prm.skip_w[l] = skip_ws[l].data_ptr()
@@ -475,7 +586,7 @@ class _FNOBlocksFn(torch.autograd.Function):
         L = _lib.lib()
         prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
         g_skip = [torch.empty_like(t) for t in skip_ws]
-        g_spec = ctx.direct if ctx.direct is not None else [torch.empty_like(t) for t in spec_ws]   # direct: the weights' own .grad storage
+        g_spec = ctx.direct if ctx.direct is not None else _fresh_grads(spec_ws, ctx.planes)   # direct: the weights' own .grad storage
         g_sb = torch.empty_like(sb) if sb is not None else None
         for l in range(nl):
             prm.skip_w[l], grd.skip_w[l] = skip_ws[l].data_ptr(), g_skip[l].data_ptr()
@@ -594,13 +705,14 @@ class _FourierFanoutFn(torch.autograd.Function):
         nc = 2 ** (ndim - 1)
         skip_ws = [t.contiguous() for t in rest[:n]]
         biases = [t.contiguous() for t in rest[n:2 * n]]
-        spec_ws = [t.contiguous() for t in rest[2 * n:]]
+        spec_ws, planes = _weights_ready(rest[2 * n:])
+        ctx.planes = planes
         assert len(spec_ws) == n * nc and n <= FANOUT_MAX
         for t in skip_ws + biases + spec_ws:
             _require_cuda(t, "parameter")
         B, c = x.shape[0], x.shape[1]
         L = _lib.lib()
-        plan = model_plan(ndim, 0, c, 0, 0, FANOUT_MAX, dims, modes, norm, 0, x.device)
+        plan = model_plan(ndim, 0, c, 0, 0, FANOUT_MAX, dims, modes, norm, 0, x.device, weight_planes=planes)
         prm = _lib.FnoModelParams()
         for j in range(n):
             prm.skip_w[j] = skip_ws[j].data_ptr()
@@ -630,7 +742,7 @@ class _FourierFanoutFn(torch.autograd.Function):
         L = _lib.lib()
         prm, grd = _lib.FnoModelParams(), _lib.FnoModelGrads()
         g_skip = [torch.empty_like(t) for t in skip_ws]
-        g_spec = ctx.direct if ctx.direct is not None else [torch.empty_like(t) for t in spec_ws]     # direct: the weights' own .grad storage
+        g_spec = ctx.direct if ctx.direct is not None else _fresh_grads(spec_ws, ctx.planes)     # direct: the weights' own .grad storage
         g_bias = [torch.empty(x.shape[1], dtype=torch.float32, device=x.device) for _ in range(n)]
         for j in range(n):
             prm.skip_w[j], grd.skip_w[j] = skip_ws[j].data_ptr(), g_skip[j].data_ptr()
@@ -861,10 +973,10 @@ class _RnoResetGateFn(torch.autograd.Function):
         L = _lib.lib()
         d_rh = d_rh.contiguous()
         ds, dh = torch.empty_like(h), torch.empty_like(h)
-        part = torch.empty(L.fno_rno_gate_partials(), dtype=torch.float32, device=h.device)
+        part = torch.empty(L.fno_rno_gate_partials(), dtype=torch.float64, device=h.device)
         _lib.check(L.fno_rno_reset_gate_backward(h.numel(), _ptr(d_rh), _ptr(r), _ptr(h), _ptr(ds), _ptr(dh), _ptr(part),
                                                  _stream()), "rno_reset_gate_backward")
-        return ds, ds, part.sum().reshape(()), dh
+        return ds, ds, part.sum().float().reshape(()), dh
 
 
 class _RnoOutputGateFn(torch.autograd.Function):
@@ -887,10 +999,10 @@ class _RnoOutputGateFn(torch.autograd.Function):
         g = g.contiguous()
         d1, d7, d3, dh = (torch.empty_like(h) for _ in range(4))
         P = L.fno_rno_gate_partials()
-        part = torch.empty(3, P, dtype=torch.float32, device=h.device)
+        part = torch.empty(3, P, dtype=torch.float64, device=h.device)
         _lib.check(L.fno_rno_output_gate_backward(h.numel(), _ptr(g), _ptr(z), _ptr(z2), _ptr(s3), _ptr(h), _ptr(d1), _ptr(d7),
                                                   _ptr(d3), _ptr(dh), _ptr(part), _stream()), "rno_output_gate_backward")
-        db = part.sum(dim=1)
+        db = part.sum(dim=1).float()
         return d1, d1, db[0].reshape(()), d7, d7, db[1].reshape(()), d3, d3, db[2].reshape(()), dh
 
 
@@ -1109,9 +1221,10 @@ class _SpectralLayerFn(torch.autograd.Function):
         B, Cc = u.shape[0], u.shape[1]
         dims = tuple(u.shape[2:])
         pw = u.numel() // (B * Cc)
-        ws_list = [t.contiguous() for t in spec_ws]
+        ws_list, planes = _weights_ready(spec_ws)
+        ctx.planes = planes
         L = _lib.lib()
-        plan = spec_plan(len(dims), Cc, Cc, dims, modes, wle, norm, u.device, input_gelu)
+        plan = spec_plan(len(dims), Cc, Cc, dims, modes, wle, norm, u.device, input_gelu, weight_planes=planes)
         sp = torch.empty_like(u)
         xhat = _bytes(L.fno_spec_xhat_bytes(plan, B), u.device)
         nws = L.fno_spec_workspace_bytes(plan, B)
@@ -1137,7 +1250,7 @@ class _SpectralLayerFn(torch.autograd.Function):
         need_du = ctx.needs_input_grad[0]
         need_dws = any(ctx.needs_input_grad[8:])
         direct = ctx.direct if need_dws else None
-        dws = (direct if direct is not None else [torch.empty_like(t) for t in ws_list]) if need_dws else None
+        dws = (direct if direct is not None else _fresh_grads(ws_list, ctx.planes)) if need_dws else None
         da = torch.empty_like(u) if need_du else None           # gradient reaching gelu(u) through the spectral branch
         du = torch.empty_like(u) if need_du else None
         dw = torch.empty_like(w2)
@@ -1166,7 +1279,7 @@ def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=F
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_weights]
     wle = int(weight_last_extent) if weight_last_extent is not None else int(sw[0].shape[-2])
     direct = None
-    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(t.grad is not None and t.grad.is_contiguous() for t in spec_weights):
+    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(_same_layout(t.grad, t) for t in spec_weights):
         direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_weights]
     return _SpectralLayerFn.apply(u, w, bias, tuple(int(m) for m in modes), norm, wle, bool(input_gelu), direct, *sw)
 

@@ -8,8 +8,11 @@ from torch import nn
 from .... import functional as F
 
 
-def _cweight(cin, cout, *modes):
-    return nn.Parameter((1.0 / (cin * cout)) * torch.rand(cin, cout, *modes, dtype=torch.cfloat))
+def _cweight(cin, cout, *modes, planes=False):
+    """the reference's initial values (scale * U[0, 1) drawn in the reference's order); planes: stored with the last dim
+    outermost in memory (functional.plane_major) - shape, values and every tensor operation on it are unchanged"""
+    w = (1.0 / (cin * cout)) * torch.rand(cin, cout, *modes, dtype=torch.cfloat)
+    return nn.Parameter(F.to_plane_major(w) if planes else w)
 
 
 class SpectralConv2d(nn.Module):
@@ -36,15 +39,27 @@ class SpectralConv3d(nn.Module):
         self.modes1, self.modes2, self.modes3 = modes1, modes2, modes3
         self.scale = 1 / (in_channels * out_channels)
         for i in range(1, 5):
-            setattr(self, f"weights{i}", _cweight(in_channels, out_channels, modes1, modes2, modes3))
+            # plane-major: only min(Nz/2+1, modes3) last-dim slices ever see data (:119-139 of the reference file); with the
+            # last dim outermost they are one contiguous prefix of the tensor - the part the engine packs, Adam steps and
+            # the gradient exchange sends (PINObserverFullField at T = 1: 1/12 of 906 MB)
+            setattr(self, f"weights{i}", _cweight(in_channels, out_channels, modes1, modes2, modes3, planes=True))
 
     def direct_grad_params(self):
         return [self.weights1, self.weights2, self.weights3, self.weights4]
 
+    def _announce_live(self, k3):
+        """k3 last-dim modes are about to be read (and receive a gradient): trainer.live_last_of plans the live-slice
+        gradient exchange from it, and an optimizer that skips the dead slices (trainer.FusedAdam) brings them up to date
+        BEFORE a longer last dimension reads them."""
+        guard = self.__dict__.get("_dead_slice_guard")
+        if guard is not None:
+            guard(self, k3)
+        self._live_last = k3
+
     def engine_call(self, x):
         """(corner weights in the engine's order, kept modes, stored last-dim extent) for an input of x's shape"""
         k3 = min(x.shape[-1] // 2 + 1, self.modes3)
-        self._live_last = k3      # last-dim modes that receive a gradient (trainer.live_last_of: live-slice gradient exchange)
+        self._announce_live(k3)
         return [self.weights1, self.weights3, self.weights2, self.weights4], (self.modes1, self.modes2, k3), self.modes3
 
     def forward(self, x):
@@ -52,7 +67,7 @@ class SpectralConv3d(nn.Module):
         # (basics.py:125-139); the engine takes (lo,lo), (lo,hi), (hi,lo), (hi,hi).  Only
         # min(Nz/2+1, modes3) last-dim modes are live (:119,:125-126); the rest get zero gradient.
         k3 = min(x.shape[-1] // 2 + 1, self.modes3)
-        self._live_last = k3
+        self._announce_live(k3)
         return F.spectral_conv(x, [self.weights1, self.weights3, self.weights2, self.weights4], None,
                                (self.modes1, self.modes2, k3), "backward", weight_last_extent=self.modes3,
                                direct_grads=getattr(self, "_direct_grads", False))

@@ -70,12 +70,19 @@ def save_if_best(model, test_l2, best, path, rank, log):
         # process group and pending Work handle; direct-write flags; cached device grids): not part of a checkpoint
         stripped = []
         for m in model.modules():
-            for k in ("_grad_overlap", "_direct_grads", "_grid_cache"):
+            for k in ("_grad_overlap", "_direct_grads", "_grid_cache", "_dead_slice_guard", "_dead_slice_k"):
                 if k in m.__dict__:
                     stripped.append((m, k, m.__dict__.pop(k)))
+        # FusedAdam keeps every parameter as a view of ONE float32 buffer - complex weights as complex views of it, which
+        # torch.save refuses ("tensors that view the same data as different types"): the pickle gets private copies
+        views = [(p, p.data) for p in model.parameters()]
         try:
+            for p, d in views:
+                p.data = d.clone()
             torch.save(model, path)
         finally:
+            for p, d in views:
+                p.data = d
             for m, k, v in stripped:
                 m.__dict__[k] = v
         log(f"Best model saved at {path}!")
@@ -159,6 +166,7 @@ def run(args, log=print):
         rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
                    seconds=time.perf_counter() - t0)
         history.append(rec)
+        opt.sync_dead_slices()       # (whole-module pickles read the parameters directly)
         best = save_if_best(model, rec["test_l2"], best, getattr(args, "save_path", None), rank, log)
         if rank == 0:
             log(f"epoch {ep}: train rel-L2 {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")
@@ -186,7 +194,9 @@ def run_full_field(args, idx, dev, rank, world, log):
         s0 = train_ds[0][0]
         enable_dp_exchange(bucket, model, (torch.as_tensor(s0)[None].to(dev).float().permute(0, 2, 3, 1).unsqueeze(-1),
                                            torch.full((1, 1), 180.0, device=dev)))
-    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay)
+    # the dead last-dim slices of the spectral weights (11/12 of them at T = 1) are replayed, not stepped: the loop reads the
+    # weights through model.state_dict() / optimizer.state_dict() only, which bring them up to date first
+    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay, skip_dead_slices=True)
     env = None
     if args.pde_loss_weight > 0:
         Nx, Ny, Nz = train_ds[0][3].shape[1:]
@@ -223,6 +233,7 @@ def run_full_field(args, idx, dev, rank, world, log):
         rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
                    seconds=time.perf_counter() - t0)
         history.append(rec)
+        opt.sync_dead_slices()       # (whole-module pickles read the parameters directly)
         best = save_if_best(model, rec["test_l2"], best, getattr(args, "save_path", None), rank, log)
         if rank == 0:
             log(f"epoch {ep}: train loss {rec['train_l2']:.5f}  test rel-L2 {rec['test_l2']:.5f}  {rec['seconds']:.2f} s")

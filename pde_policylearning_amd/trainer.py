@@ -216,7 +216,18 @@ class FlatGradBucket(object):
         for p in self.params:
             k = self._nfloat(p)
             seg = flat[off:off + k]
-            out.append(torch.view_as_complex(seg.view(*p.shape, 2)) if p.is_complex() else seg.view_as(p))
+            if p.is_contiguous():
+                out.append(torch.view_as_complex(seg.view(*p.shape, 2)) if p.is_complex() else seg.view_as(p))
+            else:
+                # a dense parameter in another memory order (plane-major dialect-C weights, functional.plane_major): the
+                # same order inside the bucket, so that the engine, the optimizer and the exchange see one layout
+                base = torch.view_as_complex(seg.view(-1, 2)) if p.is_complex() else seg
+                expect = 1
+                for size, stride in sorted(zip(p.shape, p.stride()), key=lambda t: t[1]):
+                    if size > 1 and stride != expect:
+                        raise RuntimeError("FlatGradBucket: parameters must be dense (a permutation of a contiguous tensor)")
+                    expect *= size
+                out.append(base.as_strided(p.shape, p.stride()))
             off += k
         return out
 
@@ -497,14 +508,54 @@ def live_last_of(model):
     return out
 
 
+class _DeadSliceGuard(object):
+    """What FusedAdam leaves on a model whose dead weight slices it skips: called by a dialect-C spectral convolution before
+    it reads more last-dim slices than the plan holds live, and (before_state_dict) by the model's state_dict().  Holds weak
+    references only; pickles / deep-copies as a detached no-op (torch.save(model) of run_pde_observers.py:307-315 keeps
+    working - call optimizer.sync_dead_slices() first, as train_observer does)."""
+
+    def __init__(self, opt=None, model=None):
+        import weakref
+        self._opt = weakref.ref(opt) if opt is not None else (lambda: None)
+        self._model = weakref.ref(model) if model is not None else (lambda: None)
+
+    def __call__(self, module, k3):
+        opt, root = self._opt(), self._model()
+        if opt is not None and root is not None and opt._runs is not None and k3 > module.__dict__.get("_dead_slice_k", k3):
+            module._live_last = k3
+            opt.skip_dead_slices(root)
+
+    def before_state_dict(self, *args, **kwargs):
+        opt = self._opt()
+        if opt is not None:
+            opt.sync_dead_slices()
+
+    def __reduce__(self):
+        return (_DeadSliceGuard, ())
+
+
 class FusedAdam(object):
     """torch.optim.Adam semantics (run_pde_observers.py:134: lr, weight_decay, default betas / eps) as ONE
     kernel over a flat parameter bucket.  Parameters are re-pointed at views of one contiguous buffer
-    laid out exactly like the FlatGradBucket, so the step reads the all-reduced gradient bucket directly."""
+    laid out exactly like the FlatGradBucket, so the step reads the all-reduced gradient bucket directly.
 
-    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+    Dead last-dim slices (skip_dead_slices): a dialect-C 3-D spectral weight (.., modes3) only ever sees data in
+    [..., :k], k = min(Nz/2+1, modes3) (libs/models/pino_models/basics.py:119-139; PINObserverFullField at T = 1: 1/12 of
+    906 MB).  The gradient of the rest is exactly zero, so Adam's effect on it is a recurrence on (p, m, v) alone
+    (g = weight_decay * p): those elements are not stepped - the step touches the live slices (moments kept compact) and the
+    rest of the bucket - and are REPLAYED through the skipped steps in one kernel, bit-identical to stepping them every
+    time, whenever somebody needs them: state_dict() / load_state_dict() here, the model's state_dict() (pre-hook), a
+    forward pass with a longer last dimension (the modules call back before they read the weights), sync_dead_slices().
+    Reading a weight's `.data` directly in between shows the dead slice as of the last replay - hence opt-in
+    (skip_dead_slices=True: train_observer's full-field loop, bench.py).  The live extents are taken from the bucket's
+    direct_module at the first step (after a forward pass has recorded them)."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False,
+                 skip_dead_slices=False):
         """capturable: keep the step count on the device (fno_adam_step_dev) so that a captured hipGraph of
-        the training step (GraphedTrainStep) can be replayed."""
+        the training step (GraphedTrainStep) can be replayed.
+        skip_dead_slices: see the class docstring - opt-in, because code that reads `parameter.data` directly between steps
+        (instead of state_dict()) would see the dead slices as of the last replay."""
         self.bucket = bucket
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.capturable = capturable
@@ -518,16 +569,203 @@ class FusedAdam(object):
         self.exp_avg = torch.zeros_like(bucket.flat)
         self.exp_avg_sq = torch.zeros_like(bucket.flat)
         self.step_count = 0
+        self._skip_dead = bool(skip_dead_slices)
+        self._runs = None            # lazy layout: [("dense", off, n, coff) | ("rows", off, rows, row_len, live_len, coff)]
+        self._dead = {}              # rows-run index -> [dead exp_avg, dead exp_avg_sq] (compact) or None (all zero)
+        self._dead_step = 0          # the step count the dead slices (parameters and moments) are current at
+        self._hp_log = []            # [(first step, lr, beta1, beta2, eps, weight_decay)]: what the skipped steps used
+        self._guarded, self._sd_hook = [], None
 
+    # ---- dead slices -----------------------------------------------------------------------------------------------
+    def _hyper(self):
+        return (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
+
+    def _current_step(self):
+        return int(self.step_dev.item()) if self.capturable else self.step_count
+
+    def skip_dead_slices(self, model=None, live_last=None):
+        """Plan the step around the dead last-dim slices of `model`'s dialect-C weights (default: the bucket's
+        direct_module; live extents as recorded by its last forward pass, or `live_last` = {parameter: k}).  Returns
+        whether anything is skipped.  Called by step() on its own the first time; call it again after a change."""
+        model = model if model is not None else self.bucket.direct_module
+        if live_last is None:
+            live_last = {}
+            for m in (model.modules() if model is not None else ()):
+                k = m.__dict__.get("_live_last")
+                if k is not None and hasattr(m, "modes3"):
+                    k = max(int(k), int(m.__dict__.get("_dead_slice_k", 0)))      # a plan never shrinks
+                    m._live_last = k
+                    live_last.update({w: k for w in (m.weights1, m.weights2, m.weights3, m.weights4)})
+        live = {id(p): int(k) for p, k in live_last.items() if p.is_complex() and 0 < int(k) < p.shape[-1]}
+        self.sync_dead_slices()
+        full = self._full_moments() if self._runs is not None else (self.exp_avg, self.exp_avg_sq)
+        runs, off, coff, ok = [], 0, 0, bool(live)
+        for p in self.bucket.params:
+            n = self.bucket._nfloat(p)
+            k = live.get(id(p))
+            if k is not None:
+                from . import functional as F
+                if F.plane_major(p):         # last dim outermost in memory: the live planes are a prefix of the tensor
+                    rows, row_len, live_len = 1, n, n // p.shape[-1] * k
+                elif p.is_contiguous():      # last dim innermost: the live part is the head of every row of 2 * modes3 floats
+                    row_len, live_len = 2 * p.shape[-1], 2 * k
+                    rows = n // row_len
+                else:
+                    ok = False
+                    rows, row_len, live_len = 1, n, n
+                ok = ok and off % 2 == 0
+                last = runs[-1] if runs else None
+                if last and last[0] == "rows" and last[3:5] == (row_len, live_len):
+                    runs[-1] = ("rows", last[1], last[2] + rows, row_len, live_len, last[5])
+                else:
+                    coff += -coff % 4
+                    runs.append(("rows", off, rows, row_len, live_len, coff))
+                coff += rows * live_len
+            else:
+                last = runs[-1] if runs else None
+                if last and last[0] == "dense":
+                    runs[-1] = ("dense", last[1], last[2] + n, last[3])
+                else:
+                    coff += -coff % 4
+                    ok = ok and off % 4 == 0
+                    runs.append(("dense", off, n, coff))
+                coff += n
+            off += n
+        self._release_guards()
+        if not ok:
+            if self._runs is not None:
+                self._runs, self._dead = None, {}
+                self.exp_avg, self.exp_avg_sq = full
+            return False
+        self._runs, self._dead = runs, {}
+        self.exp_avg = torch.zeros(coff, dtype=torch.float32, device=self.flat_param.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self._scatter_full(*full)
+        self._dead_step = self._current_step()
+        self._hp_log = []
+        if model is not None:
+            import weakref
+            guard = _DeadSliceGuard(self, model)
+            for m in model.modules():
+                if m.__dict__.get("_live_last") is not None and hasattr(m, "modes3"):
+                    m._dead_slice_k = int(m._live_last)
+                    m._dead_slice_guard = guard
+                    self._guarded.append(weakref.ref(m))
+            if hasattr(model, "register_state_dict_pre_hook"):
+                self._sd_hook = model.register_state_dict_pre_hook(guard.before_state_dict)
+        return True
+
+    def _release_guards(self):
+        for r in self._guarded:
+            m = r()
+            if m is not None:
+                m.__dict__.pop("_dead_slice_guard", None)
+                m.__dict__.pop("_dead_slice_k", None)
+        self._guarded = []
+        if self._sd_hook is not None:
+            self._sd_hook.remove()
+            self._sd_hook = None
+
+    def close(self):
+        """Bring the dead slices up to date and drop the hooks on the model."""
+        self.sync_dead_slices()
+        self._release_guards()
+
+    def sync_dead_slices(self):
+        """Replay the steps the dead slices have skipped (parameters and moments), so that every parameter holds the value
+        torch.optim.Adam would have left in it.  Cheap when nothing is pending."""
+        if self._runs is None:
+            return
+        from . import functional as F
+        t0, t = self._dead_step, self._current_step()
+        if t <= t0:
+            return
+        log = self._hp_log or [(t0 + 1,) + self._hyper()]
+        for i, seg in enumerate(log):
+            first = max(seg[0], t0 + 1)
+            last = (log[i + 1][0] - 1) if i + 1 < len(log) else t
+            if last < first:
+                continue
+            lr, b1, b2, eps, wd = seg[1:]
+            scal = None
+            for ri, run in enumerate(self._runs):
+                if run[0] != "rows":
+                    continue
+                dead = self._dead.get(ri)
+                if wd == 0.0 and dead is None:
+                    continue      # zero gradient, zero moments: Adam leaves the element where it is
+                if scal is None:
+                    scal = F.adam_replay_scalars(first, last - first + 1, lr, (b1, b2), self.flat_param.device,
+                                                 on_device=self.capturable)
+                _, off, rows, row_len, live_len, _ = run
+                zero = dead is None
+                if zero:
+                    dead = [torch.empty(rows * (row_len - live_len), dtype=torch.float32, device=self.flat_param.device)
+                            for _ in range(2)]
+                    self._dead[ri] = dead
+                F.adam_replay_dead(rows, row_len, live_len, self.flat_param[off:off + rows * row_len], dead[0], dead[1], zero,
+                                   scal, (b1, b2), eps, wd)
+        self._dead_step = t
+        self._hp_log = []
+
+    def _full_moments(self):
+        """(exp_avg, exp_avg_sq) in the bucket's full layout (new tensors) from the compact live + dead representation."""
+        out = []
+        for which, comp in ((0, self.exp_avg), (1, self.exp_avg_sq)):
+            full = torch.zeros_like(self.flat_param)
+            for ri, run in enumerate(self._runs):
+                if run[0] == "dense":
+                    _, off, n, coff = run
+                    full[off:off + n] = comp[coff:coff + n]
+                else:
+                    _, off, rows, row_len, live_len, coff = run
+                    v = full[off:off + rows * row_len].view(rows, row_len)
+                    v[:, :live_len] = comp[coff:coff + rows * live_len].view(rows, live_len)
+                    if self._dead.get(ri) is not None:
+                        v[:, live_len:] = self._dead[ri][which].view(rows, row_len - live_len)
+            out.append(full)
+        return tuple(out)
+
+    def _scatter_full(self, m_full, v_full):
+        """Take moments given in the bucket's full layout into the current representation."""
+        if self._runs is None:
+            self.exp_avg.copy_(m_full); self.exp_avg_sq.copy_(v_full)
+            return
+        self._dead = {}
+        for ri, run in enumerate(self._runs):
+            if run[0] == "dense":
+                _, off, n, coff = run
+                self.exp_avg[coff:coff + n] = m_full[off:off + n]
+                self.exp_avg_sq[coff:coff + n] = v_full[off:off + n]
+            else:
+                _, off, rows, row_len, live_len, coff = run
+                mv = m_full[off:off + rows * row_len].view(rows, row_len)
+                vv = v_full[off:off + rows * row_len].view(rows, row_len)
+                self.exp_avg[coff:coff + rows * live_len].view(rows, live_len).copy_(mv[:, :live_len])
+                self.exp_avg_sq[coff:coff + rows * live_len].view(rows, live_len).copy_(vv[:, :live_len])
+                if bool(mv[:, live_len:].any()) or bool(vv[:, live_len:].any()):
+                    self._dead[ri] = [mv[:, live_len:].contiguous().view(-1), vv[:, live_len:].contiguous().view(-1)]
+
+    # ---- torch.optim surface ----------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
         self.bucket.zero()
 
     def step(self):
         from . import functional as F
         self.bucket.check_views()
+        if self._skip_dead and self._runs is None and self.bucket.direct_module is not None:
+            self._skip_dead = False      # one attempt; skip_dead_slices() can be called again by hand
+            self.skip_dead_slices()
         self.step_count += 1            # host mirror; under graph replay the device counter is authoritative
-        F.adam_step(self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                    self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
+        if self._runs is None:
+            F.adam_step(self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                        self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
+            return
+        hp = self._hyper()
+        if not self._hp_log or self._hp_log[-1][1:] != hp:
+            self._hp_log.append((self.step_count,) + hp)
+        F.adam_step_runs(self._runs, self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                         self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
 
     def state_dict(self):
         """torch.optim.Adam's layout ({'state': {i: step / exp_avg / exp_avg_sq}, 'param_groups': [...]}, parameters numbered
@@ -535,9 +773,11 @@ class FusedAdam(object):
         (libs/pino_utils/utils.py:178-194) load into torch.optim.Adam and back."""
         if self.capturable:
             self.step_count = int(self.step_dev.item())
+        self.sync_dead_slices()
+        m_full, v_full = self._full_moments() if self._runs is not None else (self.exp_avg, self.exp_avg_sq)
         pos = {id(p): i for i, p in enumerate(self.bucket.user_order)}
         state = {}
-        for p, m, v in zip(self.bucket.params, self.bucket.views(self.exp_avg), self.bucket.views(self.exp_avg_sq)):
+        for p, m, v in zip(self.bucket.params, self.bucket.views(m_full), self.bucket.views(v_full)):
             if self.step_count > 0:
                 state[pos[id(p)]] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m.detach().clone(),
                                          exp_avg_sq=v.detach().clone())
@@ -554,17 +794,17 @@ class FusedAdam(object):
         order = self.bucket.user_order
         if len(group["params"]) != len(order):
             raise ValueError(f"optimizer state holds {len(group['params'])} parameters, the bucket {len(order)}")
+        self.sync_dead_slices()          # (the parameters stay: bring their dead slices to the step being replaced)
         self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
         self.weight_decay = group["weight_decay"]
-        mv = {id(p): (m, v) for p, m, v in zip(self.bucket.params, self.bucket.views(self.exp_avg),
-                                                self.bucket.views(self.exp_avg_sq))}
+        m_full, v_full = torch.zeros_like(self.flat_param), torch.zeros_like(self.flat_param)
+        mv = {id(p): (m, v) for p, m, v in zip(self.bucket.params, self.bucket.views(m_full), self.bucket.views(v_full))}
         steps = set()
         with torch.no_grad():
             for i, p in enumerate(order):
                 st = sd["state"].get(group["params"][i], sd["state"].get(i))
                 m, v = mv[id(p)]
                 if st is None:
-                    m.zero_(); v.zero_()
                     continue
                 if tuple(st["exp_avg"].shape) != tuple(p.shape):
                     raise ValueError(f"optimizer state of parameter {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
@@ -573,9 +813,11 @@ class FusedAdam(object):
         if len(steps) > 1:
             raise ValueError(f"optimizer state with different step counts per parameter ({sorted(steps)}): one flat Adam step "
                              "cannot represent it")
+        self._scatter_full(m_full, v_full)
         self.step_count = steps.pop() if steps else 0
         if self.capturable:
             self.step_dev.fill_(self.step_count)
+        self._dead_step, self._hp_log = self.step_count, []
 
 
 def broadcast_parameters(module, src=0, group=None):
@@ -634,6 +876,13 @@ class GraphedTrainStep(object):
         self.inputs = [t.clone() for t in inputs]
         self.target = target.clone()
         opt = optimizer
+        if opt._skip_dead and opt._runs is None and bucket.direct_module is not None:
+            # the optimizer plans its dead-slice layout at its first step: do it now (one forward pass records the live
+            # extents), so that the snapshot below and the captured launches see the final buffers
+            with torch.no_grad():
+                model_fn(*self.inputs)
+            opt._skip_dead = False
+            opt.skip_dead_slices()
         snap = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev, bucket.flat)]
         host_step = opt.step_count
         side = torch.cuda.Stream()

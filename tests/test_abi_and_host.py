@@ -33,9 +33,9 @@ def test_header_symbols_exported(lib):
 
 def test_struct_layout_matches_header(lib):
     from pde_policylearning_amd import _lib
-    # FnoSpecDesc: 3 + 3 + 3 + 3 ints ; FnoModelDesc: 6 + 3 + 3 + 2 ints
-    assert ctypes.sizeof(_lib.FnoSpecDesc) == 12 * 4
-    assert ctypes.sizeof(_lib.FnoModelDesc) == 14 * 4
+    # FnoSpecDesc: 3 + 3 + 3 + 4 ints ; FnoModelDesc: 6 + 3 + 3 + 3 ints
+    assert ctypes.sizeof(_lib.FnoSpecDesc) == 13 * 4
+    assert ctypes.sizeof(_lib.FnoModelDesc) == 15 * 4
     assert ctypes.sizeof(_lib.FnoModelParams) == 8 * (2 + 16 + 64 + 1 + 4)
 
 
@@ -411,3 +411,58 @@ def test_rno2d_accepts_list_pad_amount_and_picks_the_narrowest_twin():
     m = RNO2d(4, 4, 20, 0, layer_num=1, pad_amount=[2, 2], pad_dim='both')
     assert m._wide_twin().width == 32
     assert RNO2d(4, 4, 34, 0, layer_num=1)._wide_twin().width == 64
+
+
+def test_fused_adam_dead_slice_plan_on_cpu():
+    """FusedAdam.skip_dead_slices: the layout plan (row-sliced blocks merged, compact moment offsets 16-byte aligned), the
+    full <-> compact moment round trip, re-planning when a module announces a longer live extent, and hook release -
+    host logic only (the kernels: tests/test_lazy_adam_gpu.py)."""
+    from torch import nn
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam
+
+    class Conv(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.modes3 = 6
+            for i in range(1, 5):
+                setattr(self, f"weights{i}", nn.Parameter(torch.rand(2, 2, 3, 3, 6, dtype=torch.cfloat)))
+            self._live_last = 2
+
+        def direct_grad_params(self):
+            return [self.weights1, self.weights2, self.weights3, self.weights4]
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.c, self.b = nn.Linear(4, 4), Conv(), nn.Linear(4, 3)
+
+    m = Net()
+    bucket = FlatGradBucket(m.parameters(), direct_module=m)
+    opt = FusedAdam(bucket, weight_decay=1e-4, skip_dead_slices=True)
+    assert opt.skip_dead_slices() is True
+    assert opt._runs == [("rows", 0, 144, 12, 4, 0), ("dense", 1728, 35, 576)]
+    assert opt.exp_avg.numel() == 576 + 35 and bucket.flat.numel() == 1728 + 35
+    opt.exp_avg.copy_(torch.arange(opt.exp_avg.numel(), dtype=torch.float32))
+    opt.exp_avg_sq.copy_(torch.arange(opt.exp_avg.numel(), dtype=torch.float32) * 2)
+    before = opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+    full = opt._full_moments()
+    assert full[0].numel() == bucket.flat.numel()
+    assert torch.equal(full[0][:12], torch.tensor([0., 1, 2, 3] + [0.] * 8))          # live pairs, then the dead part of row 0
+    opt._scatter_full(*full)
+    assert torch.equal(opt.exp_avg, before[0]) and torch.equal(opt.exp_avg_sq, before[1]) and opt._dead == {}
+    # dead moments that are not zero (a loaded checkpoint) are kept beside the compact ones
+    full[0][4] = 7.0
+    opt._scatter_full(*full)
+    assert 0 in opt._dead and float(opt._dead[0][0][0]) == 7.0
+    assert float(opt._full_moments()[0][4]) == 7.0
+    # a module about to read five slices re-plans (nothing is pending: no kernel runs), and a plan never shrinks
+    m.c._dead_slice_guard(m.c, 5)
+    assert opt._runs[0] == ("rows", 0, 144, 12, 10, 0) and float(opt._full_moments()[0][4]) == 7.0
+    m.c._live_last = 1
+    opt.skip_dead_slices()
+    assert opt._runs[0][4] == 10
+    # every slice live: nothing to skip, the optimizer is back on the full layout
+    m.c._dead_slice_guard(m.c, 6)
+    assert opt._runs is None and opt.exp_avg.numel() == bucket.flat.numel() and float(opt.exp_avg[4]) == 7.0
+    assert "_dead_slice_guard" not in m.c.__dict__
+    opt.close()

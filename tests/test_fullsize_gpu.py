@@ -43,13 +43,39 @@ def _oracle(forward, params, x, tgt, dtype, chunk):
     return torch.cat(ys).numpy(), g
 
 
-def _compare(model, y, params, y64, g64, g32):
+def _rounded_inputs(params, x, seed=1):
+    """float64 copies of (params, x) with every number moved by a seeded relative 2^-24 * U(-1, 1): what rounding the SAME
+    problem's inputs to float32 once would do.  The float64 gradient's answer to it is condition number x float32 epsilon -
+    the distance no float32 evaluation of this problem can be expected to stay under, whatever its summation order."""
+    gen = torch.Generator().manual_seed(seed)
+
+    def move(v):
+        if not (v.is_floating_point() or v.is_complex()):
+            return v
+        d = v.to(torch.complex128) if v.is_complex() else v.double()
+        return d * (1 + (torch.rand(v.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 2.0 ** -24)
+    return {k: move(v) for k, v in params.items()}, move(x)
+
+
+def _compare(model, y, params, y64, g64, g32, gcond=None):
+    """gcond: the float64 gradients of the problem with inputs moved by one float32 rounding (_rounded_inputs); where given,
+    the budget of an ill-conditioned gradient is BUDGET_SLACK x the larger of the reference's own float32 error and that
+    conditioning floor (the float32 error alone is ONE draw: for the scalar biases of the RNO cell it moved between 4e-6
+    and 5e-5 with the batch split and the host's thread count, tools/rno_debug.py)."""
     assert rel_l2(y.detach().cpu().numpy().reshape(y64.shape), y64) < TOL
     worst = ("", 0.0)
+    floor = {name: rel_l2(g32[name], g64[name]) for name in g64}
+    if gcond is not None:
+        floor = {name: max(f, rel_l2(gcond[name], g64[name])) for name, f in floor.items()}
+        # a single-number parameter's relative error is ONE draw, not a norm over many entries (its float32 and rounding
+        # floors above are single draws too: 4e-6 and 5e-6 for cell.b1 on one box, 5e-5 and 3e-5 on another): such
+        # parameters are held to the floor of the worst-conditioned tensor of the same model
+        top = max(floor.values())
+        floor = {name: (top if g64[name].size == 1 else f) for name, f in floor.items()}
     for name, prm in model.named_parameters():
         got = prm.grad
         got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
-        e, e32 = rel_l2(got, g64[name]), rel_l2(g32[name], g64[name])
+        e, e32 = rel_l2(got, g64[name]), floor[name]
         assert np.isfinite(got).all() and e < max(TOL, BUDGET_SLACK * e32), (name, e, e32)
         worst = max(worst, (name, e), key=lambda t: t[1])
     print(f"worst gradient vs float64 oracle: {worst[0]} {worst[1]:.2e}")
@@ -83,10 +109,13 @@ def test_rno2d_config3_fullsize_vs_oracle(dev):
     fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
     y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 8)
     _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
+    # (the recurrent cell's gradients answer a float32 rounding of the inputs with 2e-5 .. 1e-4: conditioning floor)
+    pr, xr = _rounded_inputs(params, x)
+    _, gcond = _oracle(fwd, pr, xr, tgt, torch.float64, 8)
     model = model.to(dev)
     y = model(x.to(dev))
     O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
-    _compare(model, y, params, y64, g64, g32)
+    _compare(model, y, params, y64, g64, g32, gcond)
 
 
 def test_fno3d_config4_fullsize_vs_oracle(dev):

@@ -1,0 +1,40 @@
+"""Full-size RNO2d (config 3) gradients against the float64 oracle, every parameter listed (env switches are read at
+library load, so run once per setting; the oracle result is cached in /tmp between runs of one gpurun call)."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import fno_oracle as O
+from oracle import observers_oracle as OO
+from oracle.detfill import fill_named
+from tests.util import rel_l2
+from tests.test_fullsize_gpu import _oracle
+from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+
+torch.manual_seed(0)
+model = RNO2dObserver(12, 12, 64, 0, layer_num=1).eval()
+params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+x = torch.from_numpy(fill_named("c3full.x", (32, 1, 128, 128, 1), 1.0))
+tgt = torch.from_numpy(fill_named("c3full.t", (32, 128, 128, 1), 1.0))
+cache = "/tmp/rno_dbg.npz"
+if os.path.exists(cache):
+    z = np.load(cache)
+    g64 = {k[4:]: z[k] for k in z.files if k.startswith("g64:")}
+    g32 = {k[4:]: z[k] for k in z.files if k.startswith("g32:")}
+    y64 = z["y64"]
+else:
+    fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
+    y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 8)
+    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
+    np.savez(cache, y64=y64, **{"g64:" + k: v for k, v in g64.items()}, **{"g32:" + k: v for k, v in g32.items()})
+dev = torch.device("cuda:0")
+model = model.to(dev)
+for rep in range(2):
+    model.zero_grad(set_to_none=True)
+    y = model(x.to(dev))
+    O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
+    print("run", rep, "y", rel_l2(y.detach().cpu().numpy().reshape(y64.shape), y64), flush=True)
+    for name, prm in model.named_parameters():
+        got = prm.grad
+        got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
+        print(f"  {name:40s} {rel_l2(got, g64[name]):.2e}  (torch f32 {rel_l2(g32[name], g64[name]):.2e})")
