@@ -1121,7 +1121,8 @@ static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds)
   if ((size_t)a.PW * 4 * C >= (size_t)1 << 31) return false;          // 32-bit buffer offsets within one sample
   if (a.z && a.K2in > 8) return false;      // more than 8 kept last-dim modes (two extension k blocks, e.g. RNO2d at 12): k_pw_fwd_x3
                                             // is as fast or faster (RNO2d 128^2: 0.085 vs 0.108 ms per launch)
-  if (C == 32 && !a.x1) return false;      // 32 channels without a row-DFT epilogue: k_pw_fwd_x3 is faster (59 vs 70 us at config-2 size)
+  if (C == 32) return false;      // 32 channels: k_pw_fwd_x3 is faster with and without a row-DFT epilogue (FNO3d 64^3: 0.298 vs 0.329 ms per launch,
+                                  // BASELINE config 1: 11.2 vs 11.7 us)
   *lds = blk_fwd_t_lds_bytes(C, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   return *lds + 2048 <= 160 * 1024;
 }
@@ -1405,7 +1406,10 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   float* wps = hats + (size_t)L * s.n_hat;                  // packed weights of every layer (kept for backward)
   float* wpts = wps + (size_t)L * s.n_wp;
   float* amax = wpts + (size_t)L * s.n_wp;                  // kNAmax magnitude bounds (fp16 two-term GEMMs)
-  const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= 32;
+  // two-term fp16 GEMMs with published magnitude bounds: from 1024 tiles up - below that the kernels are latency-bound and
+  // the bound bookkeeping (one more launch, the weight scans in the prologues) costs more than three matrix products
+  // save (BASELINE config 1, 128 tiles: 0.27 -> 0.22 ms per step without it)
+  const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= 32 && (size_t)B * g.PW >= ((size_t)1 << 17);
   if (h2 && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   {
     CornerPtrsL cp;
@@ -1474,6 +1478,8 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     a.relu_out = tail && tail->relu_out;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     if (h2) {      // magnitude bounds for the two-term fp16 GEMMs: every block publishes max |u_{l+1}| for its consumer
+      // (measured at 32 channels, FNO3d 64^3: tracking the maximum costs k_pw_fwd_x3 0.012 ms per launch, the fp16 products
+      // it enables save the block backward 0.017 ms per launch)
       a.umax = amax + 8 + l + 1;
       if (l == 0) { a.xmax = (a.lw && lift_xmax) ? amax + 7 : nullptr; a.ubound = amax + 8; }   // (an unfused u_0 has no published bound)
       else a.xmax = amax + 8 + l;

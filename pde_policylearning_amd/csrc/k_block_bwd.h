@@ -117,9 +117,11 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, tid);
-    pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
-    if (tid < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+    int t = tid;
+    asm volatile("" : "+v"(t));      // (keeps the per-lane 64-bit prefetch addresses out of the loop-invariant registers: k_pw_fwd_x3)
+    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, t);
+    pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, t);
+    if (t < zcount4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * t);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
@@ -354,15 +356,17 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, tid);
+    int t = tid;
+    asm volatile("" : "+v"(t));      // (see k_pw_fwd_x3: no hoisted per-lane 64-bit prefetch addresses)
+    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, t);
     if constexpr (LIFT) {     // this thread's 4 pixels of the <= 4 input rows (q = tid % (NPX / 4) for all its items)
-      const float* xb = a.xin + (size_t)b * a.CL * a.PW + px0 + 4 * (tid % (NPX / 4));
+      const float* xb = a.xin + (size_t)b * a.CL * a.PW + px0 + 4 * (t % (NPX / 4));
 #pragma unroll
       for (int k = 0; k < 4; ++k) xl[k] = k < a.CL ? ld4(xb + (size_t)k * a.PW) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, tid);
+      pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, t);
     }
-    if (tid < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+    if (t < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * t);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
   auto put_row4 = [&](unsigned short* img, int c, int q, const float4& t) {   // 4 pixels of row c -> 3 terms

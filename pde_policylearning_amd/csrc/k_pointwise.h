@@ -65,7 +65,7 @@ static inline size_t pw_fwd_lds_bytes(int cin, int cout, int npx, int W, int K2i
 }
 
 template <int CIN, int COUT, int NPX>
-__global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, CIN <= 4 ? 6 : FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
+__global__ void __launch_bounds__((COUT / 32) * (NPX / 32) * 64, CIN <= 4 ? (COUT * NPX >= 64 * 128 ? 2 : 4) : FNO_OCC_PW) k_pw_fwd(PwFwdArgs a) {
   constexpr int NTN = NPX / 32;          // pixel sub-tiles
   constexpr int MT = COUT / 32;          // channel sub-tiles
   constexpr int NW = MT * NTN;
@@ -313,14 +313,17 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
   auto issue = [&](int tile) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
-    if constexpr (LIFT) pfl.issue(a.x + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, tid);
-    else pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, tid);
-    if (tid < zc4(px0)) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
+    // the thread index goes through an opaque move: hoisted out of the tile loop, the per-lane 64-bit base addresses of the
+    // two prefetches were the four registers that did not fit (20-24 bytes of scratch per lane at 64 channels)
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    if constexpr (LIFT) pfl.issue(a.x + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, t);
+    else pf.issue(a.x + (size_t)b * C * a.PW + px0, a.PW, t);
+    if (t < zc4(px0)) zpf = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * t);
   };
   if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
   int tslot = 0;
-  float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(FNO_TRACE_SEL);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
@@ -368,6 +371,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     FNO_STAMP(tslot + 4);
 
     {
+      float vmax = 0.f;          // max |u| this thread stores for the tile (a.umax; published per tile: a value that lived
+                                 // across the tile loop cost 12 bytes of scratch per lane at the 256-register limit)
       const float* bp = a.bias ? a.bias + mt * 32 + 4 * half : nullptr;
       float bv[16];
 #pragma unroll
@@ -406,6 +411,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
           }
         }
       }
+      if (a.umax) absmax_publish(vmax, a.umax);
     }
     FNO_STAMP(tslot + 5);
     if (a.x1) {
@@ -417,7 +423,6 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     __syncthreads();
     tslot += 8;
   }
-  if (a.umax) absmax_publish(vmax, a.umax);
 }
 
 // ---------------------------------------------------------------------------

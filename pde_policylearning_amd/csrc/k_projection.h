@@ -64,8 +64,11 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PF) k_proj_fwd(ProjFwdArgs a)
     __syncthreads();
     {
       const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+      if (nt2 < a.ntiles) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));      // (no hoisted per-lane 64-bit prefetch addresses: k_pw_fwd_x3)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, t_);
+      }
     }
     float ysum[NCO];
 #pragma unroll
@@ -213,8 +216,11 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
     __syncthreads();
     {
       const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+      if (nt2 < a.ntiles) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));      // (no hoisted per-lane 64-bit prefetch addresses: k_pw_fwd_x3)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, t_);
+      }
     }
     float dyl[NCO];
 #pragma unroll
@@ -477,8 +483,11 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs
     FNO_STAMP(tslot + 2);
     {
       const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+      if (nt2 < a.ntiles) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));      // (no hoisted per-lane 64-bit prefetch addresses: k_pw_fwd_x3)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, t_);
+      }
     }
     // split pass: fp32 tile [c][px] -> pixel-major bf16x3 image (A1's B operand)
     for (int it = tid; it < NPX * (C / 8); it += NT) {
@@ -743,8 +752,11 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
     __syncthreads();
     {
       const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
+      if (nt2 < a.ntiles) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));      // (no hoisted per-lane 64-bit prefetch addresses: k_pw_fwd_x3)
+        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, t_);
+      }
     }
 #ifndef FNO_PFWD_STAGGER
 #define FNO_PFWD_STAGGER 0

@@ -874,7 +874,8 @@ class GraphedTrainStep(object):
     def __init__(self, model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None, warmup=2):
         assert isinstance(optimizer, FusedAdam) and optimizer.capturable, "GraphedTrainStep needs FusedAdam(capturable=True)"
         self.inputs = [t.clone() for t in inputs]
-        self.target = target.clone()
+        # (objectives with several reference tensors take a tuple: trainer.FullFieldObjective, PinoObjective)
+        self.target = tuple(t.clone() for t in target) if isinstance(target, (tuple, list)) else target.clone()
         opt = optimizer
         if opt._skip_dead and opt._runs is None and bucket.direct_module is not None:
             # the optimizer plans its dead-slice layout at its first step: do it now (one forward pass records the live
@@ -912,8 +913,11 @@ class GraphedTrainStep(object):
             for dst, src in zip(self.inputs, inputs):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
-        if target is not None and target.data_ptr() != self.target.data_ptr():
-            self.target.copy_(target)
+        if target is not None:
+            pairs = zip(self.target, target) if isinstance(self.target, tuple) else ((self.target, target),)
+            for dst, src in pairs:
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
         self.graph.replay()
         return self.loss
 
