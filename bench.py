@@ -571,7 +571,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "gemm_mode": "bf16x3-split (fp32 operands as 3 bf16 terms, 6 products, fp32 accumulate on the bf16 matrix pipe)"
+            "gemm_mode": ("split precision, fp32 in / fp32 accumulate / fp32 out: projection and block-backward GEMMs on two fp16 terms "
+                          "per operand scaled by published magnitude bounds (3 products), block-forward GEMMs and small problems "
+                          "on three bf16 terms (6 products); parity held at 1e-5 against the float64 oracle")
                          if _lib.lib().fno_get_gemm_mode() == 1 else "f32 (v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
             "repeats": len(blocks),

@@ -1,14 +1,18 @@
 #!/bin/bash
-# usage (GPU box, from the repo root): tools/collect_profiles.sh <tag> [quick]   -> gpurun_out/<tag>_*
+# usage (GPU box, from the repo root): tools/collect_profiles.sh <tag> [quick|bench|prof]   -> gpurun_out/<tag>_*
+# (the whole set takes longer than one gpurun call may: `bench` = the bench lines of every workload, `prof` = headline line +
+# kernel-trace stats of four workloads + the PMC passes, `quick` = headline line + its stats + the PMC passes)
 # bench JSON lines (headline + secondary workloads), rocprofv3 kernel-trace stats, the two HBM-traffic PMC passes and
 # two SQ passes (matrix-pipe busy cycles, VALU / wait cycles) - every --pmc pass is its own run with --kernel-trace only.
 # Every step runs under `timeout` and appends to files (a silent hang would otherwise eat the GPU budget).
 tag="$1"; quick="$2"; R=$PWD; out=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp; cd $R
 T="timeout -k 5 240"
+if [ "$quick" != "bench" ]; then
 $T python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "headline done" >> $out/${tag}_progress.log
-if [ -z "$quick" ]; then
+fi
+if [ -z "$quick" ] || [ "$quick" = "bench" ]; then
 $T python3 bench.py --config fno2d_64x64_w32_m8_b4 --steps 50 > $out/${tag}_bench_cfg1.json 2>> $out/${tag}_bench.err
 $T python3 bench.py --config fno2d_64x64_w32_m8_b4 --no-cpu-baseline --steps 50 --eager > $out/${tag}_bench_cfg1_eager.json 2>> $out/${tag}_bench.err
 $T python3 bench.py --config fno3d_64_w32_m8_b16 --steps 10 > $out/${tag}_bench_fno3d.json 2>> $out/${tag}_bench.err
@@ -18,7 +22,9 @@ for c in rno2d_128x128_w64_m12_b32 rno2d_32x32_w34_m12_b32 pino_fullfield_32x32_
   echo "$c done" >> $out/${tag}_progress.log
 done
 $T python3 bench.py --config rno2d_128x128_w64_m12_b32 --steps 10 --warmup 3 --graph --no-cpu-baseline > $out/${tag}_bench_rno2d_128x128_w64_m12_b32_graph.json 2>> $out/${tag}_bench.err
+$T python3 bench.py --config pino_fullfield_32x32_w64_m12_b32 --steps 10 --warmup 3 --eager --no-cpu-baseline > $out/${tag}_bench_pino_fullfield_32x32_w64_m12_b32_eager.json 2>> $out/${tag}_bench.err
 fi
+[ "$quick" = "bench" ] && exit 0
 prof() {   # prof <name> <bench args...>: kernel-trace stats of one workload
   local name=$1; shift
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_$name -- python3 bench.py "$@" --no-cpu-baseline > $out/${tag}_stats_$name.log 2>&1
@@ -27,7 +33,8 @@ prof() {   # prof <name> <bench args...>: kernel-trace stats of one workload
 }
 prof headline --steps 20 --warmup 3
 cp $out/${tag}_kernel_stats_headline.csv $out/${tag}_kernel_stats.csv
-if [ -z "$quick" ]; then
+if [ -z "$quick" ] || [ "$quick" = "prof" ]; then
+prof pino_fullfield --config pino_fullfield_32x32_w64_m12_b32 --steps 10 --warmup 3 --eager
 prof fno3d --config fno3d_64_w32_m8_b16 --steps 10 --warmup 3
 prof rno2d --config rno2d_128x128_w64_m12_b32 --steps 10 --warmup 3
 prof pino_finetune_256 --config pino_finetune_256x256x65_w64_m20_b1 --steps 5 --warmup 2
