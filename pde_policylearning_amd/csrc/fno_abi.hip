@@ -1192,17 +1192,24 @@ static size_t bbwd_t_lds(int C, const BlkBwdArgs& a) {
           (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(128 / a.W) * a.K2in * C * 2 : 0) +
           (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
 }
-// k_block_bwd_g2: per group two [3][64][64] bf16 images, a 64 x 68 fp32 half-tile, the tile's spectral rows, two
+// k_block_bwd_g2: per group two [nterm][64][64] 16-bit images, a 64 x 68 fp32 half-tile, the tile's spectral rows, two
 // lifting-input buffers; shared tables; two barrier counters
-static size_t bbwd_g2_lds(const BlkBwdArgs& a) {
-  return (size_t)4 * 3 * 64 * 128 +
-         ((size_t)2 * 64 * 68 + (a.zg ? (size_t)2 * (128 / a.W) * a.K2in * 64 * 2 + (size_t)2 * a.K2in * a.W : 0) +
-          (a.xin ? 2 * 2 * 8 * 68 : 0) + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0) + 4) * 4;
+static size_t bbwd_g2_lds(const BlkBwdArgs& a, int nterm = 3) {
+  // spectral K-extension operands: fp32 rows + table, or (kx16) the bf16x3 images [3][rows][64][16] per group + [3][W][16]
+  const size_t kext = !a.zg ? 0 : a.kx16 ? (size_t)2 * 3 * (128 / a.W) * 64 * 32 + (size_t)3 * a.W * 32
+                                         : ((size_t)2 * (128 / a.W) * a.K2in * 64 * 2 + (size_t)2 * a.K2in * a.W) * 4;
+  return (size_t)4 * nterm * 64 * 128 + kext +
+         ((size_t)2 * 64 * 68 + (a.xin ? 2 * 2 * 8 * 68 : 0) + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0) + 4) * 4;
 }
 template <int C>
-static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a, bool* published = nullptr) {
+static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a_in, bool* published = nullptr) {
+  static const int kx_f32 = getenv("FNO_BBWD_KEXT_F32") ? 1 : 0;      // A/B switch: the K-extension of k_block_bwd_g2 as fp32 MFMAs
+  BlkBwdArgs a = a_in;
   const size_t pitch = p->NPX + 4;
   const bool h2 = g_h2 && g_h2_blocks && a.gmax_in && a.umax;      // two-term fp16 variants (operand bounds known)
+  const int g2_terms = h2 ? 2 : 3;
+  a.kx16 = (!kx_f32 && C == 64 && a.zg && a.K2in <= 8) ? 1 : 0;
+  if (a.kx16 && bbwd_g2_lds(a, g2_terms) > 160 * 1024) a.kx16 = 0;
   static const int v1 = getenv("FNO_BBWD_V1") ? 1 : 0;        // A/B switch: the first-generation split-precision kernel
   if (a.drop_seed) {      // dropout of the spectral branch (one-layer stacks with a tail, fno_model_*_tail)
     if (p->loose || a.lw || a.xin || !g_gemm_x3 || p->NPX != 128 || bbwd_t_lds(C, a) > 160 * 1024)
@@ -1234,9 +1241,9 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
   if constexpr (C == 64) {
     if (g_gemm_x3 && FNO_BBWD_X3 && !v1 && !no_g2 && p->NPX == 128 && (a.W == 32 || a.W == 64 || a.W == 128) &&
-        (!a.x1g || a.NJ <= 2) && a.ntiles >= 2 && bbwd_g2_lds(a) <= 160 * 1024) {
+        (!a.x1g || a.NJ <= 2) && a.ntiles >= 2 && bbwd_g2_lds(a, g2_terms) <= 160 * 1024) {
       const int g2 = grid;      // the host sums `grid` partial slabs per output: groups without a tile write zeros
-      const size_t lds2 = bbwd_g2_lds(a);
+      const size_t lds2 = bbwd_g2_lds(a, g2_terms);
       const bool two = a.x1g && a.W == 128 && a.NJ == 2;
       if (a.lw && !a.x1g && !a.gadd) {
         if (published) *published = a.gmax_out != nullptr;

@@ -52,6 +52,8 @@ struct BlkBwdArgs {
   const float* gmax_in;
   const float* umax;
   float* gmax_out;
+  int kx16;           // k_block_bwd_g2: the spectral K-extension as ONE 16-deep bf16x3 block on the matrix pipe (<= 8 kept last-dim
+                      // modes; table / spectral-row images in LDS) instead of 2-deep fp32 MFMAs on the VALU lanes
 };
 
 template <int C, int NPX>

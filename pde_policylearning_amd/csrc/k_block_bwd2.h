@@ -443,17 +443,37 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   unsigned char* aimg = gimg + IMG;
   float* r3 = reinterpret_cast<float*>(base + 4 * IMG) + grp * C * PITCH;
   float* after = reinterpret_cast<float*>(base + 4 * IMG) + 2 * C * PITCH;
-  float* zs = after + (a.zg ? grp * R2 * zrow_f : 0);
-  after += a.zg ? 2 * R2 * zrow_f : 0;
+  // spectral K-extension operands: fp32 rows + table (2-deep fp32 MFMAs), or - kx - bf16x3 images with k = 2 s + (re, im)
+  // padded to ONE 16-deep block: zimg [3][row][channel][16], timg [3][pixel of the row][16] (k_block_fwd2.h has the same pair)
+  const bool kx = a.kx16 != 0 && a.zg != nullptr;
+  const int ZT = R2 * C * 32, TT = a.W * 32;     // bytes per term plane of the two images
+  float* zs = after + (a.zg && !kx ? grp * R2 * zrow_f : 0);
+  after += a.zg && !kx ? 2 * R2 * zrow_f : 0;
+  unsigned char* zimg = reinterpret_cast<unsigned char*>(after) + (kx ? grp * 3 * ZT : 0);
+  after += kx ? 2 * 3 * ZT / 4 : 0;
   float* xls = after + (a.xin ? grp * 2 * 8 * XPITCH : 0);
   after += a.xin ? 2 * 2 * 8 * XPITCH : 0;
   float* tinv_s = after;
-  after += a.zg ? 2 * a.K2in * a.W : 0;
+  after += a.zg && !kx ? 2 * a.K2in * a.W : 0;
+  unsigned char* timg = reinterpret_cast<unsigned char*>(after);
+  after += kx ? 3 * TT / 4 : 0;
   float* tfwd_s = after;
   after += a.x1g ? 16 * a.NJ * (a.W + 4) : 0;
   unsigned* bar = reinterpret_cast<unsigned*>(after) + grp;
 
-  if (a.zg)
+  if (kx) {
+    unsigned* zi = reinterpret_cast<unsigned*>(zimg - grp * 3 * ZT);      // both groups' images: the k pads stay zero
+    for (int i = tid; i < 2 * 3 * ZT / 4; i += 512) zi[i] = 0u;
+    for (int i = tid; i < 3 * TT / 4; i += 512) reinterpret_cast<unsigned*>(timg)[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < 2 * a.K2in * a.W; i += 512) {
+      const int k = i / a.W, w = i - k * a.W;
+      unsigned short h, m, l;
+      split3(a.tinv[i], h, m, l);
+      unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * 16 + k;
+      d[0] = h; d[TT / 2] = m; d[TT] = l;
+    }
+  } else if (a.zg)
     for (int i = tid; i < 2 * a.K2in * a.W; i += 512) tinv_s[i] = a.tinv[i];
   if (a.x1g)
     for (int i = tid; i < 16 * a.NJ * a.W; i += 512) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
@@ -580,9 +600,29 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
         }
       }
       if (h == 0) {
-        if (gtid < zc4) st4(zs + 4 * gtid, zv);
-        for (int i = gtid + 256; i < zc4; i += 256)
-          st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + pxt / a.W) * zrow_f + 4 * i));
+        if (kx) {
+          // float4 piece i of the tile's spectral rows = (re, im) of channels c0, c0 + 1 of one (row, mode s): two bf16 pairs
+          // per term at k = 2 s, 2 s + 1 of those channels
+          auto put_z = [&](int i, const float4& v) {
+            const int e = 2 * i, c0 = e % C, rs = e / C, sm = rs % a.K2in, row = rs / a.K2in;
+            unsigned char* d = zimg + ((row * C + c0) * 16 + 2 * sm) * 2;
+            unsigned short hh[4], mm[4], ll[4];
+            split3(v.x, hh[0], mm[0], ll[0]); split3(v.y, hh[1], mm[1], ll[1]);
+            split3(v.z, hh[2], mm[2], ll[2]); split3(v.w, hh[3], mm[3], ll[3]);
+            *reinterpret_cast<unsigned*>(d) = hh[0] | ((unsigned)hh[1] << 16);
+            *reinterpret_cast<unsigned*>(d + 32) = hh[2] | ((unsigned)hh[3] << 16);
+            *reinterpret_cast<unsigned*>(d + ZT) = mm[0] | ((unsigned)mm[1] << 16);
+            *reinterpret_cast<unsigned*>(d + ZT + 32) = mm[2] | ((unsigned)mm[3] << 16);
+            *reinterpret_cast<unsigned*>(d + 2 * ZT) = ll[0] | ((unsigned)ll[1] << 16);
+            *reinterpret_cast<unsigned*>(d + 2 * ZT + 32) = ll[2] | ((unsigned)ll[3] << 16);
+          };
+          if (gtid < zc4) put_z(gtid, zv);
+          for (int i = gtid + 256; i < zc4; i += 256) put_z(i, ld4(a.zg + ((size_t)b * a.P + pxt / a.W) * zrow_f + 4 * i));
+        } else {
+          if (gtid < zc4) st4(zs + 4 * gtid, zv);
+          for (int i = gtid + 256; i < zc4; i += 256)
+            st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + pxt / a.W) * zrow_f + 4 * i));
+        }
       }
       if constexpr (LIFT) {      // lifting input rows of this half: [k][64 px]
         for (int idx = gtid; idx < a.CL * (GPX / 4); idx += 256) {
@@ -637,7 +677,23 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = NT3 == 2 ? (hi[r] + lo[r]) * inv_gw : hi[r] + lo[r];
       }
-      if (a.zg) {      // spectral K-extension: all table / spectrum values of a group of 4 modes are in flight together
+      if (kx) {        // spectral K-extension as one 16-deep bf16x3 block: D^T[px][c] += T^T[px][k] Z[c][k] (six products)
+        const int pl = 64 * h + n0;                    // position of this wave's 32 pixels in the 128-pixel tile
+        const unsigned char* ta = timg + ((pl % a.W + l31) * 16 + 8 * half) * 2;
+        const unsigned char* zb = zimg + (((pl / a.W) * C + crow) * 16 + 8 * half) * 2;
+        bf16x8 fa3[3], fb3[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          fa3[t] = *reinterpret_cast<const bf16x8*>(ta + t * TT);
+          fb3[t] = *reinterpret_cast<const bf16x8*>(zb + t * ZT);
+        }
+        f32x16 eh, el;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { eh[r] = 0.f; el[r] = 0.f; }
+        mfma_split_s<3>(fa3, fb3, eh, el);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += eh[r] + el[r];
+      } else if (a.zg) {      // spectral K-extension: all table / spectrum values of a group of 4 modes are in flight together
         const int pl = 64 * h + n0;                    // position of this wave's 32 pixels in the 128-pixel tile
         const float* zr = zs + ((pl / a.W) * a.K2in * C + crow) * 2 + half;
         const float* tv = tinv_s + half * a.W + pl % a.W + l31;
