@@ -8,6 +8,8 @@ if len(sys.argv) > 1:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(64, 3, 128, 128, generator=g).to(dev)
     B = 8
+    if os.environ.get("H2DBG_PERM"):      # the same eight fields in another order: do wrong patches follow the data or the position?
+        x = x[[2, 3, 0, 1, 6, 7, 4, 5] + list(range(8, 64))]
     y = m(x[:B])
     sf = y.grad_fn.saved_tensors[1].view(torch.float32)
     n_act = B * 64 * 128 * 128
