@@ -133,3 +133,31 @@ def test_fno3d_config4_fullsize_vs_oracle(dev):
     y = model(x.to(dev))
     O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
     _compare(model, y, params, y64, g64, g32)
+
+
+@pytest.mark.parametrize("which", ["fno2d", "fno3d"])
+def test_training_gradients_are_bitwise_repeatable(dev, which):
+    """The engine has no float atomics and fixed reduction orders: the same step gives the same bits.  Thirty repetitions of
+    forward + backward at a size where every kernel runs its production variant (two workgroups per CU, two-term fp16 GEMMs,
+    persistent grids with tails) - a sporadic hazard (one was found in an off-by-default kernel this way)
+    shows up as a repetition that differs."""
+    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
+    torch.manual_seed(0)
+    if which == "fno2d":
+        model, shape = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev), (24, 128, 128)
+    else:
+        model, shape = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1).to(dev), (4, 64, 64, 64)
+    x = torch.from_numpy(fill_named("rep.x", (shape[0], 3) + shape[1:], 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("rep.t", (shape[0], 1) + shape[1:], 1.0)).to(dev)
+    first = None
+    for rep in range(30):
+        model.zero_grad(set_to_none=True)
+        y = model(x)
+        O.lp_loss_rel_sum(y, tgt).backward()
+        got = [y.detach().clone()] + [(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).detach().clone()
+                                       for p in model.parameters()]
+        if first is None:
+            first = got
+            continue
+        for i, (a, b) in enumerate(zip(got, first)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (rep, i)
