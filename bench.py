@@ -39,7 +39,7 @@ CONFIGS = {
     # the YAML's active model; launch-bound since its optimizer skips the dead weight slices (round 3): hipGraph replay
     "pino_fullfield_32x32_w64_m12_b32": dict(kind="pino_ff", batch=32, size=(32, 32), graph=True),
     # the same model with the loop's loss: decode + LpLoss on the planes + pde_loss_weight 1.0 * channel-flow term (matlab_rno.yaml:56,62)
-    "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32)),
+    "pino_fullfield_pde_32x130x32_w64_m12_b32": dict(kind="pino_ff_pde", batch=32, size=(32, 32), graph=True),      # launch-bound as well
     "pinobserver2d_128x128x65_w64_m8_b2": dict(kind="pino2d", batch=2, size=(128, 128, 65)),  # configs/pino-observer-finetune-1s.yaml
     # the fine-tuning step of that YAML as train_pino.py runs it: batch 4, loss = 5 * IC + 1 * PDE residual (xy_loss 0)
     "pino_finetune_128x128x65_w64_m8_b4": dict(kind="pino2d_train", batch=4, size=(128, 128, 65)),

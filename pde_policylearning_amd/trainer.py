@@ -85,6 +85,7 @@ class FullFieldObjective(object):
         if self.weight > 0 and env is None:
             raise ValueError("pde_loss_weight > 0 needs the channel grid (ChannelFlowRHS)")
         self.last_terms = None
+        self._plane_idx = None
 
     def __call__(self, pred_raw, batch):
         v_field, U, V, W = batch
@@ -95,7 +96,12 @@ class FullFieldObjective(object):
         self.last_terms = (loss.detach(), None)
         if self.weight > 0:
             full = V.clone()
-            full[:, :, :, self.plane_indexs, :] = pred.permute(0, 1, 3, 2, 4).to(full.dtype)      # (B, T, X, P, Z)
+            # (the plane indices as a DEVICE tensor built once: a Python list would be turned into a host tensor and copied
+            # over on every call - not allowed while a hipGraph is being captured)
+            idx = self._plane_idx
+            if idx is None or idx.device != full.device:
+                idx = self._plane_idx = torch.tensor([i % full.shape[3] for i in self.plane_indexs], device=full.device)
+            full.index_copy_(3, idx, pred.permute(0, 1, 3, 2, 4).to(full.dtype))                  # (B, T, X, P, Z)
             pde = self.env.pde_loss(U.flatten(0, 1), V.flatten(0, 1), full.flatten(0, 1), W.flatten(0, 1))
             self.last_terms = (self.last_terms[0], pde.detach())
             loss = loss + self.weight * pde

@@ -23,6 +23,7 @@ for c in rno2d_128x128_w64_m12_b32 rno2d_32x32_w34_m12_b32 pino_fullfield_32x32_
 done
 $T python3 bench.py --config rno2d_128x128_w64_m12_b32 --steps 10 --warmup 3 --graph --no-cpu-baseline > $out/${tag}_bench_rno2d_128x128_w64_m12_b32_graph.json 2>> $out/${tag}_bench.err
 $T python3 bench.py --config pino_fullfield_32x32_w64_m12_b32 --steps 10 --warmup 3 --eager --no-cpu-baseline > $out/${tag}_bench_pino_fullfield_32x32_w64_m12_b32_eager.json 2>> $out/${tag}_bench.err
+$T python3 bench.py --config pino_fullfield_pde_32x130x32_w64_m12_b32 --steps 10 --warmup 3 --eager --no-cpu-baseline > $out/${tag}_bench_pino_fullfield_pde_32x130x32_w64_m12_b32_eager.json 2>> $out/${tag}_bench.err
 fi
 [ "$quick" = "bench" ] && exit 0
 prof() {   # prof <name> <bench args...>: kernel-trace stats of one workload
