@@ -53,6 +53,9 @@ def build_parser():
     ap.add_argument("--weight-decay", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=0)                  # run_pde_observers.py:25
     ap.add_argument("--no-shuffle", action="store_true", help="keep the (time-ordered) sample order; the reference shuffles")
+    ap.add_argument("--graph", action="store_true", help="PINObserverFullField on one GPU: capture the training step of a full "
+                    "batch into a hipGraph and replay it (the step is launch-bound: 1.9 vs 2.4 ms at the YAML's sizes); a "
+                    "smaller last batch runs eagerly")
     ap.add_argument("--save-path", default=None, help="whole-module checkpoint written whenever the test rel-L2 improves "
                     "(run_pde_observers.py:307-315: torch.save(observer_model, './outputs/<path>_<exp>.pth'))")
     return ap
@@ -196,7 +199,8 @@ def run_full_field(args, idx, dev, rank, world, log):
                                            torch.full((1, 1), 180.0, device=dev)))
     # the dead last-dim slices of the spectral weights (11/12 of them at T = 1) are replayed, not stepped: the loop reads the
     # weights through model.state_dict() / optimizer.state_dict() only, which bring them up to date first
-    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay, skip_dead_slices=True)
+    use_graph = bool(getattr(args, "graph", False)) and world == 1
+    opt = FusedAdam(bucket, lr=args.learning_rate, weight_decay=args.weight_decay, skip_dead_slices=True, capturable=use_graph)
     env = None
     if args.pde_loss_weight > 0:
         Nx, Ny, Nz = train_ds[0][3].shape[1:]
@@ -209,6 +213,7 @@ def run_full_field(args, idx, dev, rank, world, log):
     objective = FullFieldObjective(decoder, args.plane_indexs, env, args.pde_loss_weight)
     forward = lambda plane, re: model(plane.permute(0, 2, 3, 1).unsqueeze(-1), re)     # 'btxy -> bxyt', + channel  (:204)
     history, best = [], float("inf")
+    graphed, gshape = None, None
     for ep in range(args.epochs):
         model.train()
         t0 = time.perf_counter()
@@ -217,7 +222,14 @@ def run_full_field(args, idx, dev, rank, world, log):
             if world > 1:
                 batch = [shard_batch(t, rank, world) for t in batch]
             v_plane, v_field, U, V, W, re, _dpdx = [t.float() for t in batch]
-            tot += train_step(forward, bucket, opt, (v_plane, re), (v_field, U, V, W), objective)
+            if use_graph and graphed is None and v_plane.shape[0] == args.batch_size:
+                from .trainer import GraphedTrainStep      # the whole step (zero_grad .. Adam) captured once on a full batch
+                graphed = GraphedTrainStep(forward, bucket, opt, (v_plane, re), (v_field, U, V, W), objective)
+                gshape = tuple(v_plane.shape)
+            if graphed is not None and tuple(v_plane.shape) == gshape:
+                tot += graphed((v_plane, re), (v_field, U, V, W))
+            else:
+                tot += train_step(forward, bucket, opt, (v_plane, re), (v_field, U, V, W), objective)
             cnt += v_plane.shape[0]
         if world > 1:
             dist.all_reduce(tot)

@@ -1726,6 +1726,13 @@ def test_train_observer_full_field_branch(dev, tmp_path):
     hist = train_observer.run(args, log=lambda *_: None)
     assert all(np.isfinite(h["train_l2"]) and np.isfinite(h["test_l2"]) for h in hist)
     assert hist[-1]["train_l2"] < hist[0]["train_l2"]
+    # the same run with the step of a full batch replayed as a hipGraph (--graph): the same trajectory
+    hist_g = train_observer.run(train_observer.build_parser().parse_args(
+        ["--data-folder", str(tmp_path), "--ntrain", "8", "--ntest", "4", "--dataset", "FullFieldNSDataset", "--model",
+         "PINObserverFullField", "--modes", "4", "--width", "16", "--plane-indexs", "-4", "-3", "2", "--pde-loss-weight", "0.05",
+         "--batch-size", "4", "--epochs", "6", "--learning-rate", "2e-3", "--graph"]), log=lambda *_: None)
+    for a, b in zip(hist, hist_g):
+        assert abs(a["train_l2"] - b["train_l2"]) < 1e-4 * abs(a["train_l2"]) and abs(a["test_l2"] - b["test_l2"]) < 1e-4 * abs(a["test_l2"])
 
 
 @pytest.mark.gpu
