@@ -768,8 +768,18 @@ class FusedAdam(object):
                         self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
             return
         hp = self._hyper()
-        if not self._hp_log or self._hp_log[-1][1:] != hp:
+        if not self._hp_log:
             self._hp_log.append((self.step_count,) + hp)
+        elif self._hp_log[-1][1:] != hp:
+            if self.capturable:
+                # the host's step count is only a mirror there (graph replays do not advance it): close the stretch that
+                # ran on the old hyperparameters at the DEVICE's count, then start a new one
+                self.step_count -= 1
+                self.sync_dead_slices()
+                self.step_count += 1
+                self._hp_log = [(self._dead_step + 1,) + hp]
+            else:
+                self._hp_log.append((self.step_count,) + hp)
         F.adam_step_runs(self._runs, self.flat_param, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                          self.betas, self.eps, self.weight_decay, step_counter=self.step_dev, scratch=self.scratch)
 
