@@ -24,6 +24,25 @@ if ROOT not in sys.path:
 
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_MFMA_F32_TFLOPS = 157.3  # dense fp32 MFMA (v_mfma_f32_32x32x2_f32), same guide
+PEAK_MFMA_16BIT_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA, same guide
+# A kernel's fp32-equivalent algorithmic FLOP/s are priced against the peak of the pipe its GEMMs RUN on
+# (fno_profile_get_terms): fp32 MFMA; two fp16 terms per operand = 3 products per k block on the 16-bit pipe; three bf16 terms
+# = 6 products.
+PIPE = {1: ("fp32 MFMA", PEAK_MFMA_F32_TFLOPS), 2: ("fp16 MFMA, 3 products per k block", PEAK_MFMA_16BIT_TFLOPS / 3.0),
+        3: ("bf16 MFMA, 6 products per k block", PEAK_MFMA_16BIT_TFLOPS / 6.0)}
+
+
+def algorithmic_bytes_per_field(cfg):
+    """bytes = 4 HW [(Cin + Cout + (2L + 2) C) + ((Cout + 2C) + 3LC + n_gelu C + (C + Cin))] for the fused FNO
+    models (fwd + bwd, every activation moved the minimum number of times); None for the observer workloads."""
+    if cfg["kind"] not in ("2d", "3d"):
+        return None
+    hw = 1
+    for n in cfg["size"]:
+        hw *= n
+    C, L, cin, cout = cfg["width"], 4, 3, 1
+    n_gelu = sum(1 for l in range(L) if l < L - l)
+    return 4.0 * hw * ((cin + cout + (2 * L + 2) * C) + ((cout + 2 * C) + 3 * L * C + n_gelu * C + (C + cin)))
 
 CONFIGS = {
     # name: (ctor args, input shape per GPU)
@@ -418,6 +437,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
+        if getattr(opt, "_runs", None) is not None:
+            opt.sync_dead_slices()       # the deferred replay of the skipped (dead) weight slices belongs to these steps' work
         sync()
         blocks.append(time.perf_counter() - t0)
     if dist_on:
@@ -458,28 +479,35 @@ def main():
             eager_step()           # per-kernel events need individual launches
         torch.cuda.synchronize()
         L.fno_profile_enable(0)
-        prof = _lib.profile_summary()
+        prof = _lib.profile_summary(with_terms=True)
         L.fno_profile_reset()
         km = kernel_model(cfg)
-        tot = sum(ms for _, ms, _ in prof)
-        for name, ms, n in sorted(prof, key=lambda r: -r[1]):
+        tot = sum(ms for _, ms, _, _ in prof)
+        mode_terms = 3 if L.fno_get_gemm_mode() == 1 else 1
+        for name, ms, n, terms in sorted(prof, key=lambda r: -r[1]):
             avg = ms / n
             rec = dict(name=name, launches_per_step=n / args.profile_steps, avg_ms=round(avg, 4),
                        share=round(ms / tot, 3))
             if name in km:
+                pipe_name, pipe_peak = PIPE[terms if terms in PIPE else mode_terms]
                 rec["GBps"] = round(km[name]["bytes"] / avg / 1e6, 1)
                 rec["TFLOPs"] = round(km[name]["flops"] / avg / 1e9, 2)
+                rec["hbm_frac"] = round(rec["GBps"] / PEAK_HBM_GBS, 4)
+                rec["pipe"] = pipe_name
+                rec["pipe_peak_TFLOPs"] = round(pipe_peak, 1)
+                rec["pipe_frac"] = round(rec["TFLOPs"] / pipe_peak, 4)
             kernels.append(rec)
         dom = next((k for k in kernels if k["name"] in km), None)
         if dom is not None:
-            f_h = dom["GBps"] / PEAK_HBM_GBS
-            f_m = dom["TFLOPs"] / PEAK_MFMA_F32_TFLOPS
+            f_h, f_m = dom["hbm_frac"], dom["pipe_frac"]
             if f_m >= f_h:
-                roofline = dict(kernel=dom["name"], bound="mfma", achieved=dom["TFLOPs"],
-                                peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s", frac=round(f_m, 4), traffic=None)
+                roofline = dict(kernel=dom["name"], bound="mfma", achieved=dom["TFLOPs"], peak=dom["pipe_peak_TFLOPs"],
+                                unit="TFLOP/s", frac=round(f_m, 4), traffic=None, pipe=dom["pipe"], hbm_frac=f_h)
             else:
                 roofline = dict(kernel=dom["name"], bound="hbm", achieved=dom["GBps"], peak=PEAK_HBM_GBS,
-                                unit="GB/s", frac=round(f_h, 4), traffic=None)
+                                unit="GB/s", frac=round(f_h, 4), traffic=None, pipe=dom["pipe"], pipe_frac=f_m)
+            roofline["note"] = ("frac = the larger of (algorithmic bytes / launch time / 8 TB/s) and (fp32-equivalent algorithmic "
+                                "FLOP/s / the dense peak of the matrix pipe the kernel's GEMMs run on divided by its products per k block)")
             # HBM bytes per launch from the committed PMC passes (profiles/, tools/pmc_traffic.py): quoted only when the file
             # was collected on THESE kernel sources (source_hash) and this workload
             try:
@@ -571,9 +599,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "gemm_mode": ("split precision, fp32 in / fp32 accumulate / fp32 out: projection and block-backward GEMMs on two fp16 terms "
-                          "per operand scaled by published magnitude bounds (3 products), block-forward GEMMs and small problems "
-                          "on three bf16 terms (6 products); parity held at 1e-5 against the float64 oracle")
+            "gemm_mode": ("split precision, fp32 in / fp32 accumulate / fp32 out: channel GEMMs on two fp16 terms per operand "
+                          "scaled by published magnitude bounds (3 products per k block), small problems and the spectral "
+                          "K-extension on three bf16 terms (6 products); parity held at 1e-5 against the float64 oracle; "
+                          "per kernel: kernels[].pipe")
                          if _lib.lib().fno_get_gemm_mode() == 1 else "f32 (v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
             "repeats": len(blocks),
@@ -594,6 +623,9 @@ def main():
                                ("+allreduce(sum" + (", overlapped with bwd)" if overlap else ")") if dist_on else "") + "+Adam",
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,
+            "step_hbm_frac": (round(algorithmic_bytes_per_field(cfg) * B / (dt / args.steps) / (PEAK_HBM_GBS * 1e9), 4)
+                              if algorithmic_bytes_per_field(cfg) else None),
+            "step_hbm_note": "whole step: SURVEY 8(d) algorithmic bytes per field x batch / ms_per_step / 8 TB/s (the binding roof of the step)",
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,
         }

@@ -406,6 +406,9 @@ int fno_chanflow_pde_loss_backward(const FnoChanflowGrid* grid, int batch, const
 void fno_profile_enable(int on);
 int fno_profile_count(void);
 int fno_profile_get(int idx, const char** name, float* total_ms, int* launches);
+/* which matrix pipe record idx's channel GEMMs ran on: 0 not stated, 1 fp32 MFMA, 2 two fp16 terms per operand (3 products per
+ * k block), 3 three bf16 terms (6 products) - what a roofline has to price the kernel against */
+int fno_profile_get_terms(int idx);
 void fno_profile_reset(void);
 
 #ifdef __cplusplus

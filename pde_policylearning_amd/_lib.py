@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfnoengine.so")
+LIB_PATH = os.environ.get("FNO_LIB_PATH") or os.path.join(_HERE, "libfnoengine.so")      # (FNO_LIB_PATH: experiment builds of tools/)
 
 FNO_MAX_LAYERS = 16
 NORM_CODES = {"backward": 0, None: 0, "forward": 1, "ortho": 2}
@@ -160,6 +160,8 @@ def lib():
     L.fno_profile_reset.restype = None
     L.fno_profile_count.restype = ci
     L.fno_profile_get.argtypes = [ci, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(ci)]
+    L.fno_profile_get_terms.argtypes = [ci]
+    L.fno_profile_get_terms.restype = ci
     _lib = L
     return L
 
@@ -191,16 +193,18 @@ EXPORTED_SYMBOLS = [
     "fno_pino_loss_workspace_bytes", "fno_pino_loss_forward", "fno_pino_loss_backward",
     "fno_chanflow_pack_metrics", "fno_chanflow_rhs", "fno_chanflow_pde_loss_workspace_bytes",
     "fno_chanflow_pde_loss_forward", "fno_chanflow_pde_loss_backward",
-    "fno_profile_enable", "fno_profile_count", "fno_profile_get", "fno_profile_reset",
+    "fno_profile_enable", "fno_profile_count", "fno_profile_get", "fno_profile_get_terms", "fno_profile_reset",
 ]
 
 
-def profile_summary():
-    """[(kernel name, total ms, launches)] recorded since the last reset (profiling on)."""
+def profile_summary(with_terms=False):
+    """[(kernel name, total ms, launches)] recorded since the last reset (profiling on); with_terms: a fourth entry, the
+    matrix pipe of the kernel's channel GEMMs (fno_profile_get_terms: 0 not stated, 1 fp32, 2 two fp16 terms, 3 three bf16)."""
     L = lib()
     out = []
     for i in range(L.fno_profile_count()):
         name, ms, n = C.c_char_p(), C.c_float(), C.c_int()
         L.fno_profile_get(i, C.byref(name), C.byref(ms), C.byref(n))
-        out.append((name.value.decode(), float(ms.value), int(n.value)))
+        rec = (name.value.decode(), float(ms.value), int(n.value))
+        out.append(rec + (int(L.fno_profile_get_terms(i)),) if with_terms else rec)
     return out

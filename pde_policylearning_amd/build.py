@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fno_abi.hip")
-OUT = os.path.join(HERE, "libfnoengine.so")
+OUT = os.environ.get("FNO_LIB_PATH") or os.path.join(HERE, "libfnoengine.so")      # (FNO_LIB_PATH: experiment builds of tools/)
 DEPS = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [
     os.path.join(os.path.dirname(HERE), "include", "fnoengine.h")]
 

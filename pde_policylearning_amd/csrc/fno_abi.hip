@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,10 +56,10 @@ static int g_gemm_x3 = []() { const char* e = getenv("FNO_GEMM_F32"); return (e 
 // the variant and its operands' magnitude bounds are known: FNO_NO_H2=1 keeps bf16x3 everywhere (A/B arm)
 static int g_h2 = getenv("FNO_NO_H2") ? 0 : 1;
 static int g_h2_blocks = getenv("FNO_NO_H2_BLOCKS") ? 0 : 1;      // ... in the block kernels (the projection keeps it)
-// ... in the block FORWARD kernel: off by default.  With two workgroups per CU the variant now and then produces one wrong
-// 64-channel x 16-pixel patch per few thousand tiles inside the model (never in tools/bf2_test, never with one workgroup per
-// CU); unresolved, so it stays an experiment (FNO_H2_FWD_BLOCKS=1)
-static int g_h2_fwd_blocks = getenv("FNO_H2_FWD_BLOCKS") ? 1 : 0;
+// ... in the block FORWARD kernel (on since round 4: the sporadic wrong patches that kept it off in round 3 were the packed-fp32
+// op_sel hazard of fno_dev.h / tools/pk_opsel_hazard.hip, which natural_pair() now keeps out of the code); FNO_NO_H2_FWD_BLOCKS=1
+// restores the three-term bf16 forward (A/B arm)
+static int g_h2_fwd_blocks = getenv("FNO_NO_H2_FWD_BLOCKS") ? 0 : 1;
 extern "C" void fno_set_gemm_mode(int x3) { g_gemm_x3 = x3 ? 1 : 0; }
 extern "C" int fno_get_gemm_mode(void) { return g_gemm_x3; }
 extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
@@ -72,12 +73,23 @@ extern "C" int fno_get_mode_gemm(void) { return g_mode_mfma; }
 // --------------------------------------------------------------------------
 // optional per-kernel timing (HIP events on the launch stream)
 // --------------------------------------------------------------------------
-struct ProfRec { std::string name; hipEvent_t a, b; };
+struct ProfRec { std::string name; hipEvent_t a, b; int terms; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
-struct ProfAgg { std::string name; float ms; int n; };
+struct ProfAgg { std::string name; float ms; int n; int terms; };
+// which matrix pipe the NEXT launch's channel GEMMs use (read and cleared by launch(); the profile reports it so that bench.py
+// prices a kernel against the peak of the pipe it ran on): 0 not stated, 1 fp32 MFMA, 2 two fp16 terms (3 products per k
+// block), 3 three bf16 terms (6 products)
+static thread_local int g_terms_next = 0;
+#define GT(n) (g_terms_next = (n))
 static std::vector<ProfAgg> g_agg;
 
+#ifdef FNO_CLOCK
+extern "C" int fno_debug_clock_dump(unsigned long long* host, size_t n) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clk), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FNO_TRACE
 extern "C" int fno_debug_trace_dump(unsigned long long* host, size_t n) {
   hipDeviceSynchronize();
@@ -110,13 +122,17 @@ static void prof_aggregate() {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
     auto it = idx.find(r.name);
-    if (it == idx.end()) { idx[r.name] = g_agg.size(); g_agg.push_back({r.name, ms, 1}); }
-    else { g_agg[it->second].ms += ms; g_agg[it->second].n += 1; }
+    if (it == idx.end()) { idx[r.name] = g_agg.size(); g_agg.push_back({r.name, ms, 1, r.terms}); }
+    else { g_agg[it->second].ms += ms; g_agg[it->second].n += 1; if (r.terms > g_agg[it->second].terms) g_agg[it->second].terms = r.terms; }
   }
   g_recs.clear();
   g_evused = 0;
 }
 extern "C" int fno_profile_count(void) { prof_aggregate(); return (int)g_agg.size(); }
+extern "C" int fno_profile_get_terms(int i) {
+  prof_aggregate();
+  return (i < 0 || i >= (int)g_agg.size()) ? FNO_EINVAL : g_agg[i].terms;
+}
 extern "C" int fno_profile_get(int i, const char** name, float* total_ms, int* launches) {
   prof_aggregate();
   if (i < 0 || i >= (int)g_agg.size()) return FNO_EINVAL;
@@ -154,8 +170,11 @@ static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 bloc
     }
   }
   ProfRec rec;
+  const int terms = g_terms_next;
+  g_terms_next = 0;
   if (g_prof) {
     rec.name = name;
+    rec.terms = terms;
     rec.a = prof_event();
     rec.b = prof_event();
     hipEventRecord(rec.a, st);
@@ -904,11 +923,33 @@ struct FnoModelPlan {
   Tables t;
   int NPX;      // pixels per workgroup tile (128 or 256)
   bool loose;   // rows do not tile the pixel tile (last dim 96, 160, 73, ...): spectral rows gathered per tile, separate row-DFT passes
-  mutable bool u0_skipped = false;   // the last forward pass left u_0 (the lifting output) unwritten: block 0 recomputes it
-  mutable bool gchain_valid = false; // the last backward part left max |g| of its output gradient (amax[32 + l_lo])
-  mutable bool h2_u0 = false;        // ... and the bound of |u_0| (fused lifting)
-  mutable bool h2_fwd = false;       // the last forward pass published max |u_L| behind the saved tensors (two-term fp16 projection)
   int ncu;      // compute units of the device the plan was made on
+  // What a forward pass left in ITS `saved` buffer - the backward pass that reads the buffer must take the matching paths.
+  // Plans are cached and shared by every call with the same configuration (other batch sizes, other models, other threads),
+  // so this lives per `saved` buffer, not per plan: forward records it under the buffer's address, backward looks it up (a
+  // buffer the plan has never seen reads as "nothing published": the three-term paths, which need no bounds).
+  struct CallState {
+    bool u0_skipped = false;     // u_0 (the lifting output) was not written: block 0 recomputes it
+    bool h2_fwd = false;         // max |u_L| was published behind the saved tensors (two-term fp16 projection / block backward)
+    bool h2_u0 = false;          // ... and the bound of |u_0| (fused lifting)
+    bool gchain_valid = false;   // the last backward part left max |g| of its output gradient (amax[32 + l_lo])
+  };
+  mutable std::mutex call_mu;
+  mutable std::vector<std::pair<const void*, CallState>> calls;      // most recent last; capped (kMaxCalls)
+  static const size_t kMaxCalls = 64;
+  void put_call(const void* saved, const CallState& cs) const {
+    std::lock_guard<std::mutex> lk(call_mu);
+    for (size_t i = 0; i < calls.size(); ++i)
+      if (calls[i].first == saved) { calls.erase(calls.begin() + i); break; }
+    if (calls.size() >= kMaxCalls) calls.erase(calls.begin());
+    calls.emplace_back(saved, cs);
+  }
+  CallState get_call(const void* saved) const {
+    std::lock_guard<std::mutex> lk(call_mu);
+    for (size_t i = calls.size(); i-- > 0;)
+      if (calls[i].first == saved) return calls[i].second;
+    return CallState();
+  }
 };
 
 static const int kHID = 256;
@@ -1089,8 +1130,8 @@ template <int CIN, int COUT>
 static int launch_pw(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a, const char* name) {
   const size_t lds = pw_fwd_lds_bytes(CIN, COUT, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   if (p->NPX == 128)
-    return launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3((COUT / 32) * 4 * 64), lds, st, a);
-  return launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3((COUT / 32) * 8 * 64), lds, st, a);
+    return GT(1), launch(name, k_pw_fwd<CIN, COUT, 128>, dim3(grid), dim3((COUT / 32) * 4 * 64), lds, st, a);
+  return GT(1), launch(name, k_pw_fwd<CIN, COUT, 256>, dim3(grid), dim3((COUT / 32) * 8 * 64), lds, st, a);
 }
 static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   const int C = p->d.C;
@@ -1137,9 +1178,9 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
     const bool h2k = g_h2 && g_h2_blocks && g_h2_fwd_blocks && a.xmax && kz > 0 && !a.add && !a.relu_out;      // two-term fp16 variants: the model path's combinations
 #define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
     if (h2k && !(RELU_) && !(ADD_)) \
-      return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
-    if (kz == 0) return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
-    return launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
+      return GT(2), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
+    if (kz == 0) return GT(3), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
+    return GT(3), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
     if (a.lw && !a.relu_out && !a.add) {
       if (epi == 2) BF2(true, false, false, 2, false);
       if (epi == 1) BF2(true, false, false, 1, false);
@@ -1158,20 +1199,20 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
                      (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
   if (p->loose && !a.relu_out)
-    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   if (a.lw && !a.relu_out)
-    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   if (a.relu_out) {
     if (p->NPX != 128 || p->loose || a.lw) return fail(FNO_EUNSUPPORTED, "ReLU output: 128-pixel tiles of whole rows, no fused lifting");
-    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, false, true>, dim3(grid),
+    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, false, true>, dim3(grid),
                   dim3((C / 32) * (4 / FNO_NTW_PWX) * 64), lds, st, a);
   }
   if (p->NPX == 128)
-    return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
-  return launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
+  return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
 }
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   if (p->loose && !g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
@@ -1214,7 +1255,7 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   if (a.drop_seed) {      // dropout of the spectral branch (one-layer stacks with a tail, fno_model_*_tail)
     if (p->loose || a.lw || a.xin || !g_gemm_x3 || p->NPX != 128 || bbwd_t_lds(C, a) > 160 * 1024)
       return fail(FNO_EUNSUPPORTED, "spectral-branch dropout: split-precision GEMM mode, 128-pixel tiles of whole rows, no lifting");
-    return launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_t_lds(C, a), st, a);
   }
   if (p->loose) {
@@ -1234,8 +1275,8 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       ldsl = base + kch * per_mode;
     }
     if (v1)
-      return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
-    return launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+      return GT(3), launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+    return GT(3), launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
   }
   // C = 64, rows of 32 / 64 / 128 pixels: two independent 4-wave groups per workgroup (k_block_bwd_g2)
   static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
@@ -1247,14 +1288,14 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       const bool two = a.x1g && a.W == 128 && a.NJ == 2;
       if (a.lw && !a.x1g && !a.gadd) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2) return launch("k_block_bwd", k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
-        return launch("k_block_bwd", k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        return GT(3), launch("k_block_bwd", k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
       // (gradient addends and two 16-output blocks per wave do not fit the register budget yet: k_block_bwd_t takes those)
       if (!a.lw && !a.xin && !a.gadd && !two) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2) return launch("k_block_bwd", k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
-        return launch("k_block_bwd", k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        return GT(3), launch("k_block_bwd", k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
     }
   }
@@ -1263,26 +1304,26 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       return fail(FNO_EUNSUPPORTED, "block 0 cannot recompute the lifting in this GEMM mode (the forward pass skipped u_0)");
     if (!v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
       if (published) *published = a.gmax_out != nullptr;
-      if (h2) return launch("k_block_bwd", k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-      return launch("k_block_bwd", k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+      if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+      return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
     }
-    return launch("k_block_bwd", k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch("k_block_bwd", k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
     if (published) *published = a.gmax_out != nullptr;
-    if (h2) return launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-    return launch("k_block_bwd", k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
-    return launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
                       (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
                       (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
   if (p->NPX == 128)
-    return launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
-  return launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);
+    return GT(1), launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
+  return GT(1), launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);
 }
 // *published (if given): the launched kernel left max |gout| at a.gmax_out (the second-generation kernels do)
 static int launch_bbwd(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a, bool* published = nullptr) {
@@ -1299,15 +1340,15 @@ static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
   if (g_gemm_x3 && g_h2 && a.xmax) {
     const size_t lds = (size_t)2 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 2 * 64 * 16 +
                        (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
-    return launch("k_proj_fwd", k_proj_fwd_h2<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+    return GT(2), launch("k_proj_fwd", k_proj_fwd_h2<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   }
   if (g_gemm_x3) {
     const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 3 * 64 * 16 +
                        (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
-    return launch("k_proj_fwd", k_proj_fwd_x3<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+    return GT(3), launch("k_proj_fwd", k_proj_fwd_x3<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   }
   const size_t lds = ((size_t)C * 132 + kHID + NCO * kHID + NCO * 128 + (size_t)kHID * (C + 1)) * 4;
-  return launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  return GT(1), launch("k_proj_fwd", k_proj_fwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
 }
 template <int C>
 static int launch_pfwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
@@ -1324,8 +1365,8 @@ static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
   const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + (w1lds ? w1b : 0) <= 160 * 1024;
   const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + (w1lds ? w1b : 0);
   if (p->NPX == 128)
-    return launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
-  return launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
+    return GT(1), launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  return GT(1), launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
 }
 static size_t pbwd_x3_lds(int C, int npx, int nco) {
   return ((size_t)3 * npx * (C + 8) + (size_t)3 * C * (npx + 8) + (size_t)3 * 64 * (npx + 8)) * 2 +
@@ -1352,12 +1393,12 @@ static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsi
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
   if (a.wa1 && a.amax && use_pbwd_t(C, a.CO, p->NPX))      // two fp16 terms: same LDS carve with two planes per image
-    return launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false, 2>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
+    return GT(2), launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false, 2>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
-    return launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
+    return GT(3), launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
   if (a.wa1 && a.CO == 1 && p->NPX == 128 && pbwd_x3_lds(C, 128, 1) <= 160 * 1024)
-    return launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
+    return GT(3), launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
   return a.CO == 1 ? launch_pbwd_cn<C, 1>(p, st, grid, a) : launch_pbwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
 }
 
@@ -1435,19 +1476,20 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
   bool lift_xmax = false;      // max |x| of the model input was published (k_lift_rowdft)
+  FnoModelPlan::CallState cs;
   PwFwdArgs a;
   if (has_lift) {
     // lifting (tfno.py:19-20) + row DFT of its output
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = prm->lift_w; a.bias = prm->lift_b;
-    p->u0_skipped = lift_fused(p);
-    a.u = p->u0_skipped ? nullptr : u; a.x1 = p->loose ? nullptr : w.x1; a.tfwd = p->t.tfwd_f;
+    cs.u0_skipped = lift_fused(p);
+    a.u = cs.u0_skipped ? nullptr : u; a.x1 = p->loose ? nullptr : w.x1; a.tfwd = p->t.tfwd_f;
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     static const int lift_dft_lin = getenv("FNO_NO_LIFT_ROWDFT") ? 0 : 1;      // A/B switch
     const size_t lds_lr = ((size_t)2 * g.Klast * (g.W + 1) + (size_t)LR_ROWS * d.Cin * (g.W + 1) + 2) * 4 + (size_t)LR_ROWS * g.Klast * (d.Cin + 1) * 8;
-    if (lift_dft_lin && p->u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
+    if (lift_dft_lin && cs.u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
       // u_0 is never stored: only its row spectra are needed, and those are linear in the <= 4 input channels
       const int nrows = B * g.P;
       LAUNCHCHK(launch("k_lift_rowdft", k_lift_rowdft, dim3((nrows + LR_ROWS - 1) / LR_ROWS), dim3(256), lds_lr, st, x,
@@ -1472,7 +1514,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     LAUNCHCHK(spectral_mid_fwd(p, st, B, w, wps + (size_t)l * s.n_wp, hats + (size_t)l * s.n_hat));
     memset(&a, 0, sizeof(a));
     a.x = (l == 0 && !has_lift) ? x : u + (size_t)l * s.n_act;
-    if (l == 0 && has_lift && p->u0_skipped) { a.x = x; a.lw = prm->lift_w; a.lb = prm->lift_b; a.CL = d.Cin; }
+    if (l == 0 && has_lift && cs.u0_skipped) { a.x = x; a.lw = prm->lift_w; a.lb = prm->lift_b; a.CL = d.Cin; }
     a.w = prm->skip_w[l];
     a.bias = prm->spec_bias ? prm->spec_bias + (size_t)l * C : nullptr;
     a.z = w.z; a.tinv = p->t.tinv_f;
@@ -1494,7 +1536,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
 
-  if (!has_proj) return FNO_OK;
+  if (!has_proj) { p->put_call(saved, cs); return FNO_OK; }
   // projection (tfno.py:34-38)
   ProjFwdArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -1502,8 +1544,9 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   pa.y = y; pa.PW = g.PW; pa.CO = d.Cout; pa.act_in = (d.gelu_mask >> (L - 1)) & 1u;
   pa.tiles_per_plane = g.PW / 128; pa.ntiles = B * pa.tiles_per_plane;
   pa.xmax = (h2 && L > 0) ? amax + 8 + L : nullptr;
-  p->h2_fwd = pa.xmax != nullptr;
-  p->h2_u0 = h2 && lift_xmax && g_h2;
+  cs.h2_fwd = pa.xmax != nullptr;
+  cs.h2_u0 = h2 && lift_xmax && g_h2;
+  p->put_call(saved, cs);
   const int pgrid = std::min(pa.ntiles, FNO_GRID_PF * p->ncu);
   if (C == 32) LAUNCHCHK(launch_pfwd_c<32>(p, st, pgrid, pa));
   else LAUNCHCHK(launch_pfwd_c<64>(p, st, pgrid, pa));
@@ -1570,9 +1613,10 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   JobList jobs;
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
+  FnoModelPlan::CallState cs = p->get_call(saved);      // what the forward pass that filled `saved` published
   bool gvalid = false;      // amax[32 + l + 1] bounds the gradient the next block kernel reads (two-term fp16 GEMMs)
   float* amax_b = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
-  if (l_hi < L - 1 && g_gemm_x3 && g_h2 && p->h2_fwd) gvalid = p->gchain_valid;      // a later part: left by the previous part's last kernel
+  if (l_hi < L - 1 && g_gemm_x3 && g_h2 && cs.h2_fwd) gvalid = cs.gchain_valid;      // a later part: left by the previous part's last kernel
   // ---- projection backward -> gA = dL/du_L, row DFT (gradient tables) -> x1 ----
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
@@ -1589,14 +1633,14 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   } else {
   // two-term fp16 GEMMs (fno_dev.h "h2") when the forward pass left the bound of |u_L|: bounds of dy and the weights now
   float* amax = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
-  const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && p->h2_fwd;      // (the last forward published max |u_L|)
+  const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && cs.h2_fwd;      // (this buffer's forward published max |u_L|)
   if (h2) {
     if (hipMemsetAsync(amax + 1, 0, 3 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
     LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
                      (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, amax + 1));
     pb.amax = amax; pb.xmax = amax + 8 + L;
   }
-  if (g_gemm_x3 && g_h2 && p->h2_fwd && use_pbwd_t(C, d.Cout, p->NPX)) {      // the chain of gradient bounds starts here
+  if (g_gemm_x3 && g_h2 && cs.h2_fwd && use_pbwd_t(C, d.Cout, p->NPX)) {      // the chain of gradient bounds starts here
     if (hipMemsetAsync(amax + 32 + L, 0, sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
     pb.gmax_out = amax + 32 + L;
     gvalid = true;
@@ -1660,14 +1704,14 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     a.tfwd = p->t.tfwd_b;
     a.dw_part = dw_part_l; a.db_part = db_part_l;
     a.xin = (l == 0 && has_lift) ? x : nullptr; a.dwl_part = w.dwl_part; a.CL = d.Cin;
-    if (l == 0 && has_lift && p->u0_skipped) { a.lw = prm->lift_w; a.lb = prm->lift_b; }
+    if (l == 0 && has_lift && cs.u0_skipped) { a.lw = prm->lift_w; a.lb = prm->lift_b; }
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = g.Klast; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = (l > 0) && ((d.gelu_mask >> (l - 1)) & 1u);
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     if (tail && tail->drop_p > 0.f) { a.drop_seed = tail->drop_seed; a.drop_p = tail->drop_p; }
-    if (g_gemm_x3 && g_h2 && p->h2_fwd && L <= 24) {
+    if (g_gemm_x3 && g_h2 && cs.h2_fwd && L <= 24) {
       // bounds for the two-term fp16 GEMMs: |g| from the previous kernel of the chain, |u_l| from the forward pass
-      if (gvalid && (l > 0 || (a.lw && p->h2_u0))) { a.gmax_in = amax_b + 32 + l + 1; a.umax = amax_b + 8 + l; }
+      if (gvalid && (l > 0 || (a.lw && cs.h2_u0))) { a.gmax_in = amax_b + 32 + l + 1; a.umax = amax_b + 8 + l; }
       if (l > 0) {
         if (hipMemsetAsync(amax_b + 32 + l, 0, sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
         a.gmax_out = amax_b + 32 + l;
@@ -1687,7 +1731,8 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     gcur = gnext;
     { float* t = gnext; gnext = gspare; gspare = t; }
   }
-  p->gchain_valid = gvalid;
+  cs.gchain_valid = gvalid;
+  p->put_call(saved, cs);
   if (dx && has_lift && l_lo == 0) {      // dL/dx = W_l^T dL/du_0 (gcur is block 0's output gradient after the rotation)
     const size_t n4 = (size_t)B * g.PW / 4;
     LAUNCHCHK(launch("k_lift_dx", k_lift_dx, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 8192)), dim3(256), 0, st, gcur,
@@ -2307,14 +2352,15 @@ static int pw_check(int B, int C, size_t PW) {
   return FNO_OK;
 }
 // a FnoModelPlan shell carrying what the launch helpers read (tile size, CU count, width)
-static FnoModelPlan pw_shell(int C) {
-  FnoModelPlan p;
-  memset(&p.d, 0, sizeof(p.d));
-  p.d.C = C;
-  p.NPX = 128;
-  p.ncu = dev_ncu();
-  return p;
-}
+struct PwShell : FnoModelPlan {
+  explicit PwShell(int C) {
+    memset(&d, 0, sizeof(d));
+    d.C = C;
+    NPX = 128;
+    loose = false;
+    ncu = dev_ncu();
+  }
+};
 extern "C" size_t fno_pointwise_workspace_bytes(int C) {
   const int grid = 2 * dev_ncu();
   return ((size_t)grid * 2 * C * C + (size_t)grid * C) * sizeof(float) + 1024;
@@ -2323,7 +2369,7 @@ extern "C" int fno_pointwise_forward(int B, int C, size_t PW, const float* x, co
                                      const float* addend, int input_gelu, float* y, void* stream) {
   LAUNCHCHK(pw_check(B, C, PW));
   if (!x || !w || !y) return fail(FNO_EINVAL, "fno_pointwise_forward: null argument");
-  FnoModelPlan p = pw_shell(C);
+  PwShell p(C);
   PwFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.w = w; a.bias = bias; a.add = addend; a.u = y; a.act_in = input_gelu ? 1 : 0;
@@ -2337,7 +2383,7 @@ extern "C" int fno_pointwise_backward(int B, int C, size_t PW, const float* x, c
   LAUNCHCHK(pw_check(B, C, PW));
   if (!x || !w || !dy || !dw || !ws) return fail(FNO_EINVAL, "fno_pointwise_backward: null argument");
   if (ws_bytes < fno_pointwise_workspace_bytes(C)) return fail(FNO_ENOMEM, "workspace too small");
-  FnoModelPlan p = pw_shell(C);
+  PwShell p(C);
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (int)(PW / 128), ntiles = B * tiles;
   const int grid = std::min(ntiles, FNO_GRID_BWD * p.ncu);
@@ -2394,14 +2440,14 @@ extern "C" size_t fno_projection_workspace_bytes(int C, int hidden) {
 template <int C, int HID, bool RELU>
 static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
   const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(HID / 32) * (C / 16) * 3 * 64 * 16 + (size_t)(HID + HID + 128) * 4;
-  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
+  return GT(3), launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
 template <int C, int HID, bool RELU>
 static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
   if (use_pbwd_t(C, 1, 128))
-    return launch("k_proj_bwd", k_proj_bwd_t<C, HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
+    return GT(3), launch("k_proj_bwd", k_proj_bwd_t<C, HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
-  return launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
+  return GT(3), launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
 }
 // 2..PROJ_MAXCO output channels (PlanePredHead, pinobserver.py:257-273: fc2 -> out_dim * plane_num): the forward kernel with
 // PROJ_MAXCO output rows, the backward on the exact-fp32 first-generation kernel (the split-precision ones are built for one)
@@ -2409,7 +2455,7 @@ template <int C, int HID>
 static int proj_fwd_launch_mo(hipStream_t st, int grid, const ProjFwdArgs& a) {
   constexpr int NCO = PROJ_MAXCO;
   const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(HID / 32) * (C / 16) * 3 * 64 * 16 + (size_t)(HID + NCO * HID + NCO * 128) * 4;
-  return launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, NCO, false>, dim3(grid), dim3(512), lds, st, a);
+  return GT(3), launch("k_proj_fwd", k_proj_fwd_x3<C, HID, 128, NCO, false>, dim3(grid), dim3(512), lds, st, a);
 }
 template <int C, int HID>
 static int proj_bwd_launch_mo(hipStream_t st, int grid, const ProjBwdArgs& a) {
@@ -2419,7 +2465,7 @@ static int proj_bwd_launch_mo(hipStream_t st, int grid, const ProjBwdArgs& a) {
   const bool w1lds = (size_t)(C + 64) * pitch * 4 + small + w1b <= 160 * 1024;
   const bool dbuf = (size_t)(C + 128) * pitch * 4 + small + (w1lds ? w1b : 0) <= 160 * 1024;
   const size_t lds = (size_t)(C + (dbuf ? 128 : 64)) * pitch * 4 + small + (w1lds ? w1b : 0);
-  return launch("k_proj_bwd", k_proj_bwd<C, HID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
+  return GT(1), launch("k_proj_bwd", k_proj_bwd<C, HID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
 }
 static int proj_act_check(int hidden, int act) {
   if (act != FNO_ACT_GELU && act != FNO_ACT_RELU) return fail(FNO_EINVAL, "projection: hidden_act %d (FNO_ACT_GELU or FNO_ACT_RELU)", act);
@@ -2508,7 +2554,7 @@ extern "C" int fno_lifting_forward(int B, int Cin, int C, size_t PW, const float
                                    float* y, void* stream) {
   LAUNCHCHK(lift_check(B, Cin, C, PW));
   if (!x || !w || !y) return fail(FNO_EINVAL, "fno_lifting_forward: null argument");
-  FnoModelPlan p = pw_shell(C);
+  PwShell p(C);
   p.d.Cin = Cin;
   PwFwdArgs a;
   memset(&a, 0, sizeof(a));

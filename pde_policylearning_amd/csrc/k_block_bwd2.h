@@ -566,6 +566,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   int par = 0;
   FNO_TRACE_IF(FNO_TRACE_WHICH == 2 && a.x1g != nullptr);
   int tslot = 0;
+  FNO_CLK_BEGIN();
   for (int tile = tile0; tile < a.ntiles; tile += tstep) {
     const int b = tile / a.tiles_per_plane;
     const int pxt = (tile % a.tiles_per_plane) * 128;
@@ -826,6 +827,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
     }
   }
 
+  FNO_CLK_END(1);
   // ---- partial slabs: one dW slab per group; bias and lifting gradients summed over both groups ---------------------------
   if (a.gmax_out) absmax_publish(vmax, a.gmax_out);
   {

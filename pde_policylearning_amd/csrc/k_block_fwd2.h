@@ -214,6 +214,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   int tslot = 0;
   float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(true);
+  FNO_CLK_BEGIN();
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
@@ -446,5 +447,6 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     }
     tslot += 8;
   }
+  FNO_CLK_END(0);
   if (a.umax) absmax_publish(vmax, a.umax);
 }

@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   if (base_prio) __builtin_amdgcn_s_setprio(1);
   int tslot = 0;
   FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
+  FNO_CLK_BEGIN();
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     tslot += 12;
   }
 
+  FNO_CLK_END(3);
   // ---- partial slabs ---------------------------------------------------------------------------------------------------------
   if (a.gmax_out) absmax_publish(gvmax, a.gmax_out);
   if constexpr (NT3 == 2) {

@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
   if ((int)blockIdx.x < a.ntiles)
     pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
 
+  FNO_CLK_BEGIN();
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
@@ -171,4 +172,5 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
     }
     __syncthreads();
   }
+  FNO_CLK_END(2);
 }

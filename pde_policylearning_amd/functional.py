@@ -120,11 +120,23 @@ def _fresh_grads(ws, planes):
     return [torch.zeros_like(t) if planes else torch.empty_like(t) for t in ws]
 
 
-def _direct_views(direct_grads, spec_ws):
-    """the weights' own .grad storage as real views, or None when direct writes are off / not possible"""
+def _direct_views(direct_grads, spec_ws, last_dim=None):
+    """the weights' own .grad storage as real views, or None when direct writes are off / not possible.
+    `last_dim` = the data's last extent: with plane-major weights the engine writes only the live planes
+    [0, min(last_dim / 2 + 1, modes3)) of a gradient and nobody else clears a direct-write region (the bucket's zero()
+    skips it), so when the live extent SHRINKS against the previous direct write the planes in between are cleared here -
+    they would otherwise keep the last step's gradient (a batch with a shorter last dim behind a longer one)."""
     if not (direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled()
             and all(_same_layout(t.grad, t) for t in spec_ws)):
         return None
+    if last_dim is not None:
+        for t in spec_ws:
+            if t.is_complex() and plane_major(t):
+                k = min(int(last_dim) // 2 + 1, t.shape[-1])
+                prev = t.__dict__.get("_fno_direct_k", 0)
+                if k < prev:
+                    t.grad[..., k:prev].zero_()
+                t._fno_direct_k = k
     return [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_ws]
 
 
@@ -209,9 +221,7 @@ def spectral_conv(x, weights, bias, modes, norm="backward", weight_last_extent=N
     ws = [torch.view_as_real(w) if w.is_complex() else w for w in weights]
     wle = int(weight_last_extent) if weight_last_extent is not None else int(ws[0].shape[-2])
     b = bias.reshape(-1) if bias is not None else None
-    direct = None
-    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(_same_layout(w.grad, w) for w in weights):
-        direct = [torch.view_as_real(w.grad) if w.grad.is_complex() else w.grad for w in weights]
+    direct = _direct_views(direct_grads, weights, last_dim=x.shape[-1])
     return _SpectralConvFn.apply(x, b, tuple(int(m) for m in modes), norm, wle, direct, *ws)
 
 
@@ -680,7 +690,7 @@ def fno_blocks(x, skip_ws, spec_ws, bias, modes, norm, gelu_mask=0, direct_grads
     (`skip_ws[l]`, (C, C) or (C, C, 1..)) and one bias row of `bias` (L, C); GELU after layer l iff bit l
     of `gelu_mask`.  Returns (B, C, ...); differentiable w.r.t. x and every parameter."""
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_ws]
-    direct = _direct_views(direct_grads, spec_ws)       # backward WRITES dL/dW of the spectral weights into their existing .grad storage
+    direct = _direct_views(direct_grads, spec_ws, last_dim=x.shape[-1])       # backward WRITES dL/dW of the spectral weights into their existing .grad storage
     cfg = (len(skip_ws), tuple(int(m) for m in modes), norm, int(gelu_mask), direct)
     return _FNOBlocksFn.apply(cfg, x, bias, *skip_ws, *sw)
 
@@ -1278,9 +1288,7 @@ def spectral_pointwise_layer(u, spec_weights, modes, norm, w, bias, input_gelu=F
     loaded, so a stack is chained on pre-activation tensors.  Check spectral_layer_supported() first."""
     sw = [torch.view_as_real(t) if t.is_complex() else t for t in spec_weights]
     wle = int(weight_last_extent) if weight_last_extent is not None else int(sw[0].shape[-2])
-    direct = None
-    if direct_grads and _SINGLE_USE[-1] and torch.is_grad_enabled() and all(_same_layout(t.grad, t) for t in spec_weights):
-        direct = [torch.view_as_real(t.grad) if t.grad.is_complex() else t.grad for t in spec_weights]
+    direct = _direct_views(direct_grads, spec_weights, last_dim=u.shape[-1])
     return _SpectralLayerFn.apply(u, w, bias, tuple(int(m) for m in modes), norm, wle, bool(input_gelu), direct, *sw)
 
 

@@ -638,6 +638,8 @@ class FusedAdam(object):
                 coff += n
             off += n
         self._release_guards()
+        # the moment buffers are about to be replaced: a hipGraph captured on the old ones (GraphedTrainStep) must not replay
+        self.plan_generation = getattr(self, "plan_generation", 0) + 1
         if not ok:
             if self._runs is not None:
                 self._runs, self._dead = None, {}
@@ -836,11 +838,26 @@ class FusedAdam(object):
         self._dead_step, self._hp_log = self.step_count, []
 
 
-def broadcast_parameters(module, src=0, group=None):
-    """Identical replicas on every rank (rank `src` wins)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def dense_view(t):
+    """A contiguous view of the same storage for a tensor that is a dense PERMUTATION of its memory (the plane-major
+    dialect-C weights of libs/models/pino_models/basics.py: last dim outermost): RCCL / NCCL collectives refuse
+    non-contiguous tensors ("Tensors must be contiguous"), gloo does not."""
+    if t.is_contiguous():
+        return t
+    order = sorted(range(t.dim()), key=lambda d: -t.stride(d))
+    v = t.permute(order)
+    if not v.is_contiguous():
+        raise RuntimeError(f"broadcast_parameters: parameter of shape {tuple(t.shape)}, strides {t.stride()} is not a dense "
+                           "permutation of its storage")
+    return v
+
+
+def broadcast_parameters(module, src=0, group=None, force=False):
+    """Identical replicas on every rank (rank `src` wins).  `force`: also with one rank (exercises the backend's argument
+    checks on a single GPU)."""
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            dist.broadcast(dense_view(t.data), src=src, group=group)
 
 
 def shard_batch(t, rank, world):
@@ -919,8 +936,13 @@ class GraphedTrainStep(object):
         # afterwards would be ignored silently on replay
         self._opt = opt
         self._hyper = (opt.lr, tuple(opt.betas), opt.eps, opt.weight_decay)
+        self._plan_generation = getattr(opt, "plan_generation", 0)
 
     def __call__(self, inputs=None, target=None):
+        if getattr(self._opt, "plan_generation", 0) != self._plan_generation:
+            raise RuntimeError("GraphedTrainStep: the optimizer re-planned its dead weight slices after capture (a forward pass "
+                               "with a longer last dimension than the plan held live); the captured launches address the old "
+                               "moment buffers - build a new GraphedTrainStep")
         if (self._opt.lr, tuple(self._opt.betas), self._opt.eps, self._opt.weight_decay) != self._hyper:
             raise RuntimeError("GraphedTrainStep: the optimizer's lr / betas / eps / weight_decay changed after capture "
                                f"({self._hyper} -> {(self._opt.lr, tuple(self._opt.betas), self._opt.eps, self._opt.weight_decay)}); "

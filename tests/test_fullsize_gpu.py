@@ -135,29 +135,72 @@ def test_fno3d_config4_fullsize_vs_oracle(dev):
     _compare(model, y, params, y64, g64, g32)
 
 
-@pytest.mark.parametrize("which", ["fno2d", "fno3d"])
+def _grads(model):
+    return [(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad) for p in model.parameters() if p.grad is not None]
+
+
+@pytest.mark.parametrize("which", ["fno2d_cfg2_b64", "fno3d_cfg4", "rno2d_cfg3", "pinobserver_fullfield"])
 def test_training_gradients_are_bitwise_repeatable(dev, which):
-    """The engine has no float atomics and fixed reduction orders: the same step gives the same bits.  Thirty repetitions of
-    forward + backward at a size where every kernel runs its production variant (two workgroups per CU, two-term fp16 GEMMs,
-    persistent grids with tails) - a sporadic hazard (one was found in an off-by-default kernel this way)
-    shows up as a repetition that differs."""
-    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
+    """The engine has no float atomics and fixed reduction orders: the same step gives the same bits.  One hundred repetitions
+    of forward + backward of BASELINE configurations 2, 3 and 4 at their full per-GPU batch and of the shipped full-field
+    observer, every kernel in its production variant (two workgroups per CU, two-term fp16 GEMMs, persistent grids with
+    tails).  A sporadic hazard shows up as a repetition that differs: this is the detector that caught the gfx950
+    packed-fp32 op_sel hazard (tools/pk_opsel_hazard.hip) - with the hazardous code rebuilt
+    (-DFNO_SPLIT2_VARIANT=6) the fno2d case fails in the first repetitions (profiles/r04_h2_block_forward_failure_rates.txt)."""
+    from pde_policylearning_amd.libs.models.pino_models.pinobserver import PINObserverFullField
+    from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d, RNO2d
     torch.manual_seed(0)
-    if which == "fno2d":
-        model, shape = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev), (24, 128, 128)
+    if which == "fno2d_cfg2_b64":
+        model = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev)
+        x = torch.from_numpy(fill_named("rep.x", (64, 3, 128, 128), 1.0)).to(dev)
+        run = lambda: model(x)
+    elif which == "fno3d_cfg4":
+        model = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1).to(dev)
+        x = torch.from_numpy(fill_named("rep.x", (8, 3, 64, 64, 64), 1.0)).to(dev)
+        run = lambda: model(x)
+    elif which == "rno2d_cfg3":
+        model = RNO2d(12, 12, 64, 0, layer_num=1).to(dev).eval()      # (eval: the regressor's dropout draws a new mask per call)
+        x = torch.from_numpy(fill_named("rep.x", (32, 1, 128, 128, 1), 1.0)).to(dev)
+        run = lambda: model(x, timestep=1)
     else:
-        model, shape = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1).to(dev), (4, 64, 64, 64)
-    x = torch.from_numpy(fill_named("rep.x", (shape[0], 3) + shape[1:], 1.0)).to(dev)
-    tgt = torch.from_numpy(fill_named("rep.t", (shape[0], 1) + shape[1:], 1.0)).to(dev)
+        model = PINObserverFullField(plane_num=3, modes1=[12] * 4, modes2=[12] * 4, modes3=[12] * 4, fc_dim=128, layers=[64] * 5,
+                                     in_dim=1, out_dim=1, act="gelu", pad_ratio=[0.0, 0.0625]).to(dev)      # (configs/matlab_rno.yaml's active model)
+        x = torch.from_numpy(fill_named("rep.x", (32, 32, 32, 1, 1), 1.0)).to(dev)
+        re = torch.full((32, 1), 150.0, device=dev)
+        run = lambda: model(x, re)
     first = None
-    for rep in range(30):
+    for rep in range(100):
         model.zero_grad(set_to_none=True)
-        y = model(x)
+        y = run()
+        y = y[0] if isinstance(y, (tuple, list)) else y
+        tgt = torch.from_numpy(fill_named("rep.t", tuple(y.shape), 1.0)).to(dev) if first is None else tgt
         O.lp_loss_rel_sum(y, tgt).backward()
-        got = [y.detach().clone()] + [(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad).detach().clone()
-                                       for p in model.parameters()]
+        got = [y.detach()] + _grads(model)
         if first is None:
-            first = got
+            first = [g.clone() for g in got]
             continue
         for i, (a, b) in enumerate(zip(got, first)):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (rep, i)
+
+
+def test_graph_replay_is_bitwise_repeatable(dev):
+    """The same for the hipGraph-replay path (trainer.GraphedTrainStep, the default of the launch-bound workloads): with a
+    zero learning rate every replay is the same step on the same parameters; 100 replays at BASELINE config 2's shape, the
+    gradient bucket compared bit for bit."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, GraphedTrainStep
+    torch.manual_seed(0)
+    model = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev)
+    x = torch.from_numpy(fill_named("rep.x", (64, 3, 128, 128), 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("rep.t", (64, 1, 128, 128), 1.0)).to(dev)
+    bucket = FlatGradBucket(model.parameters(), direct_module=model)
+    opt = FusedAdam(bucket, lr=0.0, weight_decay=0.0, capturable=True)
+    step = GraphedTrainStep(model, bucket, opt, (x,), tgt, FusedLpLoss(size_average=False))
+    first = None
+    for rep in range(100):
+        loss = step()
+        got = (bucket.flat.clone(), loss.clone())
+        if first is None:
+            first = got
+            continue
+        assert torch.equal(got[0].view(torch.int32), first[0].view(torch.int32)) and float(got[1]) == float(first[1]), rep
