@@ -29,9 +29,21 @@ def dev():
     return torch.device("cuda:0")
 
 
+ORACLE_THREADS = 16      # torch's CPU FFT / einsum stop scaling long before a many-core host is full (bench.py's sweep: 8-16 best)
+
+
 def _oracle(forward, params, x, tgt, dtype, chunk):
     """forward(params, x_chunk) -> prediction; sum-reduced relative L2 against tgt; gradients accumulated over the chunks.
     Returns (y, {name: grad}) as numpy arrays of `dtype`."""
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(nthr, ORACLE_THREADS))
+    try:
+        return _oracle_impl(forward, params, x, tgt, dtype, chunk)
+    finally:
+        torch.set_num_threads(nthr)
+
+
+def _oracle_impl(forward, params, x, tgt, dtype, chunk):
     pc = {k: (v.to(dtype) if v.is_floating_point() else v.to(torch.complex128 if dtype == torch.float64 else v.dtype))
           .clone().requires_grad_(True) for k, v in params.items()}
     ys = []
