@@ -37,4 +37,10 @@ for rep in range(2):
     for name, prm in model.named_parameters():
         got = prm.grad
         got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
-        print(f"  {name:40s} {rel_l2(got, g64[name]):.2e}  (torch f32 {rel_l2(g32[name], g64[name]):.2e})")
+        ref = g64[name].astype(np.float64).ravel()
+        gg, g3 = got.astype(np.float64).ravel(), g32[name].astype(np.float64).ravel()
+        nn = float(ref @ ref) or 1.0
+        a_e, a_t = float(gg @ ref) / nn - 1.0, float(g3 @ ref) / nn - 1.0      # scalar part of the deviation: g = (1 + a) g64 + rest
+        r_e = float(np.linalg.norm(gg - (1 + a_e) * ref)) / nn ** 0.5
+        r_t = float(np.linalg.norm(g3 - (1 + a_t) * ref)) / nn ** 0.5
+        print(f"  {name:40s} {rel_l2(got, g64[name]):.2e}  (torch f32 {rel_l2(g32[name], g64[name]):.2e})   scalar part {a_e:+.2e} ({a_t:+.2e}), rest {r_e:.2e} ({r_t:.2e})")
