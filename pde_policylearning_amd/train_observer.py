@@ -10,6 +10,15 @@ environment (out of scope).
   python -m pde_policylearning_amd.train_observer --data-folder DIR --ntrain 800 --ntest 200 --dataset FullFieldNSDataset \
          --model PINObserverFullField --modes 12 --width 64 --plane-indexs -10 -8 -6 --pde-loss-weight 1.0 [--init-cond-path F.mat]
   (N GPUs: python -m torch.distributed.run --nproc-per-node N -m pde_policylearning_amd.train_observer ...)
+
+The reference's own YAMLs drop in (run_pde_observers.py:336-346 + libs/arguments.py:10-39): `--train_yaml configs/base_fno.yaml`
+is loaded with the reference's merge rule (YAML keys OVER command-line values; duplicate YAML keys: the last one wins, as
+yaml.safe_load does), `--set_epoch` / `--set_re` are applied after the merge as upstream, and the keys the loop reads
+(model_name, dataset_name, modes, width, batch_size, x_range, y_range, learning_rate, weight_decay, epochs, recurrent_model,
+recurrent_index, layer_num, model_timestep, plane_indexs, pde_loss_weight, random_split, ntrain, ntest, DATA_FOLDER,
+downsample_rate, init_cond_path, Re) become the run plan (`plan_from_yaml`); keys of the out-of-scope control loop / W&B are
+carried along and ignored:
+  python -m pde_policylearning_amd.train_observer --train_yaml configs/base_fno.yaml [--data-folder DIR] [--set_epoch 5]
 """
 import argparse
 import os
@@ -22,19 +31,25 @@ from torch.utils.data import DataLoader
 
 from .libs.models.fno_models import FNO2dObserver
 from .libs.models.rno_models import RNO2dObserver
-from .libs.pde_data_loader import FullFieldNSDataset, PDEDataset
+from .libs.pde_data_loader import FullFieldNSDataset, PDEDataset, SequentialPDEDataset
 from .trainer import (enable_dp_exchange, DevicePrefetcher, FlatGradBucket, FullFieldObjective, FusedAdam, FusedLpLoss, MeanStdDecoder,
                       broadcast_parameters, shard_batch, train_step)
 
 
 def build_parser():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--data-folder", required=True)
-    ap.add_argument("--ntrain", type=int, required=True)
-    ap.add_argument("--ntest", type=int, required=True)
+    ap.add_argument("--train_yaml", "--train-yaml", dest="train_yaml", default=None,
+                    help="a reference YAML (configs/base_fno.yaml, matlab_rno.yaml, minchan_rno.yaml ...): its keys win over the flags")
+    ap.add_argument("--set_epoch", "--set-epoch", dest="set_epoch", type=int, default=-1)        # run_pde_observers.py:344-345
+    ap.add_argument("--set_re", "--set-re", dest="set_re", type=int, default=-1)                  # :342-343
+    ap.add_argument("--data-folder", default=None, help="required without --train_yaml; with it: replaces the YAML's DATA_FOLDER")
+    ap.add_argument("--ntrain", type=int, default=None)
+    ap.add_argument("--ntest", type=int, default=None)
     ap.add_argument("--random-split", action="store_true")          # run_pde_observers.py:69-72
     ap.add_argument("--model", default="FNO2dObserver", choices=["FNO2dObserver", "RNO2dObserver", "PINObserverFullField"])
-    ap.add_argument("--dataset", default="PDEDataset", choices=["PDEDataset", "FullFieldNSDataset"])   # configs/matlab_rno.yaml:21-22
+    ap.add_argument("--dataset", default="PDEDataset", choices=["PDEDataset", "SequentialPDEDataset", "FullFieldNSDataset"])   # configs/matlab_rno.yaml:21-22
+    ap.add_argument("--recurrent-model", action="store_true")        # run_pde_observers.py:174-178
+    ap.add_argument("--recurrent-index", type=int, default=0)
     ap.add_argument("--plane-indexs", type=int, nargs="+", default=[-10, -8, -6])                     # :62
     ap.add_argument("--pde-loss-weight", type=float, default=0.0)                                     # :56
     ap.add_argument("--init-cond-path", default=None, help=".mat initial condition holding the grid (x, y, z, ym); "
@@ -59,6 +74,61 @@ def build_parser():
     ap.add_argument("--save-path", default=None, help="whole-module checkpoint written whenever the test rel-L2 improves "
                     "(run_pde_observers.py:307-315: torch.save(observer_model, './outputs/<path>_<exp>.pth'))")
     return ap
+
+
+# YAML key -> run-plan attribute (everything else of the YAML is carried under its own name)
+_YAML_KEYS = {"DATA_FOLDER": "data_folder", "model_name": "model", "dataset_name": "dataset"}
+
+
+def load_train_yaml(path):
+    """libs/arguments.py:10-13: yaml.safe_load of the whole file (a key given twice keeps its LAST value: matlab_rno.yaml
+    and minchan_rno.yaml both set `width` twice)."""
+    import yaml
+    with open(path, "r") as f:
+        d = yaml.safe_load(f)
+    if not isinstance(d, dict):
+        raise ValueError(f"{path}: a mapping of settings is expected")
+    return d
+
+
+def plan_from_yaml(args, yaml_dict=None):
+    """The run plan of `train_observer` from parsed flags + (optionally) a reference YAML, with the reference's semantics:
+    merge_args_with_yaml (libs/arguments.py:16-26: the YAML's keys replace the flags'), then --set_re / --set_epoch
+    (run_pde_observers.py:342-345).  An explicit --data-folder still replaces DATA_FOLDER (the YAMLs hold paths of the
+    authors' machines).  Returns a new namespace; `args` is not modified."""
+    plan = dict(vars(args))
+    explicit_folder = plan.get("data_folder")
+    if yaml_dict is None and plan.get("train_yaml"):
+        yaml_dict = load_train_yaml(plan["train_yaml"])
+    y = dict(yaml_dict or {})
+    for k, v in y.items():
+        plan[_YAML_KEYS.get(k, k)] = v
+    if y:
+        if "dataset_name" not in y:
+            # the upstream loop only trains SequentialPDEDataset / FullFieldNSDataset (run_pde_observers.py:170,200); YAMLs
+            # without the key (base_fno.yaml, minchan_rno.yaml) mean the plane sequences
+            plan["dataset"] = "SequentialPDEDataset"
+        if "model_timestep" not in y:
+            ts = y.get("timestep", 1)       # (minchan_rno.yaml: `timestep: 2`; base_fno.yaml: -1)
+            plan["model_timestep"] = int(ts) if isinstance(ts, int) and ts > 0 else 1
+        if explicit_folder:
+            plan["data_folder"] = explicit_folder
+        # run_pde_observers.py:104-107 builds the full-field observer with layers [64] * 5 whatever `width` says
+        # (matlab_rno.yaml: width 34 belongs to the commented-out RNO2dObserver)
+        plan["fullfield_width"] = 64
+    if plan.get("set_re", -1) > 0:
+        plan["Re"] = plan["set_re"]
+    if plan.get("set_epoch", -1) > 0:
+        plan["epochs"] = plan["set_epoch"]
+    plan["recurrent_model"] = bool(plan.get("recurrent_model", False)) or plan.get("model") == "RNO2dObserver"
+    ns = argparse.Namespace(**plan)
+    missing = [k for k in ("data_folder", "ntrain", "ntest") if getattr(ns, k, None) is None]
+    if missing:
+        raise ValueError("train_observer: " + ", ".join(missing) + " not given (flags or --train_yaml)")
+    if ns.model not in ("FNO2dObserver", "RNO2dObserver", "PINObserverFullField"):
+        raise NotImplementedError(f"model_name {ns.model!r} is outside the accelerated hot path (FNO2dObserver, RNO2dObserver, "
+                                  "PINObserverFullField)")
+    return ns
 
 
 def save_if_best(model, test_l2, best, path, rank, log):
@@ -120,17 +190,40 @@ def run(args, log=print):
     idx = torch.randperm(n) if args.random_split else torch.arange(n)
     if args.dataset == "FullFieldNSDataset":
         return run_full_field(args, idx, dev, rank, world, log)
-    ds_args = types.SimpleNamespace(model_timestep=1)
-    train_ds = PDEDataset(ds_args, args.data_folder, idx[:args.ntrain].tolist(), args.downsample_rate, args.x_range, args.y_range)
-    test_ds = PDEDataset(ds_args, args.data_folder, idx[-args.ntest:].tolist(), args.downsample_rate, args.x_range, args.y_range)
+    T = max(int(getattr(args, "model_timestep", 1) or 1), 1)
+    recurrent = bool(getattr(args, "recurrent_model", False)) or args.model == "RNO2dObserver"
+    ri = int(getattr(args, "recurrent_index", 0) or 0)
+    X, Y = args.x_range, args.y_range
+    if args.dataset == "SequentialPDEDataset":
+        # run_pde_observers.py:75-82,170-183: items are `model_timestep` consecutive planes (T, X, Y); a recurrent model sees
+        # the sequence (B, T, X, Y, 1) and is scored on time step `recurrent_index`, every other model sees T independent planes
+        ds_args = types.SimpleNamespace(model_timestep=T)
+        mk = lambda ix: SequentialPDEDataset(ds_args, args.data_folder, ix, args.downsample_rate, X, Y,
+                                             use_patch=bool(getattr(args, "use_patch", False)))
+        if recurrent:
+            if not 0 <= ri < T:
+                raise ValueError(f"recurrent_index {ri} outside the sequence of model_timestep {T}")
+            def make_batch(p, v):
+                return p.reshape(-1, T, X, Y, 1), v.reshape(-1, T, X, Y)[:, ri]
+        else:
+            def make_batch(p, v):
+                return p.reshape(-1, X, Y, 1), v.reshape(-1, X, Y)
+    else:
+        ds_args = types.SimpleNamespace(model_timestep=1)
+        mk = lambda ix: PDEDataset(ds_args, args.data_folder, ix, args.downsample_rate, X, Y)
+        def make_batch(p, v):
+            return (p.unsqueeze(1) if args.model == "RNO2dObserver" else p), v.squeeze(-1)
+    train_ds, test_ds = mk(idx[:args.ntrain].tolist()), mk(idx[-args.ntest:].tolist())
     train_loader = make_train_loader(train_ds, args, world)
     test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
     if args.model == "FNO2dObserver":
-        model = FNO2dObserver(args.modes, args.modes, args.width).to(dev)
+        model = FNO2dObserver(args.modes, args.modes, args.width, use_v_plane=bool(getattr(args, "use_v_plane", False))).to(dev)
         forward = lambda p: model(p, None)
+    elif args.model == "RNO2dObserver":
+        model = RNO2dObserver(args.modes, args.modes, args.width, recurrent_index=ri, layer_num=args.layer_num).to(dev)
+        forward = lambda p: model(p)                             # (B, T, X, Y, 1) -> time step `recurrent_index`
     else:
-        model = RNO2dObserver(args.modes, args.modes, args.width, recurrent_index=0, layer_num=args.layer_num).to(dev)
-        forward = lambda p: model(p.unsqueeze(1))                 # (B, T = 1, X, Y, 1)
+        raise NotImplementedError(f"{args.model} on plane datasets (PINObserverFullField trains on FullFieldNSDataset)")
     broadcast_parameters(model)
     fused = args.model == "FNO2dObserver"
     if fused and world > 1:
@@ -153,7 +246,7 @@ def run(args, log=print):
         for p_plane, v_plane in DevicePrefetcher(train_loader, dev):
             if world > 1:
                 p_plane, v_plane = shard_batch(p_plane, rank, world), shard_batch(v_plane, rank, world)
-            tgt = v_plane.squeeze(-1)
+            p_plane, tgt = make_batch(p_plane, v_plane)
             tot += train_step(forward, bucket, opt, (p_plane,), tgt, loss_fn)     # :185-193
             cnt += tgt.shape[0]
         if world > 1:
@@ -163,7 +256,7 @@ def run(args, log=print):
         test_tot, test_cnt = torch.zeros((), device=dev), 0
         with torch.no_grad():
             for p_plane, v_plane in DevicePrefetcher(test_loader, dev):
-                tgt = v_plane.squeeze(-1)
+                p_plane, tgt = make_batch(p_plane, v_plane)
                 test_tot += loss_fn(forward(p_plane).reshape(tgt.shape), tgt)
                 test_cnt += tgt.shape[0]
         rec = dict(epoch=ep, train_l2=float(tot) / max(cnt, 1), test_l2=float(test_tot) / max(test_cnt, 1),
@@ -189,7 +282,7 @@ def run_full_field(args, idx, dev, rank, world, log):
     test_loader = DataLoader(test_ds, batch_size=args.batch_size, shuffle=False, drop_last=False)
     P, L = len(args.plane_indexs), 4
     model = PINObserverFullField(plane_num=P, modes1=[args.modes] * L, modes2=[args.modes] * L, modes3=[args.modes] * L,
-                                 fc_dim=128, layers=[args.width] * (L + 1), in_dim=1, out_dim=1, act="gelu",
+                                 fc_dim=128, layers=[getattr(args, "fullfield_width", None) or args.width] * (L + 1), in_dim=1, out_dim=1, act="gelu",
                                  pad_ratio=[0.0, 0.0625]).to(dev)                   # run_pde_observers.py:117-131
     broadcast_parameters(model)
     bucket = FlatGradBucket(model.parameters(), direct_module=model)      # spectral-weight gradients written in place
@@ -253,7 +346,7 @@ def run_full_field(args, idx, dev, rank, world, log):
 
 
 def main():
-    run(build_parser().parse_args())
+    run(plan_from_yaml(build_parser().parse_args()))
 
 
 if __name__ == "__main__":

@@ -487,3 +487,33 @@ def test_no_packed_fp32_op_sel_hazard_in_matrix_kernels():
     assert sum(1 for v in res.values() if v[0]) > 100, "the scan did not see the engine's matrix kernels"
     bad = {k: v[1] for k, v in res.items() if v[0] and v[1]}
     assert not bad, f"packed-fp32 op_sel hazard forms in matrix kernels: {bad}"
+
+
+def test_reference_yamls_become_the_run_plan(tmp_path):
+    """`train_observer --train_yaml configs/base_fno.yaml` (BASELINE.json north_star; reference: libs/arguments.py:10-39 merge,
+    run_pde_observers.py:336-346): the YAML's keys win over the flags, a key given twice keeps its last value, --set_epoch /
+    --set_re apply after the merge, and the settings the loop reads come out as the reference's main() would see them."""
+    from pde_policylearning_amd import train_observer as T
+    from tests import yaml_fixtures as Y
+    paths = {}
+    for name, text in (("base_fno", Y.BASE_FNO), ("minchan_rno", Y.MINCHAN_RNO), ("matlab_rno", Y.MATLAB_RNO)):
+        paths[name] = tmp_path / (name + ".yaml")
+        paths[name].write_text(text)
+    parse = lambda *argv: T.plan_from_yaml(T.build_parser().parse_args(list(argv)))
+    p = parse("--train_yaml", str(paths["base_fno"]), "--batch-size", "7", "--modes", "99")
+    assert (p.model, p.dataset, p.modes, p.width, p.batch_size, p.x_range, p.y_range) == ("FNO2dObserver", "SequentialPDEDataset", 12, 32, 20, 32, 32)
+    assert (p.ntrain, p.ntest, p.epochs, p.random_split, p.recurrent_model, p.model_timestep) == (7500, 2500, 500, True, False, 1)
+    assert (p.learning_rate, p.weight_decay, p.data_folder) == (0.001, 0.0001, "./data/planes_channel180_minchan")
+    p = parse("--train_yaml", str(paths["base_fno"]), "--set_epoch", "3", "--data-folder", "/data/mine")
+    assert p.epochs == 3 and p.data_folder == "/data/mine"
+    p = parse("--train_yaml", str(paths["minchan_rno"]))
+    assert (p.model, p.dataset, p.width, p.layer_num, p.batch_size, p.epochs) == ("RNO2dObserver", "SequentialPDEDataset", 34, 3, 32, 200)
+    assert (p.recurrent_model, p.recurrent_index, p.model_timestep, p.random_split) == (True, 0, 2, False)      # `timestep: 2`
+    p = parse("--train_yaml", str(paths["matlab_rno"]), "--set_re", "180")
+    assert (p.model, p.dataset, p.plane_indexs, p.pde_loss_weight, p.model_timestep) == ("PINObserverFullField", "FullFieldNSDataset", [-10, -8, -6], 1.0, 1)
+    assert (p.width, p.fullfield_width, p.batch_size, p.layer_num, p.epochs, p.Re) == (34, 64, 32, 1, 100, 180)
+    assert (p.ntrain, p.ntest, p.init_cond_path) == (280, 20, "./data/channel180_minchan_mf.mat")
+    with pytest.raises(ValueError, match="ntrain"):
+        parse("--data-folder", "/x")                    # no YAML, no counts
+    q = parse("--data-folder", "/x", "--ntrain", "8", "--ntest", "2", "--model", "RNO2dObserver")
+    assert q.recurrent_model and q.dataset == "PDEDataset"

@@ -159,3 +159,71 @@ def test_rno2d_predict_golden(dev):
     assert abs(float(loss) / float(g["loss"][0]) - 1) < TOL
     loss.backward()
     _check_grads(model, g)
+
+
+def test_train_observer_yaml_rno_sequences_vs_oracle(dev, tmp_path, monkeypatch):
+    """`train_observer --train_yaml` on a reference-style RNO YAML (minchan_rno.yaml's keys: `timestep: 2`, recurrent_model,
+    recurrent_index, width given twice) over a SequentialPDEDataset folder: two epochs of two steps of RNO2dObserver at
+    model_timestep 2 (run_pde_observers.py:75-82, 170-193: sequences (B, T, X, Y, 1), scored on time step recurrent_index)
+    against the CPU oracle (observers_oracle.rno2d_forward + torch.optim.Adam) on the same files, initial weights and batch
+    order.  Dropout is switched off on both sides (the oracle restates eval mode)."""
+    import yaml
+    from oracle import observers_oracle as OO
+    from pde_policylearning_amd import train_observer
+    from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
+    rng = np.random.default_rng(7)
+    n, S, T, B = 20, 32, 2, 4
+    xs = np.linspace(0, 2 * np.pi, S, endpoint=False)
+    p = (rng.standard_normal((n, 1, 1)) * np.sin(xs)[None, :, None] + rng.standard_normal((n, 1, 1)) * np.cos(2 * xs)[None, None, :]
+         + 0.1 * rng.standard_normal((n, S, S))).astype(np.float32)
+    v = (0.7 * np.roll(p, 3, axis=1) - 0.2 * p + 0.5).astype(np.float32)
+    for i in range(n):
+        np.save(tmp_path / f"P_planes_{i:06d}.npy", p[i])
+        np.save(tmp_path / f"V_planes_{i:06d}.npy", v[i])
+    meta = {"P_planes": dict(mean=p.mean(0), std=p.std(0)), "V_planes": dict(mean=v.mean(0), std=v.std(0))}
+    np.save(tmp_path / "metadata.npy", meta, allow_pickle=True)
+    cfg = tmp_path / "rno.yaml"
+    cfg.write_text("DATA_FOLDER: './data/somewhere_else'\nntrain: 16\nntest: 4\nmodel_name: RNO2dObserver\nlearning_rate: 0.001\n"
+                   "weight_decay: 0.0001\nmodes: 12\nwidth: 32\ndownsample_rate: 1\nx_range: 32\ny_range: 32\nuse_patch: false\n"
+                   "timestep: 2\nrecurrent_model: true\nrecurrent_index: 1\nrandom_split: false\nwidth: 64\nbatch_size: 4\n"
+                   "layer_num: 1\nclose_wandb: true\nepochs: 2\n")
+
+    def no_dropout(*a, **k):
+        m = RNO2dObserver(*a, **k)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m
+    monkeypatch.setattr(train_observer, "RNO2dObserver", no_dropout)
+    args = train_observer.plan_from_yaml(train_observer.build_parser().parse_args(
+        ["--train_yaml", str(cfg), "--data-folder", str(tmp_path), "--no-shuffle"]))
+    assert (args.width, args.model_timestep, args.recurrent_index, args.dataset) == (64, 2, 1, "SequentialPDEDataset")
+    hist = train_observer.run(args, log=lambda *_: None)
+
+    # ---- the oracle's trajectory --------------------------------------------------------------------------------------
+    torch.manual_seed(args.seed)
+    ref = RNO2dObserver(12, 12, 64, recurrent_index=1, layer_num=1)
+    prm = {k: v.detach().clone().requires_grad_(True) for k, v in ref.state_dict().items()}
+    opt = torch.optim.Adam(list(prm.values()), lr=1e-3, weight_decay=1e-4)
+    eps = 1e-5
+    enc = lambda a, s: (torch.from_numpy(a) - torch.from_numpy(s["mean"])) / (torch.from_numpy(s["std"]) + eps)
+    pn, vn = enc(p, meta["P_planes"]), enc(v, meta["V_planes"])
+    dec = lambda t: t * (torch.from_numpy(meta["V_planes"]["std"]) + eps) + torch.from_numpy(meta["V_planes"]["mean"])
+    seq = lambda a, lo, hi: a[lo:hi].reshape(-1, T, S, S)
+
+    def loss_of(lo, hi):
+        x, tgt = seq(pn, lo, hi).unsqueeze(-1), seq(vn, lo, hi)[:, 1]
+        y = OO.rno2d_forward(prm, x, 12, 12, 64, 1, 1).reshape(tgt.shape)
+        return O.lp_loss_rel_sum(dec(y), dec(tgt))
+    for ep in range(2):
+        tot = 0.0
+        for lo in (0, 8):                          # 16 training frames = 8 sequences = two batches of 4
+            opt.zero_grad()
+            l = loss_of(lo, lo + 8)
+            l.backward()
+            opt.step()
+            tot += float(l)
+        with torch.no_grad():
+            test = float(loss_of(16, 20))
+        assert abs(hist[ep]["train_l2"] - tot / 8) < 2e-4 * (tot / 8), (ep, hist[ep], tot / 8)
+        assert abs(hist[ep]["test_l2"] - test / 2) < 2e-4 * (test / 2), (ep, hist[ep], test / 2)
