@@ -84,6 +84,12 @@ static thread_local int g_terms_next = 0;
 #define GT(n) (g_terms_next = (n))
 static std::vector<ProfAgg> g_agg;
 
+#ifdef PFW_TRACE
+extern "C" int fno_debug_pfw_dump(unsigned long long* host, size_t n) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pfw_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FNO_CLOCK
 extern "C" int fno_debug_clock_dump(unsigned long long* host, size_t n) {
   hipDeviceSynchronize();
@@ -1337,6 +1343,14 @@ static int bbwd_ksplit(const FnoModelPlan* p) {
 template <int C, int NCO>
 static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
   // no row structure in the projection: always 128-pixel tiles
+  static const int no_pfw = getenv("FNO_NO_PFWD_W") ? 1 : 0;       // A/B switch: the 8-wave tile kernel (k_proj_fwd_h2) instead
+  if (g_gemm_x3 && g_h2 && a.xmax && NCO == 1 && !no_pfw && a.PW % 32 == 0) {
+    // independent waves, four per SIMD (k_projection_h2.h): two workgroups per CU
+    constexpr int NWV = 12;
+    const int ncols = a.ntiles * 4;
+    return GT(2), launch("k_proj_fwd", k_proj_fwd_w<C, kHID, NWV>, dim3(std::min((ncols + NWV - 1) / NWV, 2 * p->ncu)), dim3(NWV * 64),
+                         proj_fwd_w_lds(C, kHID), st, a);
+  }
   if (g_gemm_x3 && g_h2 && a.xmax) {
     const size_t lds = (size_t)2 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 2 * 64 * 16 +
                        (size_t)(kHID + NCO * kHID + NCO * 128) * 4;

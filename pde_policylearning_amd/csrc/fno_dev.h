@@ -308,6 +308,9 @@ FNO_DEV float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
   return make_float4(v[0], v[1], v[2], v[3]);
 }
+FNO_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 FNO_DEV bf16x8 buf_ld8h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }

@@ -125,9 +125,13 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
     float ysum[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      f32x16 acc, lo;      // hh products / cross terms
+    // One-chunk software pipeline (round 4): the products of chunk ch + 1 are ISSUED before the GELU of chunk ch, so a wave's
+    // matrix work runs under its own vector work instead of waiting for the SIMD partner to be in the other phase (the
+    // chunk loop used to be `unroll 1`: 12 MFMAs, then ~170 vector instructions, strictly in turn; PFWD_PIPE=0 restores it).
+#ifndef PFWD_PIPE
+#define PFWD_PIPE 1
+#endif
+    auto products = [&](int ch, f32x16& acc, f32x16& lo) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo[r] = 0.f; }
       const unsigned short* wa = w1b + ((size_t)((ch * 2 + hm) * KB * 2) * 64 + lane) * 8;
@@ -138,6 +142,8 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
         for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const f16x8*>(wa + (size_t)(kb * 2 + t) * 64 * 8);
         mfma_h2s(af, bfrag[kb], acc, lo);
       }
+    };
+    auto activate = [&](int ch, const f32x16& acc, const f32x16& lo) {
       const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
       const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
       f32x2 hp[8];
@@ -157,7 +163,28 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
 #pragma unroll
         for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
       }
+    };
+#if PFWD_PIPE
+    static_assert(NCH % 2 == 0, "two accumulator sets alternate");
+    f32x16 accA, loA, accB, loB;
+    products(0, accA, loA);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch += 2) {
+      products(ch + 1, accB, loB);
+      __builtin_amdgcn_sched_barrier(0);        // (the products above stay ahead of the vector work below)
+      activate(ch, accA, loA);
+      if (ch + 2 < NCH) products(ch + 2, accA, loA);
+      __builtin_amdgcn_sched_barrier(0);
+      activate(ch + 1, accB, loB);
     }
+#else
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      f32x16 acc, lo;      // hh products / cross terms
+      products(ch, acc, lo);
+      activate(ch, acc, lo);
+    }
+#endif
 #pragma unroll
     for (int co = 0; co < NCO; ++co) {
       ysum[co] += __shfl_xor(ysum[co], 32, 64);
@@ -174,3 +201,161 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
   }
   FNO_CLK_END(2);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Projection forward, third generation ("w": independent waves; round 4).  tools/occupancy_valu_test.hip measured what bounds
+// the fused kernels: one SIMD issues 0.14-0.19 vector instructions per cycle from ONE wave, 0.23-0.28 from two, 0.30-0.37
+// from four and 0.51-0.59 from eight - and beside a wave that keeps the matrix pipe busy only 0.09-0.11 / 0.15-0.18 / 0.23-0.27
+// from one / two / four vector waves (profiles/r04_valu_rate_vs_waves_per_simd.txt).  The 8-wave kernels with one workgroup
+// per CU (two waves per SIMD, 160-250 VGPRs) therefore run their GELU-heavy vector phases at a third of the SIMD's issue rate,
+// whatever their structure.  This kernel is built for SIX to EIGHT waves per SIMD instead (two 12- / 16-wave workgroups per CU,
+// 80 / 64 VGPRs, 67 / 34 KB of LDS each) and has NO barrier in its main loop:
+//   * a wave owns a COLUMN of 32 consecutive pixels for all channels and all hidden rows; it loads the column straight from HBM
+//     into MFMA operand layout (lane = (pixel, k half), eight channels 16 kb + 8 half + j in eight registers: every load
+//     instruction moves two whole 128-byte lines), applies GELU and splits in registers - no LDS round trip, no commit barrier;
+//   * only the weights live in LDS (two fp16 terms of W1, split once per workgroup), read as A fragments by every wave;
+//   * per chunk of 32 hidden rows: 12 fp16 MFMAs into (hh, cross) accumulators, then bias + GELU + the w2 dot on the 16
+//     accumulator values of a lane; the waves of a SIMD drift apart on their own, so one wave's matrix burst runs under the
+//     others' vector work.
+// Same arithmetic as k_proj_fwd_h2 (bitwise: same products, same order); reference semantics neuralop/models/tfno.py:23-38.
+#ifdef PFW_TRACE
+__device__ unsigned long long g_pfw_trace[64 * 16 * 4];
+#endif
+// Two 12-wave workgroups per CU (six waves per SIMD, <= 80 VGPRs), static shares of the columns.  Measured on the way
+// (profiles/r04_proj_fwd_w_workgroup_times.txt, tools/kernel_clock.py): the workgroup that arrives second on a CU loses the
+// vector-issue arbitration to the older one (median 83 us vs 137 us for workgroups [0, 256) / [256, 512) of one launch, both
+// started within 5 us) - alternating the issue priority per column in opposite phase evens that out (107 / 137 us) but the
+// launch ends at the same time (150 us from first start to last end: the SIMDs' issue capacity, not the split, bounds it;
+// the old 8-wave tile kernel: 176 us); ONE 16-wave workgroup per CU with an LDS work queue is balanced but slower (159-174 us:
+// four waves per SIMD); eight global work queues (returning atomics on eight addresses) serialise: 465 us.  The chip holds
+// 1.9-2.0 GHz inside this kernel where the 8-wave kernels hold 2.3-2.4 (denser issue, MI355X_MICROARCH.md DVFS item 4).
+template <int C, int HID, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArgs a) {
+  constexpr int KB = C / 16, NCHK = HID / 32, NT = NWAVE * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short* w1b = reinterpret_cast<unsigned short*>(smem);          // [HID/32][KB][2 terms][64 lanes][8 halfs]
+  float* b1s = reinterpret_cast<float*>(w1b + (size_t)NCHK * KB * 2 * 64 * 8);
+  float* w2s = b1s + HID;
+  float* scratch = w2s + HID;                                              // NWAVE floats
+  float gk_six, gk_inf;
+  gelu_consts(gk_six, gk_inf);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  FNO_CLK_BEGIN();
+
+#ifdef PFW_TRACE
+  const unsigned long long tr_k0 = __builtin_readcyclecounter();
+#endif
+  const float sx = h2_scale(*a.xmax);
+  const float sw = h2_scale(wg_absmax<NT>(a.w1, HID * C, scratch, tid));
+#ifdef PFW_TRACE
+  const unsigned long long tr_k1 = __builtin_readcyclecounter();
+#endif
+  const float inv = 1.0f / (sx * sw);
+  for (int i = tid; i < HID; i += NT) { b1s[i] = a.b1[i]; w2s[i] = a.w2[i]; }
+  for (int it = tid; it < NCHK * KB * 64; it += NT) {      // item = (hidden 32-block, k block, lane)
+    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a.w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
+    f16x8 h, l;
+    split2x8(v, sw, h, l);
+    unsigned short* dst = w1b + ((size_t)((mt * KB + kb) * 2) * 64 + ln) * 8;
+    *reinterpret_cast<f16x8*>(dst) = h;
+    *reinterpret_cast<f16x8*>(dst + 64 * 8) = l;
+  }
+  __syncthreads();
+
+  const int cols_per_plane = a.PW / 32, ncols = a.ntiles * 4;
+  const unsigned PWb = (unsigned)a.PW * 4u;
+  const float b2v = a.b2[0];
+#ifdef PFW_TRACE      // diagnostic build: where a wave's cycles go (stamps cost an s_waitcnt lgkmcnt(0) each)
+  unsigned long long tr_load = 0, tr_mfma = 0, tr_valu = 0, tr_cols = 0, tr_t = __builtin_readcyclecounter(), tr_n;
+  const unsigned long long tr_k2 = tr_t;
+#define PFW_STAMP(acc) do { tr_n = __builtin_readcyclecounter(); acc += tr_n - tr_t; tr_t = tr_n; } while (0)
+#else
+#define PFW_STAMP(acc) do { } while (0)
+#endif
+  const int voff = (8 * half * a.PW + l31) * 4;
+  // Static shares; the issue priority alternates from column to column, in opposite phase for the two workgroups of a CU
+  // (blockIdx.x < / >= gridDim.x / 2 under round-robin dispatch), so that neither starves the other (priority outranks age).
+  int kcol = (2 * (int)blockIdx.x >= (int)gridDim.x) ? 1 : 0;
+  for (int col = blockIdx.x * NWAVE + wave; col < ncols; col += gridDim.x * NWAVE, ++kcol) {
+    if (kcol & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    const int b = col / cols_per_plane;
+    const int px0 = (col - b * cols_per_plane) * 32;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)b * C * a.PW + px0, (unsigned)(C - 1) * PWb + 128u);
+    // B[k = c][n = px] fragments of the column: lane (px = l31, half) holds channels 16 kb + 8 half + j
+    f16x8 bfrag[KB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf_ld1(rx, voff, (unsigned)(16 * kb + j) * PWb);
+      if (a.act_in) gelu8(v, gk_six, gk_inf);
+      split2x8(v, sx, bfrag[kb][0], bfrag[kb][1]);
+    }
+#ifdef PFW_TRACE
+    asm volatile("" :: "v"(bfrag[KB - 1][1]));
+#endif
+    PFW_STAMP(tr_load);
+    float ysum = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < NCHK; ++ch) {
+      f32x16 acc, lo;      // hh products / cross terms
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo[r] = 0.f; }
+      const unsigned short* wa = w1b + ((size_t)(ch * KB * 2) * 64 + lane) * 8;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        f16x8 af[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const f16x8*>(wa + (size_t)(kb * 2 + t) * 64 * 8);
+        mfma_h2s(af, bfrag[kb], acc, lo);
+      }
+#ifdef PFW_TRACE
+      asm volatile("s_nop 11" :: "v"(acc), "v"(lo));
+#endif
+      PFW_STAMP(tr_mfma);
+      // D[row = hidden 32 ch + (r & 3) + 8 (r >> 2) + 4 half][col = pixel l31]
+      const float* b1p = b1s + ch * 32 + 4 * half;
+      const float* w2p = w2s + ch * 32 + 4 * half;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {            // eight values at a time: half the live temporaries of the packed GELU
+        f32x2 hp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 8 * q + 2 * k;
+          hp[k][0] = fmaf(acc[r] + lo[r], inv, b1p[(r & 3) + 8 * (r >> 2)]);
+          hp[k][1] = fmaf(acc[r + 1] + lo[r + 1], inv, b1p[((r + 1) & 3) + 8 * ((r + 1) >> 2)]);
+        }
+        gelu_pairs<4>(hp, gk_six, gk_inf);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 8 * q + 2 * k;
+          ysum = fmaf(w2p[(r & 3) + 8 * (r >> 2)], hp[k][0], ysum);
+          ysum = fmaf(w2p[((r + 1) & 3) + 8 * ((r + 1) >> 2)], hp[k][1], ysum);
+        }
+      }
+#ifdef PFW_TRACE
+      asm volatile("" :: "v"(ysum));
+#endif
+      PFW_STAMP(tr_valu);
+    }
+    ysum += __shfl_xor(ysum, 32, 64);
+    if (half == 0) a.y[(size_t)b * a.PW + px0 + l31] = ysum + b2v;
+#ifdef PFW_TRACE
+    ++tr_cols;
+#endif
+  }
+  FNO_CLK_END(2);
+#ifdef PFW_TRACE
+  if (lane == 0 && blockIdx.x < 64) {
+    unsigned long long* q = g_pfw_trace + (blockIdx.x * NWAVE + wave) * 4;
+    q[0] = tr_load; q[1] = tr_mfma; q[2] = tr_valu; q[3] = tr_cols | ((tr_k1 - tr_k0) << 16) | ((tr_k2 - tr_k1) << 40);
+  }
+#endif
+}
+static inline size_t proj_fwd_w_lds(int C, int HID) { return (size_t)(HID / 32) * (C / 16) * 2 * 64 * 16 + (size_t)(2 * HID + 16 + 4) * 4; }

@@ -45,5 +45,17 @@ for kid, name in enumerate(("k_blk_fwd_t (block forward)", "k_block_bwd_g2 (bloc
         continue
     ghz = (r[ok, 1] - r[ok, 0]) / (r[ok, 3] - r[ok, 2]) * 0.1
     us = (r[ok, 3] - r[ok, 2]) / 100.0
+    span = (r[ok, 3].max() - r[ok, 2].min()) / 100.0
+    late = (r[ok, 2] - r[ok, 2].min()) / 100.0
     print(f"   {name:38s} workgroups {int(ok.sum()):4d}   clock median {np.median(ghz):.3f} GHz  (min {ghz.min():.3f}, max {ghz.max():.3f})"
-          f"   tile-loop time median {np.median(us):.1f} us")
+          f"   stamped-section time median {np.median(us):.1f} us; first start to last end {span:.1f} us; "
+          f"workgroups starting > 5 us after the first: {int((late > 5).sum())}")
+
+    if kid == 2:
+        d = (r[ok, 3] - r[ok, 2]) / 100.0
+        idx = np.nonzero(ok)[0]
+        print("      duration quantiles [0, 10, 50, 90, 100] %:", " ".join(f"{np.percentile(d, q):.1f}" for q in (0, 10, 50, 90, 100)))
+        print("      median by blockIdx % 8 (XCD under round-robin):", " ".join(f"{np.median(d[idx % 8 == x]):.1f}" for x in range(8)))
+        print("      median of workgroups [0, 256) / [256, 512):", f"{np.median(d[idx < 256]):.1f} / {np.median(d[idx >= 256]):.1f}")
+        end = (r[ok, 3] - r[ok, 2].min()) / 100.0
+        print("      end time quantiles [0, 10, 50, 90, 100] %:", " ".join(f"{np.percentile(end, q):.1f}" for q in (0, 10, 50, 90, 100)))
