@@ -609,7 +609,8 @@ def main():
             "value_min": round(B * world * args.steps / max(blocks), 2),
             "value_max": round(B * world * args.steps / min(blocks), 2),
             "ms_per_step_all": [round(1e3 * b / args.steps, 4) for b in blocks],
-            "n_ranks": dist.get_world_size() if dist_on else 1,
+            "n_ranks": dist.get_world_size() if dist_on else 1,      # RCCL ranks seen by torch.distributed
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist_on else None,
             "allreduce_ms_total": exchange[0] if exchange else None,
             "allreduce_ms_exposed": exchange[1] if exchange else None,
             "gradient_exchange": {"bucket_bytes": 4 * bucket.flat.numel(), "wire_bytes_per_rank_per_step": bucket.planned_wire_bytes(),

@@ -1646,21 +1646,24 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, dy, w.x1));     // dy is dL/du_L
   } else {
   // two-term fp16 GEMMs (fno_dev.h "h2") when the forward pass left the bound of |u_L|: bounds of dy and the weights now
+  // Bound slots written by the backward pass: [32 + l] max |g_l| (the chain) and, through bwd_b = amax + 59, [60] max |dy|,
+  // [61] max |W1|, [62] max |w2| (the kernels index them as bwd_b[1..3]) - ONE contiguous range, cleared by ONE memset at
+  // the start of the pass (round 3 issued five small ones per step; the forward's memset of all 64 slots is the other one)
   float* amax = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
+  float* bwd_b = amax + 59;
   const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && cs.h2_fwd;      // (this buffer's forward published max |u_L|)
+  if (h2 && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   if (h2) {
-    if (hipMemsetAsync(amax + 1, 0, 3 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
     LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
-                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, amax + 1));
-    pb.amax = amax; pb.xmax = amax + 8 + L;
+                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, bwd_b + 1));
+    pb.amax = bwd_b; pb.xmax = amax + 8 + L;
   }
   if (g_gemm_x3 && g_h2 && cs.h2_fwd && use_pbwd_t(C, d.Cout, p->NPX)) {      // the chain of gradient bounds starts here
-    if (hipMemsetAsync(amax + 32 + L, 0, sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
     pb.gmax_out = amax + 32 + L;
     gvalid = true;
   }
   if (g_gemm_x3) {
-    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? amax + 2 : nullptr));
+    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? bwd_b + 2 : nullptr));
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
@@ -1726,10 +1729,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     if (g_gemm_x3 && g_h2 && cs.h2_fwd && L <= 24) {
       // bounds for the two-term fp16 GEMMs: |g| from the previous kernel of the chain, |u_l| from the forward pass
       if (gvalid && (l > 0 || (a.lw && cs.h2_u0))) { a.gmax_in = amax_b + 32 + l + 1; a.umax = amax_b + 8 + l; }
-      if (l > 0) {
-        if (hipMemsetAsync(amax_b + 32 + l, 0, sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
-        a.gmax_out = amax_b + 32 + l;
-      }
+      if (l > 0) a.gmax_out = amax_b + 32 + l;      // (cleared with the whole range at the start of the pass)
     }
     bool published = false;
     LAUNCHCHK(launch_bbwd(p, st, s.grid_bb, a, &published));

@@ -125,11 +125,12 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
     float ysum[NCO];
 #pragma unroll
     for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
-    // One-chunk software pipeline (round 4): the products of chunk ch + 1 are ISSUED before the GELU of chunk ch, so a wave's
-    // matrix work runs under its own vector work instead of waiting for the SIMD partner to be in the other phase (the
-    // chunk loop used to be `unroll 1`: 12 MFMAs, then ~170 vector instructions, strictly in turn; PFWD_PIPE=0 restores it).
+    // One-chunk software pipeline (round 4 experiment, -DPFWD_PIPE=1): the products of chunk ch + 1 ISSUED before the GELU of
+    // chunk ch, so that a wave's matrix work runs under its own vector work.  Measured 0.194-0.199 vs 0.200-0.212 ms per
+    // launch at config 2 (within the noise of the boxes) for 208 instead of 168 VGPRs, and the four-output variant spills with
+    // it: off.  (One output channel takes k_proj_fwd_w below by default.)
 #ifndef PFWD_PIPE
-#define PFWD_PIPE 1
+#define PFWD_PIPE 0
 #endif
     auto products = [&](int ch, f32x16& acc, f32x16& lo) {
 #pragma unroll

@@ -28,6 +28,21 @@ class DenseComplexWeight(nn.Module):
     def to_tensor(self):
         return torch.view_as_complex(self.tensor)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints of the reference carry this weight under whatever leaf name its tltorch version gives the dense
+        factorized tensor (unpinned: tltorch is neither vendored nor version-locked, spectral_convolution.py:253-268) and
+        possibly as a complex tensor.  Any SINGLE entry below this module's prefix is taken as the weight; a complex value
+        is stored as its real (.., 2) view."""
+        key = prefix + "tensor"
+        if key not in state_dict:
+            cands = [k for k in state_dict if k.startswith(prefix)]
+            if len(cands) == 1:
+                state_dict[key] = state_dict.pop(cands[0])
+        v = state_dict.get(key)
+        if torch.is_tensor(v) and v.is_complex():
+            state_dict[key] = torch.view_as_real(v.resolve_conj().contiguous())
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
 
 def _unsupported(what):
     raise NotImplementedError(

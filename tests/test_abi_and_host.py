@@ -517,3 +517,25 @@ def test_reference_yamls_become_the_run_plan(tmp_path):
         parse("--data-folder", "/x")                    # no YAML, no counts
     q = parse("--data-folder", "/x", "--ntrain", "8", "--ntest", "2", "--model", "RNO2dObserver")
     assert q.recurrent_model and q.dataset == "PDEDataset"
+
+
+def test_reference_checkpoint_leaf_names_are_tolerated():
+    """The spectral weights of a reference checkpoint sit under a leaf name that its tltorch version decides (unpinned) and may
+    be complex: any single leaf below `fno_blocks.convs.weight.N.` loads (spectral_convolution.py:253-268)."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    torch.manual_seed(1)
+    src = FNO2d(8, 8, 32, in_channels=3, out_channels=1)
+    sd = src.state_dict()
+    foreign = {}
+    for k, v in sd.items():
+        if ".convs.weight." in k and k.endswith(".tensor"):
+            n = int(k.split(".convs.weight.")[1].split(".")[0])
+            # two spellings a tltorch release could use: a real view under another name, a complex tensor
+            foreign[k[:-len("tensor")] + ("_tensor_real" if n % 2 else "weight")] = v.clone() if n % 2 else torch.view_as_complex(v.clone())
+        else:
+            foreign[k] = v.clone()
+    dst = FNO2d(8, 8, 32, in_channels=3, out_channels=1)
+    missing, unexpected = dst.load_state_dict(foreign, strict=True)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(sd.items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k

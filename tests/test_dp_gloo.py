@@ -171,10 +171,12 @@ def _overlap_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_overlapped_bucket_reduces_every_element_once():
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlapped_bucket_reduces_every_element_once(world):
     """FlatGradBucket.for_fno: async exchange of the late layers' segment + the rest == one all-reduce of everything;
-    the late segment holds the projection and blocks L-1..split_layer."""
-    world, port = 2, _free_port()
+    the late segment holds the projection and blocks L-1..split_layer.  World sizes 2 and 4 (the driver's scaling run uses
+    1 / 2 / 4 / 8 ranks of the same code)."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
