@@ -68,8 +68,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r03_pmc_traffic.json"
-PMC_SQ_CSV = "r03_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r04_pmc_traffic.json"
+PMC_SQ_CSV = "r04_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def source_hash():

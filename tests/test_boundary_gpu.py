@@ -199,6 +199,7 @@ def test_train_observer_yaml_rno_sequences_vs_oracle(dev, tmp_path, monkeypatch)
         ["--train_yaml", str(cfg), "--data-folder", str(tmp_path), "--no-shuffle"]))
     assert (args.width, args.model_timestep, args.recurrent_index, args.dataset) == (64, 2, 1, "SequentialPDEDataset")
     hist = train_observer.run(args, log=lambda *_: None)
+    torch.set_num_threads(min(torch.get_num_threads(), 16))      # (torch's CPU FFT / einsum do not scale past that on a many-core host)
 
     # ---- the oracle's trajectory --------------------------------------------------------------------------------------
     torch.manual_seed(args.seed)

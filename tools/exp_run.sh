@@ -1,11 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04
-timeout -k 10 300 python -m pytest tests/test_parity_gpu.py -x -q -k "projection or fno_model_golden" 2>&1 | tail -n 2
-FNO_LIB_PATH=$PWD/tools/exp_clock.so python tools/kernel_clock.py 2>&1 | tail -n 8
-for i in 1 2; do
-python bench.py --no-cpu-baseline --repeats 5 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k={x['name']:x['avg_ms'] for x in d['kernels']}; print('new', d['ms_per_step'], 'proj_fwd', k.get('k_proj_fwd'))"
-FNO_NO_PFWD_W=1 python bench.py --no-cpu-baseline --repeats 5 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k={x['name']:x['avg_ms'] for x in d['kernels']}; print('old', d['ms_per_step'], 'proj_fwd', k.get('k_proj_fwd'))"
+for e in "X=1" "FNO_NO_PFWD_W=1"; do
+env $e python bench.py --config fno3d_64_w32_m8_b16 --no-cpu-baseline --steps 10 --repeats 5 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k={x['name']:(x['launches_per_step'],x['avg_ms']) for x in d['kernels']}; print('$e fno3d', d['ms_per_step'], d['value'], {n:k[n] for n in list(k)[:8]})"
 done
 exit 0
