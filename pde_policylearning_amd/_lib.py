@@ -61,6 +61,11 @@ def lib():
         raise RuntimeError(
             f"fnoengine: {LIB_PATH} not found. Build it with `python -m pde_policylearning_amd.build` "
             "(needs hipcc; gfx950). There is no CPU / PyTorch fallback.")
+    # torch first: its wheel carries its own libamdhip64.so.7 / libhsa-runtime64, and the library works on pointers torch's
+    # allocator hands out, so both must sit on ONE HIP runtime.  Loaded after torch, the library's NEEDED libamdhip64.so.7
+    # resolves to the copy already in the process; loaded before it, /opt/rocm's copy comes in as a second runtime and
+    # every later call fails with "no HIP device" (seen with build() and smoke() in one process).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
     L.fno_version.restype = ci

@@ -539,3 +539,20 @@ def test_reference_checkpoint_leaf_names_are_tolerated():
     assert not missing and not unexpected
     for (k, a), (_, b) in zip(sd.items(), dst.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_library_shares_the_hip_runtime_of_torch():
+    """One HIP runtime per process: the library works on torch's pointers and streams, so it must resolve libamdhip64.so.7 to
+    the copy torch loaded (pde_policylearning_amd/_lib.py lib()).  A fresh interpreter that has NOT imported torch loads the
+    library through _lib.lib(), then torch: /opt/rocm's runtime must not appear beside the wheel's."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pde_policylearning_amd import _lib\n_lib.lib()\nimport torch, os\n"
+            "tl = os.path.realpath(os.path.join(os.path.dirname(torch.__file__), 'lib'))\n"
+            "libs = sorted({os.path.realpath(l.split()[-1]) for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l})\n"
+            "own = [l for l in libs if l.startswith(tl)]\n"
+            "print(libs)\n"
+            "assert not own or own == libs, libs\n"
+            "assert len({os.path.basename(l).split('.so')[0] for l in libs}) == len(libs), libs\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
