@@ -1174,11 +1174,16 @@ static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds)
   return *lds + 2048 <= 160 * 1024;
 }
 template <int C>
-static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
+static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a_in) {
   size_t lds2 = 0;
-  if (blk_fwd_t_ok<C>(p, a, &lds2)) {
+  const PwFwdArgs& a = a_in;
+  if (blk_fwd_t_ok<C>(p, a_in, &lds2)) {
     const dim3 g2(std::min(a.ntiles, (g_grid_bf2 > 0 ? g_grid_bf2 : (C == 64 ? 2 : 3)) * p->ncu)), blk((C / 32) * 2 * 64);
     const int epi = a.x1 ? (a.act_out ? 2 : 1) : 0;
+    // two workgroups per CU: the one dispatched first gets the larger share of the CU's tiles (pair_share, fno_dev.h)
+    static const int share_bf = getenv("FNO_BF_SHARE") ? atoi(getenv("FNO_BF_SHARE")) : 18;      // of 32; 0 / 16 = even
+    PwFwdArgs a = a_in;
+    a.share32 = ((int)g2.x == 2 * p->ncu) ? share_bf : 0;
     // (template flags: LIFT, RELU, ACT_IN, EPI, ADD - k_block_fwd2.h; other combinations keep k_pw_fwd_x3)
     const int kz = a.z ? (2 * a.K2in + 15) / 16 : 0;
     const bool h2k = g_h2 && g_h2_blocks && g_h2_fwd_blocks && a.xmax && kz > 0 && !a.add && !a.relu_out;      // two-term fp16 variants: the model path's combinations
@@ -1348,8 +1353,11 @@ static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
     // independent waves, four per SIMD (k_projection_h2.h): two workgroups per CU
     constexpr int NWV = 12;
     const int ncols = a.ntiles * 4;
-    return GT(2), launch("k_proj_fwd", k_proj_fwd_w<C, kHID, NWV>, dim3(std::min((ncols + NWV - 1) / NWV, 2 * p->ncu)), dim3(NWV * 64),
-                         proj_fwd_w_lds(C, kHID), st, a);
+    static const int share_pf = getenv("FNO_PFW_SHARE") ? atoi(getenv("FNO_PFW_SHARE")) : 18;      // of 32; 0 / 16 = even (pair_share)
+    const int g = std::min((ncols + NWV - 1) / NWV, 2 * p->ncu);
+    ProjFwdArgs aw = a;
+    aw.share32 = g == 2 * p->ncu ? share_pf : 0;
+    return GT(2), launch("k_proj_fwd", k_proj_fwd_w<C, kHID, NWV>, dim3(g), dim3(NWV * 64), proj_fwd_w_lds(C, kHID), st, aw);
   }
   if (g_gemm_x3 && g_h2 && a.xmax) {
     const size_t lds = (size_t)2 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 2 * 64 * 16 +
@@ -1651,11 +1659,15 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   // the start of the pass (round 3 issued five small ones per step; the forward's memset of all 64 slots is the other one)
   float* amax = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
   float* bwd_b = amax + 59;
+  bool db2_done = false;
   const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && cs.h2_fwd;      // (this buffer's forward published max |u_L|)
   if (h2 && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   if (h2) {
+    // (one output channel: the same launch leaves 256 partial sums of dy = the bias gradient's partial slabs; k_channel_sums
+    // below is then not launched)
+    db2_done = d.Cout == 1;
     LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
-                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, bwd_b + 1));
+                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, bwd_b + 1, db2_done ? w.db2_part : nullptr));
     pb.amax = bwd_b; pb.xmax = amax + 8 + L;
   }
   if (g_gemm_x3 && g_h2 && cs.h2_fwd && use_pbwd_t(C, d.Cout, p->NPX)) {      // the chain of gradient bounds starts here
@@ -1677,8 +1689,8 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   jobs.add(w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C);
   jobs.add(w.db1_part, gr->proj_b1, s.grid * (p->NPX / 32), 1, kHID, kHID, kHID);
   jobs.add(w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID);
-  LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
-  jobs.add(w.db2_part, gr->proj_b2, 64, 1, d.Cout, d.Cout, d.Cout);
+  if (!db2_done) LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
+  jobs.add(w.db2_part, gr->proj_b2, db2_done ? 256 : 64, 1, d.Cout, d.Cout, d.Cout);
   if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, w.ga, w.x1));   // dL/du_L's row spectrum
   }
 

@@ -56,20 +56,40 @@ __device__ unsigned long long g_trace[16 * 256];
 // of the four hot kernels, one record per workgroup -> the clock the chip holds INSIDE the kernel (MI355X_MICROARCH.md, DVFS
 // give-back item 6).  The stamps go to a buffer nothing else reads; no stamp executes in the product build.
 #ifdef FNO_CLOCK
-__device__ unsigned long long g_clk[4 * 1024 * 4];
+__device__ unsigned long long g_clk[4 * 1024 * 8];
+// record: {cycles at loop begin, at loop end, real time (100 MHz) at loop begin, at loop end, at kernel entry, 0, 0, 0}
+#define FNO_CLK_ENTRY() const unsigned long long clk_re_ = __builtin_amdgcn_s_memrealtime()
 #define FNO_CLK_BEGIN() const unsigned long long clk_c0_ = __builtin_amdgcn_s_memtime(), clk_r0_ = __builtin_amdgcn_s_memrealtime()
 #define FNO_CLK_END(id)                                                                              \
   do {                                                                                               \
     const unsigned long long c1_ = __builtin_amdgcn_s_memtime(), r1_ = __builtin_amdgcn_s_memrealtime();  \
     if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                     \
-      unsigned long long* q_ = g_clk + ((id) * 1024 + blockIdx.x) * 4;                                \
-      q_[0] = clk_c0_; q_[1] = c1_; q_[2] = clk_r0_; q_[3] = r1_;                                     \
+      unsigned long long* q_ = g_clk + ((id) * 1024 + blockIdx.x) * 8;                                \
+      q_[0] = clk_c0_; q_[1] = c1_; q_[2] = clk_r0_; q_[3] = r1_; q_[4] = clk_re_;                    \
     }                                                                                                \
   } while (0)
 #else
+#define FNO_CLK_ENTRY() do { } while (0)
 #define FNO_CLK_BEGIN() do { } while (0)
 #define FNO_CLK_END(id) do { } while (0)
 #endif
+
+// Uneven tile shares for kernels that run TWO workgroups per CU (round 4).  The SIMD issues the OLDER wave first, so of the two
+// workgroups that share a CU the one dispatched first (blockIdx < gridDim / 2 under in-order dispatch) runs at almost the
+// speed it would have alone and the second at 0.55-0.6 of it; with equal static shares the first finishes at 65-70 % of the
+// launch and its half of the CU idles (profiles/r04_two_workgroups_per_cu_tail.txt: end times 77 / 91 / 112 / 118 us at the 10 /
+// 50 / 90 / 100 % quantiles of k_blk_fwd_t).  The pair (b, b + G/2) owns the tiles p + (G/2) j and splits the j range
+// share32 : 32 - share32.  Only speed depends on the dispatch order; every tile is owned exactly once whatever it is.
+// Returns first tile, step and end (exclusive, in tile index) of the calling workgroup's loop.
+struct TileShare { int first, step, end; };
+FNO_DEV TileShare pair_share(int ntiles, int share32) {
+  const int G = gridDim.x, b = blockIdx.x;
+  if (share32 <= 0 || (G & 1) || ntiles < 2 * G) return TileShare{b, G, ntiles};
+  const int H = G >> 1, p = b >= H ? b - H : b;
+  const int J = (ntiles - p + H - 1) / H;             // tiles p, p + H, ... of the pair
+  const int J1 = (J * share32 + 16) >> 5;
+  return b < H ? TileShare{p, H, p + H * J1} : TileShare{p + H * J1, H, p + H * J};
+}
 
 // row index inside a 32x32 accumulator tile held by lane-half `half`, register r
 FNO_DEV int acc_row32(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

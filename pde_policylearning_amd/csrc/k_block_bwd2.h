@@ -423,6 +423,7 @@ FNO_DEV void group_barrier(unsigned* cnt, unsigned& epoch, int lane) {
 // GADD: a gradient addend is added to dx (fan-out chains); NJP: 16-output blocks of the row DFT per wave when a row spans both halves
 template <bool LIFT = false, bool GADD = false, int NJP = 1, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
+  FNO_CLK_ENTRY();
   constexpr int C = 64, GPX = 64, KB = C / 16, PITCH = GPX + 4, XPITCH = GPX + 4;
   constexpr int TERM = C * 128;                  // bytes per term plane
   constexpr int IMG = NT3 * TERM;                // one image
@@ -461,69 +462,25 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   after += a.x1g ? 16 * a.NJ * (a.W + 4) : 0;
   unsigned* bar = reinterpret_cast<unsigned*>(after) + grp;
 
-  if (kx) {
-    unsigned* zi = reinterpret_cast<unsigned*>(zimg - grp * 3 * ZT);      // both groups' images: the k pads stay zero
-    for (int i = tid; i < 2 * 3 * ZT / 4; i += 512) zi[i] = 0u;
-    for (int i = tid; i < 3 * TT / 4; i += 512) reinterpret_cast<unsigned*>(timg)[i] = 0u;
-    __syncthreads();
-    for (int i = tid; i < 2 * a.K2in * a.W; i += 512) {
-      const int k = i / a.W, w = i - k * a.W;
-      unsigned short h, m, l;
-      split3(a.tinv[i], h, m, l);
-      unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * 16 + k;
-      d[0] = h; d[TT / 2] = m; d[TT] = l;
-    }
-  } else if (a.zg)
-    for (int i = tid; i < 2 * a.K2in * a.W; i += 512) tinv_s[i] = a.tinv[i];
-  if (a.x1g)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += 512) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
-  if (tid < 2) reinterpret_cast<unsigned*>(after)[tid] = 0u;
-  __syncthreads();
-  unsigned epoch = 0;
-
-  // operand scales of the two-term fp16 GEMMs (powers of two; 1 with three bf16 terms)
-  float sg = 1.f, sa = 1.f, sw = 1.f;
-  if constexpr (NT3 == 2) {
-    float mw = 0.f;
-    for (int i = tid; i < C * C; i += 512) mw = fmaxf(mw, fabsf(a.w[i]));
+  // Every global value the prologue needs is REQUESTED first (weights, bounds, both tables), then the images are cleared and
+  // the values used: the prologue was a chain of dependent L2 round trips behind barriers (9.2 us of a 170-200 us launch,
+  // tools/kernel_clock.py), now it is one.
+  constexpr int NTI = 4;
+  float wraw[KB][8];                 // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
-    __shared__ float red[8];
-    if (lane == 0) red[tid >> 6] = mw;
-    __syncthreads();
-    mw = 0.f;
+  for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) mw = fmaxf(mw, red[k]);
-    sw = h2_scale(mw); sg = h2_scale(*a.gmax_in); sa = h2_scale(*a.umax);
-  }
-  const float inv_gw = 1.f / (sg * sw), inv_ga = 1.f / (sg * sa);
-  float vmax = 0.f;                                     // max |gout| of this thread (a.gmax_out)
-  // B fragments of the dx GEMM: B[k = o][n = i] = W[o][i], lane <-> input channel i, split into terms
-  bf16x8 wfrag[KB][NT3];
+    for (int j = 0; j < 8; ++j) wraw[kb][j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
+  float bg = 0.f, bu = 0.f;
+  if constexpr (NT3 == 2) { bg = *a.gmax_in; bu = *a.umax; }
+  const int nti = a.zg ? 2 * a.K2in * a.W : 0, ntf = a.x1g ? 16 * a.NJ * a.W : 0;
+  float tiv[NTI], tfv[NTI];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + crow];
-    split_n_x8<NT3>(v, sw, wfrag[kb]);
+  for (int k = 0; k < NTI; ++k) {
+    tiv[k] = tid + k * 512 < nti ? a.tinv[tid + k * 512] : 0.f;
+    tfv[k] = tid + k * 512 < ntf ? a.tfwd[tid + k * 512] : 0.f;
   }
   constexpr int NKL = 3;
-  float wl[NKL];
-  if constexpr (LIFT) {
-#pragma unroll
-    for (int s = 0; s < NKL; ++s) {
-      const int k = half + 2 * s;
-      wl[s] = k < a.CL ? a.lw[crow * a.CL + k] : (k == a.CL ? a.lb[crow] : 0.f);
-    }
-  }
-
-  f32x16 dwtot;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) dwtot[r] = 0.0f;
-  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x4 dl = {0.f, 0.f, 0.f, 0.f};                   // lifting gradients: job wg (16 channels)
-  f32x4 dft0[NJP], dft1[NJP];                         // W = 128: row-DFT accumulators of jobs wg (, wg + 4), carried over the halves
-
   float4 gq[4], uq[4];
   const int grow0 = mt * 32 + (lane >> 3);
   float xa[NKL];
@@ -555,7 +512,81 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
     if (h == 0 && gtid < zc4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * zrow_f + 4 * gtid);
   };
   const int tile0 = blockIdx.x * 2 + grp, tstep = 2 * gridDim.x;
-  if (tile0 < a.ntiles) issue(tile0, 0);
+  if (tile0 < a.ntiles) issue(tile0, 0);      // the first tile travels while the tables and fragments are set up
+  auto put_tinv = [&](int i, float v) {
+    const int k = i / a.W, w = i - k * a.W;
+    unsigned short h, m, l;
+    split3(v, h, m, l);
+    unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * 16 + k;
+    d[0] = h; d[TT / 2] = m; d[TT] = l;
+  };
+  if (kx) {
+    unsigned* zi = reinterpret_cast<unsigned*>(zimg - grp * 3 * ZT);      // both groups' images: the k pads stay zero
+    for (int i = tid; i < 2 * 3 * ZT / 4; i += 512) zi[i] = 0u;
+    for (int i = tid; i < 3 * TT / 4; i += 512) reinterpret_cast<unsigned*>(timg)[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NTI; ++k)
+      if (tid + k * 512 < nti) put_tinv(tid + k * 512, tiv[k]);
+    for (int i = tid + NTI * 512; i < nti; i += 512) put_tinv(i, a.tinv[i]);
+  } else if (a.zg) {
+#pragma unroll
+    for (int k = 0; k < NTI; ++k)
+      if (tid + k * 512 < nti) tinv_s[tid + k * 512] = tiv[k];
+    for (int i = tid + NTI * 512; i < nti; i += 512) tinv_s[i] = a.tinv[i];
+  }
+  if (a.x1g) {
+#pragma unroll
+    for (int k = 0; k < NTI; ++k) {
+      const int i = tid + k * 512;
+      if (i < ntf) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = tfv[k];
+    }
+    for (int i = tid + NTI * 512; i < ntf; i += 512) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  }
+  if (tid < 2) reinterpret_cast<unsigned*>(after)[tid] = 0u;
+  // operand scales of the two-term fp16 GEMMs (powers of two; 1 with three bf16 terms)
+  float sg = 1.f, sa = 1.f, sw = 1.f;
+  __shared__ float red[8];
+  if constexpr (NT3 == 2) {
+    // max |W|: the fragments of the workgroup's waves cover every element of W (column crow, all rows over the two halves)
+    float mw = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mw = fmaxf(mw, fabsf(wraw[kb][j]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    if (lane == 0) red[tid >> 6] = mw;
+  }
+  __syncthreads();
+  unsigned epoch = 0;
+  if constexpr (NT3 == 2) {
+    float mw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mw = fmaxf(mw, red[k]);
+    sw = h2_scale(mw); sg = h2_scale(bg); sa = h2_scale(bu);
+  }
+  const float inv_gw = 1.f / (sg * sw), inv_ga = 1.f / (sg * sa);
+  float vmax = 0.f;                                     // max |gout| of this thread (a.gmax_out)
+  bf16x8 wfrag[KB][NT3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) split_n_x8<NT3>(wraw[kb], sw, wfrag[kb]);
+  float wl[NKL];
+  if constexpr (LIFT) {
+#pragma unroll
+    for (int s = 0; s < NKL; ++s) {
+      const int k = half + 2 * s;
+      wl[s] = k < a.CL ? a.lw[crow * a.CL + k] : (k == a.CL ? a.lb[crow] : 0.f);
+    }
+  }
+
+  f32x16 dwtot;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dwtot[r] = 0.0f;
+  float dbsum[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dl = {0.f, 0.f, 0.f, 0.f};                   // lifting gradients: job wg (16 channels)
+  f32x4 dft0[NJP], dft1[NJP];                         // W = 128: row-DFT accumulators of jobs wg (, wg + 4), carried over the halves
+
 #ifndef FNO_G2_STAGGER
 #define FNO_G2_STAGGER 55
 #endif

@@ -54,6 +54,7 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int 
 // (LIFT: of the model input) and the weights by their own maximum; the spectral extension keeps three bf16 terms.
 template <int C, bool LIFT, bool RELU, bool ACT_IN, int EPI, bool ADD, int KZ, int NT3 = 3>
 __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a) {
+  FNO_CLK_ENTRY();
   static_assert(!(LIFT && ACT_IN) && !(ADD && EPI != 0), "variants");
   constexpr int NPX = 128, MT = C / 32, NTG = 2, NTW = 2, NW = MT * NTG, NT = NW * 64, KB = C / 16;
   constexpr int TERM = NPX * C * 2;                      // bytes per term plane of the activation image
@@ -79,78 +80,6 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   const int cg0 = __builtin_amdgcn_readfirstlane(tid / NPX);
   float six, inf;                                        // clamp constants of the packed GELU, kept in SGPRs
   gelu_consts(six, inf);
-
-  // ---- once per workgroup: tables ------------------------------------------------------------------------------------------
-  if constexpr (KZ > 0) {
-    for (int i = tid; i < 3 * (TT + ZT) / 4; i += NT) reinterpret_cast<unsigned*>(timg)[i] = 0u;   // k pads stay zero
-    __syncthreads();
-    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) {
-      const int k = i / a.W, w = i - k * a.W;
-      unsigned short h, m, l;
-      split3(a.tinv[i], h, m, l);
-      unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * KZ * 16 + k;
-      d[0] = h; d[TT / 2] = m; d[TT] = l;
-    }
-  }
-  if constexpr (EPI != 0)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
-
-  // B fragments of the transposed GEMM: B[k = c][n = o] = W[o][c], lane <-> output channel o, split into (h, m, l)
-  const int orow = mt * 32 + l31;
-  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
-  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
-  // operand scales of the two-term fp16 GEMM (powers of two; 1 with three bf16 terms)
-  float sx = 1.f, sw = 1.f;
-  if constexpr (NT3 == 2) {
-    __shared__ float red[NW];
-    auto wg_max = [&](float m) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      __syncthreads();
-      if (lane == 0) red[wave] = m;
-      __syncthreads();
-      float r = 0.f;
-#pragma unroll
-      for (int k = 0; k < NW; ++k) r = fmaxf(r, red[k]);
-      return r;
-    };
-    float mw = 0.f;
-    for (int i = tid; i < C * C; i += NT) mw = fmaxf(mw, fabsf(a.w[i]));
-    sw = h2_scale(wg_max(mw));
-    float bx = *a.xmax;                                    // |x| <= bx; |gelu(x)| <= |x|
-    if constexpr (LIFT) {                                  // |u_0[c]| <= sum_k |lw[c][k]| bx + |lb[c]|
-      float m = 0.f;
-      for (int c = tid; c < C; c += NT) {
-        const float4 wv = ld4(lws + 4 * c);                // (staged above; the first wg_max barrier made it visible)
-        m = fmaxf(m, (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(wv.w)) * bx + fabsf(lws[4 * C + c]));
-      }
-      (void)wg_max(0.f);
-      bx = wg_max(m);
-      if (a.ubound && blockIdx.x == 0 && tid == 0) *a.ubound = bx;      // (the same value in every workgroup) for the backward pass
-    }
-    sx = h2_scale(bx);
-  }
-  const float inv_xw = 1.f / (sx * sw);
-  bf16x8 wfrag[KB][NT3];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.w[orow * C + kb * 16 + 8 * half + j];
-    split_n_x8<NT3>(v, sw, wfrag[kb]);
-  }
-  // With a row-DFT epilogue (EPI != 0) the accumulators are TRANSPOSED (lane <-> channel, registers <-> 4-pixel runs: one bias
-  // register, 16-byte LDS writes of the tile).  Without one the only consumer is the store, and the plain orientation
-  // (lane <-> pixel, registers <-> channel rows) leaves as whole 128-byte lines per wave half: 118 vs 127 us at config-2 size.
-  constexpr bool TR = EPI != 0;
-  const float bias_o = a.bias ? a.bias[orow] : 0.f;
-  float bias_r[TR ? 1 : 16];
-  if constexpr (!TR) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)] : 0.f;
-  }
-
-  __syncthreads();
 
   const int zc4 = KZ > 0 ? R * a.K2in * C / 2 : 0;          // float4 pieces of one tile's spectral rows
   const unsigned PWb = (unsigned)a.PW * 4u;              // bytes per channel row
@@ -179,6 +108,109 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     for (int k = 0; k < ZP; ++k)
       if (tid + k * NT < zc4) zpf[k] = ld4(a.z + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * (tid + k * NT));
   };
+  const TileShare ts = pair_share(a.ntiles, a.share32);
+  if (ts.first < ts.end) issue(ts.first);      // the first tile travels while the tables and fragments are set up
+
+  // ---- once per workgroup: tables, weight fragments --------------------------------------------------------------------------
+  // Every global value the prologue needs is REQUESTED first, then the images are cleared and the values are used: the
+  // prologue was a chain of five dependent L2 round trips (table, forward table, weight scan, bound, weight fragments,
+  // each behind a barrier: 10.8 us of a 120-150 us launch, tools/kernel_clock.py), now it is one.
+  const int orow = mt * 32 + l31;
+  constexpr int NTI = 8;                                   // table values per thread held in registers (more: a second pass)
+  float tiv[KZ > 0 ? NTI : 1], tfv[EPI != 0 ? NTI : 1];
+  float wraw[KB][8];                                       // B fragments of the transposed GEMM: B[k = c][n = o] = W[o][c]
+  float bx = 0.f;
+  if constexpr (NT3 == 2) bx = *a.xmax;                    // |x| <= bx; |gelu(x)| <= |x|
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wraw[kb][j] = a.w[orow * C + kb * 16 + 8 * half + j];
+  const int nti = KZ > 0 ? 2 * a.K2in * a.W : 0, ntf = EPI != 0 ? 16 * a.NJ * a.W : 0;
+  if constexpr (KZ > 0) {
+#pragma unroll
+    for (int k = 0; k < NTI; ++k) tiv[k] = tid + k * NT < nti ? a.tinv[tid + k * NT] : 0.f;
+  }
+  if constexpr (EPI != 0) {
+#pragma unroll
+    for (int k = 0; k < NTI; ++k) tfv[k] = tid + k * NT < ntf ? a.tfwd[tid + k * NT] : 0.f;
+  }
+  auto put_tinv = [&](int i, float v) {
+    const int k = i / a.W, w = i - k * a.W;
+    unsigned short h, m, l;
+    split3(v, h, m, l);
+    unsigned short* d = reinterpret_cast<unsigned short*>(timg) + w * KZ * 16 + k;
+    d[0] = h; d[TT / 2] = m; d[TT] = l;
+  };
+  if constexpr (KZ > 0) {
+    for (int i = tid; i < 3 * (TT + ZT) / 4; i += NT) reinterpret_cast<unsigned*>(timg)[i] = 0u;   // k pads stay zero
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NTI; ++k)
+      if (tid + k * NT < nti) put_tinv(tid + k * NT, tiv[k]);
+    for (int i = tid + NTI * NT; i < nti; i += NT) put_tinv(i, a.tinv[i]);
+  }
+  if constexpr (EPI != 0) {
+#pragma unroll
+    for (int k = 0; k < NTI; ++k) {
+      const int i = tid + k * NT;
+      if (i < ntf) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = tfv[k];
+    }
+    for (int i = tid + NTI * NT; i < ntf; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
+  }
+
+  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
+  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
+  // operand scales of the two-term fp16 GEMM (powers of two; 1 with three bf16 terms)
+  float sx = 1.f, sw = 1.f;
+  if constexpr (NT3 == 2) {
+    __shared__ float red[NW];
+    auto wg_max = [&](float m) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      __syncthreads();
+      if (lane == 0) red[wave] = m;
+      __syncthreads();
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) r = fmaxf(r, red[k]);
+      return r;
+    };
+    // max |W|: the fragments of the workgroup's waves cover every element of W (row orow, all columns over the two halves)
+    float mw = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mw = fmaxf(mw, fabsf(wraw[kb][j]));
+    sw = h2_scale(wg_max(mw));
+    if constexpr (LIFT) {                                  // |u_0[c]| <= sum_k |lw[c][k]| bx + |lb[c]|
+      float m = 0.f;
+      for (int c = tid; c < C; c += NT) {
+        const float4 wv = ld4(lws + 4 * c);                // (staged above; the first wg_max barrier made it visible)
+        m = fmaxf(m, (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(wv.w)) * bx + fabsf(lws[4 * C + c]));
+      }
+      (void)wg_max(0.f);
+      bx = wg_max(m);
+      if (a.ubound && blockIdx.x == 0 && tid == 0) *a.ubound = bx;      // (the same value in every workgroup) for the backward pass
+    }
+    sx = h2_scale(bx);
+  }
+  const float inv_xw = 1.f / (sx * sw);
+  bf16x8 wfrag[KB][NT3];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) split_n_x8<NT3>(wraw[kb], sw, wfrag[kb]);
+  // With a row-DFT epilogue (EPI != 0) the accumulators are TRANSPOSED (lane <-> channel, registers <-> 4-pixel runs: one bias
+  // register, 16-byte LDS writes of the tile).  Without one the only consumer is the store, and the plain orientation
+  // (lane <-> pixel, registers <-> channel rows) leaves as whole 128-byte lines per wave half: 118 vs 127 us at config-2 size.
+  constexpr bool TR = EPI != 0;
+  const float bias_o = a.bias ? a.bias[orow] : 0.f;
+  float bias_r[TR ? 1 : 16];
+  if constexpr (!TR) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[mt * 32 + 4 * half + (r & 3) + 8 * (r >> 2)] : 0.f;
+  }
+
+  __syncthreads();
+
   // one float4 of spectral rows = (o, re), (o, im), (o + 1, re), (o + 1, im) of row-mode rs -> k = 2 s, 2 s + 1 of two channels
   auto put_z = [&](int f, const float4& zq) {
     const int rs = (4 * f) / (2 * C), o = ((4 * f) % (2 * C)) >> 1;
@@ -194,7 +226,6 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     *reinterpret_cast<unsigned*>(d + 2 * ZT) = l[0] | ((unsigned)l[1] << 16);
     *reinterpret_cast<unsigned*>(d + 2 * ZT + KZ * 32) = l[2] | ((unsigned)l[3] << 16);
   };
-  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
 
   // per-lane offsets that do not change from tile to tile
   // output / addend: row orow (the descriptor starts at row mt * 32), pixels ng * 64 + 4 half ..; the (q, g) part of the
@@ -212,7 +243,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(true);
   FNO_CLK_BEGIN();
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (int tile = ts.first; tile < ts.end; tile += ts.step) {
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
@@ -381,7 +412,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     }
     // the next tile's loads go out behind the GEMM (their 32 registers must not be live beside the weight fragments, the
     // accumulators and the fragment double buffer); epilogue, row DFT and the other workgroup's phases cover their latency
-    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    if (tile + ts.step < ts.end) issue(tile + ts.step);
     FNO_STAMP(tslot + 3);
     __syncthreads();        // every wave is done with the images (the fp32 output tile reuses them)
     FNO_STAMP(tslot + 4);

@@ -53,6 +53,8 @@ struct PwFwdArgs {
   float* ubound;      // k_blk_fwd_t<LIFT, NT3 = 2>: the bound of |u_0| it derived from xmax and the lifting parameters is left here
   float* umax;        // if set: max |u| of what this launch stores is published here (atomic max of the float pattern; the
                       // two-term fp16 GEMMs of the consumer scale their operand by it: fno_dev.h, "h2")
+  int share32 = 0;    // k_blk_fwd_t with two workgroups per CU: 32nds of a CU's tiles that go to the workgroup dispatched FIRST
+                      // (0 = even split; pair_share() in fno_dev.h)
 };
 
 // dynamic LDS bytes needed by k_pw_fwd<CIN, COUT, NPX>

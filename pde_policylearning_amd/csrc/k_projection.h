@@ -21,6 +21,7 @@ struct ProjFwdArgs {
   float* y;          // (B, CO, PW)
   int PW, CO, act_in, tiles_per_plane, ntiles;
   const float* xmax; // k_proj_fwd_h2: device scalar, a bound of |x| (published by the kernel that stored x)
+  int share32 = 0;   // k_proj_fwd_w: 32nds of a CU's columns for the workgroup dispatched first (0 = even; pair_share, fno_dev.h)
 };
 
 constexpr int PROJ_MAXCO = 4;   // largest supported projection output width

@@ -47,14 +47,16 @@ __global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __rest
 }
 // max |x| of three arrays in one launch -> dst[0..2] (atomic max of the float pattern; zeroed by the caller): blocks
 // [0, g0) scan x0, [g0, g0 + g1) x1, the rest x2
+// sum0 (or null): the blocks of job 0 also leave the SUM of their share of x0 in sum0[block] (g0 partial sums, fixed order:
+// the bias gradient of a one-channel projection is the sum of dy, and this launch reads dy anyway)
 __global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
-                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst) {
+                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst, float* __restrict__ sum0) {
   const int bi = blockIdx.x;
   const int job = bi < g0 ? 0 : (bi < g0 + g1 ? 1 : 2);
   const float* x = job == 0 ? x0 : (job == 1 ? x1 : x2);
   const size_t n = job == 0 ? n0 : (job == 1 ? n1 : n2);
   const int b0 = job == 0 ? 0 : (job == 1 ? g0 : g0 + g1), nb = job == 0 ? g0 : (job == 1 ? g1 : (int)gridDim.x - g0 - g1);
-  float m = 0.f;
+  float m = 0.f, sm = 0.f;
   if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // 16-byte loads, four in flight per thread (the scalar
     const size_t n4 = n / 4, stride = (size_t)nb * blockDim.x;             // loop was 16 dependent 4-byte loads: 21 us per launch)
     size_t i = (size_t)(bi - b0) * blockDim.x + threadIdx.x;
@@ -64,20 +66,27 @@ __global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const
                          fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
       m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
                          fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+      sm += (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
     }
     for (; i < n4; i += stride) {
       const float4 a = ld4(x + 4 * i);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      sm += (a.x + a.y) + (a.z + a.w);
     }
   } else {
-    for (size_t i = (size_t)(bi - b0) * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    for (size_t i = (size_t)(bi - b0) * blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) { m = fmaxf(m, fabsf(x[i])); sm += x[i]; }
   }
   // one publish per workgroup (same-address atomics serialise)
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  __shared__ float wm[16];
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  for (int o = 32; o >= 1; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); sm += __shfl_xor(sm, o, 64); }
+  __shared__ float wm[16], ws[16];
+  if ((threadIdx.x & 63) == 0) { wm[threadIdx.x >> 6] = m; ws[threadIdx.x >> 6] = sm; }
   __syncthreads();
+  if (sum0 && job == 0 && threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += ws[k];
+    sum0[bi - b0] = t;
+  }
   if (threadIdx.x < 64) {
     const int nw = (int)(blockDim.x >> 6);
     float r = threadIdx.x < nw ? wm[threadIdx.x] : 0.f;
@@ -92,6 +101,7 @@ __global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const
 // scaled by powers of two from a.amax = {max |x|, max |dy|, max |W1|, max |w2|} (device scalars)
 template <int C, int HID, bool RELU = false, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
+  FNO_CLK_ENTRY();
   constexpr int NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32, XI = C / 16;
   static_assert(C == 32 || C == 64, "32 or 64 channels");
   constexpr int NCH = HID / 64, CPW = NCH / 2;

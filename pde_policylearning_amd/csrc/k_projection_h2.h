@@ -63,6 +63,7 @@ FNO_DEV float wg_absmax(const float* __restrict__ w, int n, float* scratch, int 
 // k_proj_fwd_x3 with two fp16 terms.  a.xmax: device scalar, a bound of |x| (required)
 template <int C, int HID, int NPX, int NCO, bool RELU = false>
 __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
+  FNO_CLK_ENTRY();
   constexpr int NTN = NPX / 32;
   constexpr int NW = 2 * NTN;
   constexpr int NT = NW * 64;
@@ -233,12 +234,14 @@ __device__ unsigned long long g_pfw_trace[64 * 16 * 4];
 // 1.9-2.0 GHz inside this kernel where the 8-wave kernels hold 2.3-2.4 (denser issue, MI355X_MICROARCH.md DVFS item 4).
 template <int C, int HID, int NWAVE>
 __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArgs a) {
+  FNO_CLK_ENTRY();
   constexpr int KB = C / 16, NCHK = HID / 32, NT = NWAVE * 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned short* w1b = reinterpret_cast<unsigned short*>(smem);          // [HID/32][KB][2 terms][64 lanes][8 halfs]
   float* b1s = reinterpret_cast<float*>(w1b + (size_t)NCHK * KB * 2 * 64 * 8);
   float* w2s = b1s + HID;
   float* scratch = w2s + HID;                                              // NWAVE floats
+  int* colq = reinterpret_cast<int*>(scratch + 16);                        // the workgroup's column counter
   float gk_six, gk_inf;
   gelu_consts(gk_six, gk_inf);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -249,23 +252,48 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
 #ifdef PFW_TRACE
   const unsigned long long tr_k0 = __builtin_readcyclecounter();
 #endif
-  const float sx = h2_scale(*a.xmax);
-  const float sw = h2_scale(wg_absmax<NT>(a.w1, HID * C, scratch, tid));
+  // ONE pass over W1: a thread fetches its fragment items (hidden 32-block, k block, lane: eight consecutive channels of one
+  // row), the workgroup maximum of |W1| comes from the same registers (the items cover W1 exactly once), then they are split.
+  // (Was a scan followed by a second, dependent read of the same 64 KB: 21 k cycles of prologue per workgroup.)
+  constexpr int NIT = (NCHK * KB * 64 + NT - 1) / NT;
+  const float bxv = *a.xmax;
+  float wv[NIT][8];
+  float mw = 0.f;
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int it = tid + q * NT;
+    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wv[q][j] = it < NCHK * KB * 64 ? a.w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j] : 0.f;
+      mw = fmaxf(mw, fabsf(wv[q][j]));
+    }
+  }
+  for (int i = tid; i < HID; i += NT) { b1s[i] = a.b1[i]; w2s[i] = a.w2[i]; }
+  if (tid == 0) *colq = 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+  if (lane == 0) scratch[wave] = mw;
+  __syncthreads();
+  mw = 0.f;
+#pragma unroll
+  for (int k = 0; k < NWAVE; ++k) mw = fmaxf(mw, scratch[k]);
+  const float sx = h2_scale(bxv), sw = h2_scale(mw);
 #ifdef PFW_TRACE
   const unsigned long long tr_k1 = __builtin_readcyclecounter();
 #endif
   const float inv = 1.0f / (sx * sw);
-  for (int i = tid; i < HID; i += NT) { b1s[i] = a.b1[i]; w2s[i] = a.w2[i]; }
-  for (int it = tid; it < NCHK * KB * 64; it += NT) {      // item = (hidden 32-block, k block, lane)
-    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
-    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
-    f16x8 h, l;
-    split2x8(v, sw, h, l);
-    unsigned short* dst = w1b + ((size_t)((mt * KB + kb) * 2) * 64 + ln) * 8;
-    *reinterpret_cast<f16x8*>(dst) = h;
-    *reinterpret_cast<f16x8*>(dst + 64 * 8) = l;
+  for (int q = 0; q < NIT; ++q) {
+    const int it = tid + q * NT;
+    if (it < NCHK * KB * 64) {
+      const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
+      f16x8 h, l;
+      split2x8(wv[q], sw, h, l);
+      unsigned short* dst = w1b + ((size_t)((mt * KB + kb) * 2) * 64 + ln) * 8;
+      *reinterpret_cast<f16x8*>(dst) = h;
+      *reinterpret_cast<f16x8*>(dst + 64 * 8) = l;
+    }
   }
   __syncthreads();
 
@@ -280,10 +308,20 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
 #define PFW_STAMP(acc) do { } while (0)
 #endif
   const int voff = (8 * half * a.PW + l31) * 4;
-  // Static shares; the issue priority alternates from column to column, in opposite phase for the two workgroups of a CU
-  // (blockIdx.x < / >= gridDim.x / 2 under round-robin dispatch), so that neither starves the other (priority outranks age).
+  // A workgroup owns a static share of the columns (pair_share: the one dispatched first on its CU the larger one) and its
+  // waves POP them from a counter in LDS: the waves of a SIMD are served oldest first, so with one static share per wave the
+  // youngest wave of the launch finished its 5-6 columns 35 us after the median one (kernel 192 us, wave 0 of the workgroups
+  // done at 103 / 125 / 158 us at the 10 / 50 / 100 % quantiles; profiles/r04_two_workgroups_per_cu_tail.txt).  The issue
+  // priority alternates from column to column, in opposite phase for the two workgroups of a CU.
+  const TileShare ts = pair_share(ncols, a.share32);
+  const int nmine = ts.first < ts.end ? (ts.end - ts.first + ts.step - 1) / ts.step : 0;
   int kcol = (2 * (int)blockIdx.x >= (int)gridDim.x) ? 1 : 0;
-  for (int col = blockIdx.x * NWAVE + wave; col < ncols; col += gridDim.x * NWAVE, ++kcol) {
+  for (;; ++kcol) {
+    int jq = 0;
+    if (lane == 0) jq = __hip_atomic_fetch_add(colq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    jq = __builtin_amdgcn_readfirstlane(jq);
+    if (jq >= nmine) break;
+    const int col = ts.first + ts.step * jq;
     if (kcol & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     const int b = col / cols_per_plane;
     const int px0 = (col - b * cols_per_plane) * 32;

@@ -30,11 +30,20 @@ while time.time() - t0 < 3.0:
     torch.cuda.synchronize()
     n += 50
 L = _lib.lib()
+# whole-launch durations (HIP events on the launch stream) of the same process, for the time OUTSIDE the stamped section
+L.fno_profile_reset()
+L.fno_profile_enable(1)
+for _ in range(5):
+    train_step(model, bucket, opt, inputs, tgt, loss_fn)
+torch.cuda.synchronize()
+L.fno_profile_enable(0)
+launch_ms = {name: ms / max(cnt, 1) for name, ms, cnt in _lib.profile_summary()}
 L.fno_debug_clock_dump.argtypes = [C.c_void_p, C.c_size_t]
-N = 4 * 1024 * 4
+N = 4 * 1024 * 8
 buf = (C.c_ulonglong * N)()
 assert L.fno_debug_clock_dump(buf, N) == 0
-a = np.frombuffer(buf, np.uint64).reshape(4, 1024, 4).astype(np.float64)
+a = np.frombuffer(buf, np.uint64).reshape(4, 1024, 8).astype(np.float64)
+print("per-launch times by HIP events:", {k: round(v * 1e3, 1) for k, v in launch_ms.items() if v > 0.05})
 print(f"{n} steps in {time.time() - t0:.2f} s; in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the tile loop, last launch of each kernel")
 for kid, name in enumerate(("k_blk_fwd_t (block forward)", "k_block_bwd_g2 (block backward)", "k_proj_fwd_h2 (projection forward)",
                             "k_proj_bwd_t (projection backward)")):
@@ -50,6 +59,10 @@ for kid, name in enumerate(("k_blk_fwd_t (block forward)", "k_block_bwd_g2 (bloc
     print(f"   {name:38s} workgroups {int(ok.sum()):4d}   clock median {np.median(ghz):.3f} GHz  (min {ghz.min():.3f}, max {ghz.max():.3f})"
           f"   stamped-section time median {np.median(us):.1f} us; first start to last end {span:.1f} us; "
           f"workgroups starting > 5 us after the first: {int((late > 5).sum())}")
+    entry = r[ok, 4]
+    print(f"      kernel entry -> stamped section: median {np.median(r[ok, 2] - entry) / 100.0:.1f} us (max {(r[ok, 2] - entry).max() / 100.0:.1f}); "
+          f"first entry to last end {(r[ok, 3].max() - entry.min()) / 100.0:.1f} us; entries spread over {(entry.max() - entry.min()) / 100.0:.1f} us; "
+          f"end-time quantiles from the first entry [10, 50, 90, 100] %: " + " ".join(f"{np.percentile(r[ok, 3] - entry.min(), q) / 100.0:.1f}" for q in (10, 50, 90, 100)))
 
     if kid == 2:
         d = (r[ok, 3] - r[ok, 2]) / 100.0
