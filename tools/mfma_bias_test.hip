@@ -18,6 +18,8 @@ __device__ inline void split3(float x, unsigned short& h, unsigned short& m, uns
   l = f2bf(r);
 }
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define MH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 __global__ void k_probe(float* out) {
   const int lane = threadIdx.x;
@@ -48,9 +50,38 @@ __global__ void k_gemm(const float* A, const float* B, float* C, int K) {
   const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
   f32x16 acc, acs;
   for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acs[i] = 0.f; }
+  // VAR 4: VAR 1 on (-A, B), result negated (does the bias follow the SIGN of what is accumulated?)
+  // VAR 5: VAR 1 with the sign of A alternating from tile to tile (what a kernel could do per pixel tile)
+  // VAR 6 / 7: two fp16 terms, three products, hh and cross terms in separate accumulators (fno_dev.h "h2"); 7 = on (-A, B)
+  const float sgn = (VAR == 4 || VAR == 7) ? -1.f : (VAR == 5 && (blockIdx.x & 1)) ? -1.f : 1.f;
   if (VAR == 2) {
     for (int s = 0; s < K / 2; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * K + 2 * s + hh], B[(2 * s + hh) * 32 + r], acc, 0, 0, 0);
+  } else if (VAR == 6 || VAR == 7) {
+    for (int kb = 0; kb < K / 16; ++kb) {
+      f16x8 ah, al, bh, bl;
+      for (int j = 0; j < 8; ++j) {
+        const int k = kb * 16 + 8 * hh + j;
+        const float av = sgn * A[r * K + k], bv = B[k * 32 + r];
+        ah[j] = (_Float16)av; al[j] = (_Float16)(av - (float)ah[j]);
+        bh[j] = (_Float16)bv; bl[j] = (_Float16)(bv - (float)bh[j]);
+      }
+      acc = MH(ah, bh, acc); acs = MH(ah, bl, acs); acs = MH(al, bh, acs);
+    }
+    for (int i = 0; i < 16; ++i) acc[i] = sgn * (acc[i] + acs[i]);
+  } else if (VAR == 4 || VAR == 5) {
+    for (int kb = 0; kb < K / 16; ++kb) {
+      bf16x8 a[3], b[3];
+      for (int j = 0; j < 8; ++j) {
+        const int k = kb * 16 + 8 * hh + j;
+        unsigned short h, m, l;
+        split3(sgn * A[r * K + k], h, m, l); a[0][j] = h; a[1][j] = m; a[2][j] = l;
+        split3(B[k * 32 + r], h, m, l); b[0][j] = h; b[1][j] = m; b[2][j] = l;
+      }
+      acs = MF(a[2], b[0], acs); acs = MF(a[0], b[2], acs); acs = MF(a[1], b[1], acs);
+      acs = MF(a[1], b[0], acs); acs = MF(a[0], b[1], acs); acc = MF(a[0], b[0], acc);
+    }
+    for (int i = 0; i < 16; ++i) acc[i] = sgn * (acc[i] + acs[i]);
   } else {
     for (int kb = 0; kb < K / 16; ++kb) {
       bf16x8 a[3], b[3];
@@ -103,15 +134,21 @@ int main() {
       ref[(size_t)t * 1024 + i * 32 + j] = s;
     }
     std::vector<float> C((size_t)T * 1024);
-    for (int var = 0; var < 3; ++var) {
+    const char* vn[8] = {"x3 one accumulator", "x3 small terms separate", "fp32 MFMA", "", "x3 separate on (-A, B)", "x3 separate, sign by tile",
+                         "h2 (two fp16 terms)", "h2 on (-A, B)"};
+    for (int var : {0, 1, 2, 4, 5, 6, 7}) {
       if (var == 0) hipLaunchKernelGGL(k_gemm<0>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
       if (var == 1) hipLaunchKernelGGL(k_gemm<1>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
       if (var == 2) hipLaunchKernelGGL(k_gemm<2>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 4) hipLaunchKernelGGL(k_gemm<4>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 5) hipLaunchKernelGGL(k_gemm<5>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 6) hipLaunchKernelGGL(k_gemm<6>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
+      if (var == 7) hipLaunchKernelGGL(k_gemm<7>, dim3(T), dim3(64), 0, 0, dA, dB, dC, K);
       hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
       double se = 0, se2 = 0, sr2 = 0, sabs = 0, sref = 0;
       for (size_t i = 0; i < C.size(); ++i) { const double e = C[i] - ref[i]; se += e; se2 += e * e; sr2 += ref[i] * ref[i]; sabs += fabs(ref[i]); sref += ref[i]; }
       printf("K=%3d dist=%d %-26s rel-L2 %.3e   sum(err)/sum|ref| %+.3e   sum(err)/|sum(ref)| %+.3e\n", K, dist,
-             var == 0 ? "x3 one accumulator" : var == 1 ? "x3 small terms separate" : "fp32 MFMA", sqrt(se2 / sr2), se / sabs, se / fabs(sref));
+             vn[var], sqrt(se2 / sr2), se / sabs, se / fabs(sref));
     }
     hipFree(dA); hipFree(dB); hipFree(dC);
   }

@@ -22,18 +22,26 @@ if os.path.exists(cache):
     g64 = {k[4:]: z[k] for k in z.files if k.startswith("g64:")}
     g32 = {k[4:]: z[k] for k in z.files if k.startswith("g32:")}
     y64 = z["y64"]
+    y32 = z["y32"]
 else:
     fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
     y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 8)
-    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
-    np.savez(cache, y64=y64, **{"g64:" + k: v for k, v in g64.items()}, **{"g32:" + k: v for k, v in g32.items()})
+    y32, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
+    np.savez(cache, y64=y64, y32=y32, **{"g64:" + k: v for k, v in g64.items()}, **{"g32:" + k: v for k, v in g32.items()})
 dev = torch.device("cuda:0")
 model = model.to(dev)
 for rep in range(2):
     model.zero_grad(set_to_none=True)
     y = model(x.to(dev))
     O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
-    print("run", rep, "y", rel_l2(y.detach().cpu().numpy().reshape(y64.shape), y64), flush=True)
+    ye = y.detach().cpu().numpy().reshape(y64.shape).astype(np.float64)
+    y3 = np.asarray(y32).reshape(y64.shape).astype(np.float64)
+    print("run", rep, "y", rel_l2(ye, y64), "(torch f32", rel_l2(y3, y64), ")", flush=True)
+    # coherent parts of the output error: its mean, and its component along |y| (a shrink / growth of magnitudes)
+    for nm, v in (("engine", ye), ("torch f32", y3)):
+        e = v - y64
+        print(f"   {nm:10s} mean(err) / mean|y| {e.mean() / np.abs(y64).mean():+.2e}   <err, y> / <y, y> {float((e * y64).sum() / (y64 * y64).sum()):+.2e}"
+              f"   <err, sign y> / sum|y| {float((e * np.sign(y64)).sum() / np.abs(y64).sum()):+.2e}   rms(err) / rms(y) {np.sqrt((e * e).mean() / (y64 * y64).mean()):.2e}")
     for name, prm in model.named_parameters():
         got = prm.grad
         got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
