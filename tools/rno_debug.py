@@ -32,8 +32,19 @@ dev = torch.device("cuda:0")
 model = model.to(dev)
 for rep in range(2):
     model.zero_grad(set_to_none=True)
+    # RNO_FLIP=1: forward on the split-precision GEMMs, backward on the fp32 MFMA kernels; 2: the other way round
+    # (fno_set_gemm_mode is read at launch time; which half of the pass owns an error?)
+    flip = int(os.environ.get("RNO_FLIP", "0"))
+    from pde_policylearning_amd import _lib as _L
+    if flip:
+        _L.lib().fno_set_gemm_mode(1 if flip == 1 else 0)
     y = model(x.to(dev))
-    O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
+    loss = O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape))
+    if flip:
+        torch.cuda.synchronize()
+        _L.lib().fno_set_gemm_mode(0 if flip == 1 else 1)
+    loss.backward()
+    torch.cuda.synchronize()
     ye = y.detach().cpu().numpy().reshape(y64.shape).astype(np.float64)
     y3 = np.asarray(y32).reshape(y64.shape).astype(np.float64)
     print("run", rep, "y", rel_l2(ye, y64), "(torch f32", rel_l2(y3, y64), ")", flush=True)
