@@ -30,6 +30,23 @@ else:
     np.savez(cache, y64=y64, y32=y32, **{"g64:" + k: v for k, v in g64.items()}, **{"g32:" + k: v for k, v in g32.items()})
 dev = torch.device("cuda:0")
 model = model.to(dev)
+# RNO_F32_FWD=fourier_fanout,fno_block_tail,...: these engine calls run their FORWARD on the fp32-MFMA kernels (the backward
+# stays on the split-precision ones): which layer family's forward owns an error?
+from pde_policylearning_amd import functional as _F, _lib as _L0
+for _name in [n for n in os.environ.get("RNO_F32_FWD", "").split(",") if n]:
+    def _wrap(fn):
+        def inner(*a, **k):
+            _L0.lib().fno_set_gemm_mode(0)
+            try:
+                return fn(*a, **k)
+            finally:
+                _L0.lib().fno_set_gemm_mode(1)
+        return inner
+    setattr(_F, _name, _wrap(getattr(_F, _name)))
+# RNO_UNSUPPORT=block_tail_supported,projection_supported: these predicates answer False (the model then takes its
+# less fused composition for that part, still in the split-precision mode)
+for _name in [n for n in os.environ.get("RNO_UNSUPPORT", "").split(",") if n]:
+    setattr(_F, _name, lambda *a, **k: False)
 for rep in range(2):
     model.zero_grad(set_to_none=True)
     # RNO_FLIP=1: forward on the split-precision GEMMs, backward on the fp32 MFMA kernels; 2: the other way round
