@@ -18,6 +18,11 @@ from tests.util import rel_l2
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# An ill-conditioned gradient is allowed BUDGET_SLACK x the float32 oracle's own distance from float64.  Why 2 and not 1.25:
+# at RNO2d's full size the distance of EITHER float32 evaluation is set by a handful of ReLU decisions of the regressor within
+# rounding of a tie, upstream of every tensor; over four data sets and two engine compositions the engine / torch ratio is
+# 0.1 - 2.1 with all tensors of a run moving together (profiles/r04_rno_gradient_error_by_seed.txt, DESIGN.md section 4e:
+# every kernel switch, fp32 forward per layer family, mask-decision counts against float64 - no kernel owns the factor).
 BUDGET_SLACK = 2.0
 
 

@@ -14,9 +14,10 @@ from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
 torch.manual_seed(0)
 model = RNO2dObserver(12, 12, 64, 0, layer_num=1).eval()
 params = {k: v.detach().clone() for k, v in model.state_dict().items()}
-x = torch.from_numpy(fill_named("c3full.x", (32, 1, 128, 128, 1), 1.0))
-tgt = torch.from_numpy(fill_named("c3full.t", (32, 128, 128, 1), 1.0))
-cache = "/tmp/rno_dbg.npz"
+seed = os.environ.get("RNO_SEED", "")      # another deterministic data set (the oracle cache is per seed)
+x = torch.from_numpy(fill_named("c3full.x" + seed, (32, 1, 128, 128, 1), 1.0))
+tgt = torch.from_numpy(fill_named("c3full.t" + seed, (32, 128, 128, 1), 1.0))
+cache = f"/tmp/rno_dbg{seed}.npz"
 if os.path.exists(cache):
     z = np.load(cache)
     g64 = {k[4:]: z[k] for k in z.files if k.startswith("g64:")}
