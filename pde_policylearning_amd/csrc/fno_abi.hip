@@ -637,7 +637,7 @@ struct JobList {
   }
   int run(hipStream_t st) {
     if (jobs.count == 0) return FNO_OK;
-    return launch("k_reduce_jobs", k_reduce_jobs, dim3(256, jobs.count), dim3(16, 64), 0, st, jobs);
+    return launch("k_reduce_jobs", k_reduce_jobs<64>, dim3(256, jobs.count), dim3(16, 64), 0, st, jobs);
   }
 };
 

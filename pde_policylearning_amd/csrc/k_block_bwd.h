@@ -672,10 +672,13 @@ __global__ void __launch_bounds__(1024) k_reduce_slabs(const float* __restrict__
 // All slab reductions of one backward pass in ONE launch: blockIdx.y selects the job.
 struct ReduceJob { const float* part; float* out; int nslab, n, ld_out, ncols, ld_in; };
 struct ReduceJobs { ReduceJob j[24]; int count; };
-__global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
-  // block (16, 64): 16 column groups x 64 slab lanes.  Many small workgroups (a 64x64 weight gradient
+// NSY slab lanes per column group: 64 (1024 threads, 4 slab loads per thread, a 6-step tree).  16 (256 threads, 16 loads per
+// thread, a 4-step tree) was measured in round 4 and is SLOWER: 28 vs 19.5 us at BASELINE config 2, 43 vs 23 us at config 4.
+template <int NSY>
+__global__ void __launch_bounds__(16 * NSY) k_reduce_jobs(ReduceJobs jobs) {
+  // block (16, NSY): 16 column groups x NSY slab lanes.  Many small workgroups (a 64x64 weight gradient
   // alone gives 64 of them) keep every CU loading; each thread has <= 8 independent 16-B loads in flight.
-  __shared__ float4 sh[64][17];
+  __shared__ float4 sh[NSY][17];
   const ReduceJob jb = jobs.j[blockIdx.y];
   const int tx = threadIdx.x, sy = threadIdx.y;
   const size_t slab = (size_t)(jb.n / jb.ncols) * jb.ld_in;
@@ -687,15 +690,15 @@ __global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
       if (g < ng) {
         const float* p = jb.part + (size_t)row * jb.ld_in + col;
-#pragma unroll 4
-        for (int k = sy; k < jb.nslab; k += 64) {
+#pragma unroll 8
+        for (int k = sy; k < jb.nslab; k += NSY) {
           const float4 v = ld4(p + k * slab);
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
       }
       sh[sy][tx] = s;
       __syncthreads();
-      for (int off = 32; off > 0; off >>= 1) {       // fixed-order tree over the 64 slab lanes
+      for (int off = NSY / 2; off > 0; off >>= 1) {       // fixed-order tree over the slab lanes
         if (sy < off) {
           const float4 v = sh[sy + off][tx];
           float4 t = sh[sy][tx];
@@ -713,18 +716,19 @@ __global__ void __launch_bounds__(1024) k_reduce_jobs(ReduceJobs jobs) {
     }
     return;
   }
-  // scalar columns (bias-type jobs): 16 elements x 64 slab lanes
+  // scalar columns (bias-type jobs): 16 elements x NSY slab lanes
   for (int e0 = blockIdx.x * 16; e0 < jb.n; e0 += gridDim.x * 16) {
     const int e = e0 + tx;
     float s = 0.f;
     if (e < jb.n) {
       const int row = e / jb.ncols, col = e % jb.ncols;
       const float* p = jb.part + (size_t)row * jb.ld_in + col;
-      for (int k = sy; k < jb.nslab; k += 64) s += p[k * slab];
+#pragma unroll 8
+      for (int k = sy; k < jb.nslab; k += NSY) s += p[k * slab];
     }
     sh[sy][tx].x = s;
     __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = NSY / 2; off > 0; off >>= 1) {
       if (sy < off) sh[sy][tx].x += sh[sy + off][tx].x;
       __syncthreads();
     }

@@ -448,18 +448,37 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
   const int row0 = blockIdx.x * LR_ROWS;              // rows are (b, prow) pairs, b-major
   const int nr = min(LR_ROWS, nrows - row0);
   float vmax = 0.f;
-  // (loops over whole rows per wave: no per-element index divisions)
-  for (int j = wave; j < 2 * K2; j += 4)
-    for (int w = lane; w < W; w += 64) ts[j * WP + w] = tfwd[j * W + w];
-  for (int rk = wave; rk < LR_ROWS * CL; rk += 4) {
-    const int r = rk / CL, k = rk - r * CL;
-    const int row = row0 + r;
-    const int b = row / P, prow = row - b * P;
-    const float* src = x + ((size_t)b * CL + k) * PW + (size_t)prow * W;
-    for (int w = lane; w < W; w += 64) {
-      const float xv = r < nr ? src[w] : 0.f;
-      xs[rk * WP + w] = xv;
-      vmax = fmaxf(vmax, fabsf(xv));
+  const int c = lane;                                  // the output stage's lane <-> channel weights: requested up front
+  float wv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wv[k] = (c < C && k < CL) ? lw[c * CL + k] : 0.f;
+  const float bc = (lb && c < C) ? lb[c] : 0.f;
+  // Eight loads per thread in flight before the first LDS write (round 4: the row-per-wave loops issued one load, waited,
+  // wrote, ... - 12 + 7 dependent round trips per workgroup, 30 us per launch for 38 MB at BASELINE config 2)
+  {
+    const int nt_tab = 2 * K2 * W, nt_x = LR_ROWS * CL * W;
+    for (int base = 0; base < nt_tab; base += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int i = base + q * 256 + tid; v[q] = i < nt_tab ? tfwd[i] : 0.f; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int i = base + q * 256 + tid; if (i < nt_tab) ts[(i / W) * WP + i % W] = v[q]; }
+    }
+    for (int base = 0; base < nt_x; base += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = base + q * 256 + tid;
+        const int rk = i / W, w = i - rk * W, r = rk / CL, k = rk - r * CL;
+        const int row = row0 + r;
+        const int b = row / P, prow = row - b * P;
+        v[q] = (i < nt_x && r < nr) ? x[((size_t)b * CL + k) * PW + (size_t)prow * W + w] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = base + q * 256 + tid;
+        if (i < nt_x) { xs[(i / W) * WP + i % W] = v[q]; vmax = fmaxf(vmax, fabsf(v[q])); }
+      }
     }
   }
   if (xmax) {      // max |x| of the model input (bound for the fused block 0's fp16 operand scale): one publish per workgroup
@@ -492,12 +511,7 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
   }
   __syncthreads();
   // lane <-> channel (two channels per lane pair of passes when C > 64 never happens: C is 32 or 64); a wave per (row, bin)
-  const int c = lane;
   if (c < C) {
-    float wv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wv[k] = k < CL ? lw[c * CL + k] : 0.f;
-    const float bc = lb ? lb[c] : 0.f;
     float2* dst = x1 + (size_t)row0 * K2 * C + c;
     for (int p = wave; p < nr * K2; p += 4) {           // p = r * K2 + k2
       const float2* h = xh + p * (CL + 1);
