@@ -119,3 +119,28 @@ def test_projection_head_hostile_dynamic_range(dev, case):
     ye.backward(dy.to(dev))
     for a, r64, r32, name in zip(eng, g64, g32, ("x", "w1", "b1", "w2", "b2")):
         _within_budget(rel_l2(a.grad.cpu().numpy(), r64), rel_l2(r32, r64), (case, name))
+
+
+@pytest.mark.parametrize("B", [9, 17])
+def test_uneven_tile_shares_cover_every_tile(dev, B):
+    """Two workgroups per CU split a CU's tiles unevenly (pair_share, fno_dev.h: the block forward's tiles, the projection
+    forward's pixel columns popped from an LDS counter).  Batch sizes whose tile count is not a multiple of the grid
+    (9 x 128 = 1152 and 17 x 128 = 2176 tiles on 512 workgroups: pairs own 4-5 or 8-9 tiles, split 2/2, 3/2, 4/4, 5/4) must
+    still write every pixel exactly once: output and every gradient against float64."""
+    S, C, L, modes = 128, 64, 4, (12, 12)
+    p = _fno_params(C, L, [m // 2 for m in modes])
+    x = torch.from_numpy(fill_named(f"ux{B}", (B, 3, S, S), 1.0))
+    tgt = torch.from_numpy(fill_named(f"ut{B}", (B, 1, S, S), 1.0))
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    p64 = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+    y64 = O.fno_forward(p64, x.double(), modes, n_layers=L)
+    O.lp_loss_rel_sum(y64, tgt.double()).backward()
+    p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    O.lp_loss_rel_sum(O.fno_forward(p32, x, modes, n_layers=L), tgt).backward()
+    y, pg = _run_fused(p, x, modes, dev, n_layers=L)
+    assert rel_l2(y.detach().cpu().numpy(), y64.detach().numpy()) < TOL_Y
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    torch.cuda.synchronize()
+    for k in p:
+        g64 = p64[k].grad.numpy()
+        _within_budget(rel_l2(pg[k].grad.cpu().numpy(), g64), rel_l2(p32[k].grad.numpy(), g64), (B, k))
