@@ -491,14 +491,21 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
   }
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
-    const dim3 grid(Ktot, (B + 63) / 64, nm), blk(2 * (2 * Cout / 32) * 64);
-    const size_t lds = (size_t)64 * (2 * Cin + 1) * 4 + (size_t)std::max(Cin * (Cout + 1), Cout * (Cin + 1)) * 8;      // spectra + the complex weight block
+    // batch rows per workgroup (k_spectral_mid.h): 32 where the batch has no more AND the workgroup stays four waves
+    // (64 output channels; at 32 channels the two-wave workgroup stages its weights too slowly: 10.7 vs 8.6 us at FNO3d)
+    const int br = (B > 32 || Cout < 64) ? 64 : 32;
+    const dim3 grid(Ktot, (B + br - 1) / br, nm), blk((br / 32) * (2 * Cout / 32) * 64);
+    const size_t lds = (size_t)br * (2 * Cin + 1) * 4 + (size_t)std::max(Cin * (Cout + 1), Cout * (Cin + 1)) * 8;      // spectra + the complex weight block
     const float2 *xx = (const float2*)x, *ww = (const float2*)w;
     float2* oo = (float2*)out;
-    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
-    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
-    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
-    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+#define MGK(CI_, CO_) do { \
+      if (br == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<CI_, CO_, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w); \
+      return launch("k_mode_gemm", k_mode_gemm_mfma<CI_, CO_, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w); } while (0)
+    if (Cin == 32 && Cout == 32) MGK(32, 32);
+    if (Cin == 32 && Cout == 64) MGK(32, 64);
+    if (Cin == 64 && Cout == 32) MGK(64, 32);
+    MGK(64, 64);
+#undef MGK
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
@@ -529,13 +536,18 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
   }
   if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
     const dim3 grid(Ktot, nm), blk((Cin / 32) * (2 * Cout / 32) * 64);
-    const size_t lds = ((size_t)64 * 2 * Cin + (size_t)128 * (2 * Cout + 32)) * 4;
+    const int bc = B > 32 ? 32 : 16;      // samples staged per chunk (k_spectral_mid.h)
+    const size_t lds = ((size_t)bc * 2 * Cin + (size_t)2 * bc * (2 * Cout + 32)) * 4;
     const float2 *xx = (const float2*)x, *gg = (const float2*)g;
     float2* dd = (float2*)dw;
-    if (Cin == 32 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
-    if (Cin == 32 && Cout == 64) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<32, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
-    if (Cin == 64 && Cout == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
-    return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<64, 64>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2);
+#define DWK(CI_, CO_) do { \
+      if (bc == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<CI_, CO_, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2); \
+      return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<CI_, CO_, 16>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2); } while (0)
+    if (Cin == 32 && Cout == 32) DWK(32, 32);
+    if (Cin == 32 && Cout == 64) DWK(32, 64);
+    if (Cin == 64 && Cout == 32) DWK(64, 32);
+    DWK(64, 64);
+#undef DWK
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int it = 2 * (512 / Cout);                   // 2 input channels per thread

@@ -512,9 +512,11 @@ __global__ void __launch_bounds__(512) k_mode_gemm_dw_lds(const float2* __restri
 // 64 batch rows; the expanded real weight block and the spectra are staged once in LDS (weight rows padded by 32 floats so
 // that the two lane halves, which read adjacent k rows, fall on disjoint banks; spectrum rows by 1 float for the
 // row-per-lane A reads).  Wave (mt, nt): batch rows [32 mt, +32), real output columns [32 nt, +32).
-//   grid (Ktot, ceil(B / 64)), block 2 * (2 CO / 32) waves, LDS 64 (2 CI + 1) floats + max(CI (CO + 1), CO (CI + 1)) float2
-template <int CI, int CO>
-__global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
+//   grid (Ktot, ceil(B / MG_BR)), block (MG_BR / 32) * (2 CO / 32) waves, LDS MG_BR (2 CI + 1) floats + max(CI (CO + 1), CO (CI + 1)) float2
+// MG_BR = batch rows per workgroup: 64, or 32 when the batch has no more (RNO2d / PINO observers at batch 32: half of the
+// 64-row tile was padding; with 32 rows the workgroup is four waves and 50 KB, three per CU instead of two).
+template <int CI, int CO, int MG_BR>
+__global__ void __launch_bounds__((MG_BR / 32) * (2 * CO / 32) * 64) k_mode_gemm_mfma(const float2* __restrict__ x,
                                                                            const float2* __restrict__ w,
                                                                            float2* __restrict__ out, int B, int Ktot,
                                                                            int conj_w, size_t x_ms, size_t w_ms, size_t o_ms,
@@ -526,16 +528,16 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
   // The weight block stays COMPLEX in LDS (rows padded by one float2) and the real operand [[wr wi], [-wi wr]] is formed
   // per lane while it is read: 33 KB instead of the 80 KB expanded block, so two workgroups share a CU (the launch is
   // bound by staging latency, not arithmetic: 28 -> 16 us for the RNO cell's batched contractions).
-  constexpr int NTN = 2 * CO / 32, NT = 2 * NTN * 64, PA = 2 * CI + 1;
+  constexpr int NTN = 2 * CO / 32, NT = (MG_BR / 32) * NTN * 64, PA = 2 * CI + 1;
   constexpr int PW_N = CO + 1, PW_T = CI + 1;         // row pitch (float2) of the stored block: (CI, CO) or, trans_w, (CO, CI)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                                              // [64][PA]
-  float2* wc = reinterpret_cast<float2*>(smem + 64 * PA);        // (64 * PA floats: 8-byte aligned)
+  float* xs = smem;                                              // [MG_BR][PA]
+  float2* wc = reinterpret_cast<float2*>(smem + MG_BR * PA);     // (MG_BR * PA floats: 8-byte aligned, MG_BR even)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int mt = wave / NTN, nt = wave % NTN;
-  const int k = blockIdx.x, b0 = blockIdx.y * 64;
-  const int nb = min(64, B - b0);
+  const int k = blockIdx.x, b0 = blockIdx.y * MG_BR;
+  const int nb = min(MG_BR, B - b0);
   const float sg = conj_w ? -1.f : 1.f;
   const float2* wk = w + (size_t)k * CI * CO;
   if (trans_w) {
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
   } else {
     for (int i = tid; i < CI * CO; i += NT) wc[(i / CO) * PW_N + i % CO] = wk[i];      // stored (CI, CO): row = input channel
   }
-  for (int i = tid; i < 64 * CI; i += NT) {
+  for (int i = tid; i < MG_BR * CI; i += NT) {
     const int bb = i / CI, ci = i % CI;
     const float2 v = bb < nb ? x[((size_t)(b0 + bb) * Ktot + k) * CI + ci] : make_float2(0.f, 0.f);
     xs[bb * PA + 2 * ci] = v.x;
@@ -575,9 +577,12 @@ __global__ void __launch_bounds__(2 * (2 * CO / 32) * 64) k_mode_gemm_mfma(const
 
 // dW[k][i][o] = sum_b conj(X[b][k][i]) G[b][k][o] the same way: rows i, real columns 2o + c, K = 2B with
 //   A[i][2b + h] = (xr, xi)_h,   B[2b][2o + c] = (gr, gi)_c,   B[2b + 1][2o + c] = (gi, -gr)_c.
-// The batch is staged in chunks of 64 samples.  Wave (mt, nt): input channels [32 mt, +32), columns [32 nt, +32).
-//   grid (Ktot), block (CI / 32) * (2 CO / 32) waves, LDS 64 * 2 CI + 128 (2 CO + 32) floats
-template <int CI, int CO>
+// The batch is staged in chunks of DW_BC samples (32: 57 KB of LDS at 64 channels, two workgroups per CU, so that the 288
+// workgroups of BASELINE config 2 - 72 modes x 4 layers - are resident at once; chunks of 64 samples, 114 KB, ran them as
+// one workgroup per CU in two rounds: 30 us per launch).  Wave (mt, nt): input channels [32 mt, +32), columns [32 nt, +32).
+//   grid (Ktot), block (CI / 32) * (2 CO / 32) waves, LDS DW_BC * 2 CI + 2 DW_BC (2 CO + 32) floats
+// DW_BC is 32 for batches above 32 samples, 16 below (four workgroups per CU: 17 vs 18 us at batch 32, 11 vs 13 at batch 16).
+template <int CI, int CO, int DW_BC>
 __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw_mfma(const float2* __restrict__ x,
                                                                                       const float2* __restrict__ g,
                                                                                       float2* __restrict__ dw, int B,
@@ -585,8 +590,8 @@ __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw
   x += blockIdx.y * x_ms; g += blockIdx.y * g_ms; dw += blockIdx.y * d_ms;        // blockIdx.y = member (see k_mode_gemm_mfma)
   constexpr int NTN = 2 * CO / 32, NT = (CI / 32) * NTN * 64, PA = 2 * CI, PB = 2 * CO + 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                 // [64][PA]   raw interleaved spectra of the chunk
-  float* gs = smem + 64 * PA;       // [128][PB]  rows 2b: (gr, gi), rows 2b + 1: (gi, -gr)
+  float* xs = smem;                 // [DW_BC][PA]   raw interleaved spectra of the chunk
+  float* gs = smem + DW_BC * PA;    // [2 DW_BC][PB]  rows 2b: (gr, gi), rows 2b + 1: (gi, -gr)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int mt = wave / NTN, nt = wave % NTN;
@@ -594,16 +599,16 @@ __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    const int nb = min(64, B - b0);
+  for (int b0 = 0; b0 < B; b0 += DW_BC) {
+    const int nb = min(DW_BC, B - b0);
     __syncthreads();
-    for (int i = tid; i < 64 * CI; i += NT) {
+    for (int i = tid; i < DW_BC * CI; i += NT) {
       const int bb = i / CI, ci = i % CI;
       const float2 v = bb < nb ? x[((size_t)(b0 + bb) * Ktot + k) * CI + ci] : make_float2(0.f, 0.f);
       xs[bb * PA + 2 * ci] = v.x;
       xs[bb * PA + 2 * ci + 1] = v.y;
     }
-    for (int i = tid; i < 64 * CO; i += NT) {
+    for (int i = tid; i < DW_BC * CO; i += NT) {
       const int bb = i / CO, o = i % CO;
       const float2 v = bb < nb ? g[((size_t)(b0 + bb) * Ktot + k) * CO + o] : make_float2(0.f, 0.f);
       float* r0 = gs + (2 * bb) * PB + 2 * o;
@@ -614,7 +619,7 @@ __global__ void __launch_bounds__((CI / 32) * (2 * CO / 32) * 64) k_mode_gemm_dw
     const float* ap = xs + 2 * (mt * 32 + l31) + half;
     const float* bp = gs + half * PB + nt * 32 + l31;
 #pragma unroll 8
-    for (int s = 0; s < 64; ++s) acc = mfma32(ap[s * PA], bp[(2 * s) * PB], acc);
+    for (int s = 0; s < DW_BC; ++s) acc = mfma32(ap[s * PA], bp[(2 * s) * PB], acc);
   }
   float* op = reinterpret_cast<float*>(dw);
 #pragma unroll
