@@ -487,7 +487,12 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
     __shared__ float wmax[4];
     if (lane == 0) wmax[wave] = vmax;
     __syncthreads();
-    if (wave == 0) absmax_publish(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])), xmax);
+    // All workgroups of the launch reach this point together, see the slot still at zero and would ALL issue the atomic:
+    // 1024 same-address atomics serialise to ~24 us (found in round 4: the kernel took 30 us with or without its DFT and
+    // its stores).  One workgroup in sixteen publishes here; the others look again at the end of the kernel, when the
+    // slot already holds (nearly) the maximum and almost none of them has anything to add.  Same result: a maximum.
+    vmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));      // the workgroup's maximum, in every thread
+    if (wave == 0 && (blockIdx.x & 15) == 0) absmax_publish(vmax, xmax);
   }
   __syncthreads();
   for (int i = tid; i < LR_ROWS * K2 * (CL + 1); i += 256) {
@@ -522,4 +527,5 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
       dst[(size_t)p * C] = make_float2(sr, si);
     }
   }
+  if (xmax && wave == 0 && (blockIdx.x & 15) != 0) absmax_publish(vmax, xmax);      // (see above: the late look)
 }
