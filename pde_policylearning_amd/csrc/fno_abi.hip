@@ -22,6 +22,7 @@
 #include "k_projection.h"
 #include "k_projection2.h"
 #include "k_projection_h2.h"
+#include "k_projection3.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
 #include "k_pino_loss2.h"
@@ -137,7 +138,7 @@ static void prof_aggregate() {
 extern "C" int fno_profile_count(void) { prof_aggregate(); return (int)g_agg.size(); }
 extern "C" int fno_profile_get_terms(int i) {
   prof_aggregate();
-  return (i < 0 || i >= (int)g_agg.size()) ? FNO_EINVAL : g_agg[i].terms;
+  return (i < 0 || i >= (int)g_agg.size()) ? 0 : g_agg[i].terms;      // (0 = "not stated": never an error code as a term count)
 }
 extern "C" int fno_profile_get(int i, const char** name, float* total_ms, int* launches) {
   prof_aggregate();
@@ -152,6 +153,8 @@ static const int g_print_occ = getenv("FNO_PRINT_OCC") ? 1 : 0;
 template <typename... KArgs, typename... Args>
 static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
                   Args... args) {
+  const int terms = g_terms_next;      // read and cleared before any early return: a failed launch must not leave it for the next one
+  g_terms_next = 0;
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return FNO_OK;
   if (lds > 64 * 1024) {
     if (lds > 160 * 1024) return fail(FNO_EUNSUPPORTED, "%s needs %zu bytes of LDS (160 KB per CU)", name, lds);
@@ -176,8 +179,6 @@ static int launch(const char* name, void (*kern)(KArgs...), dim3 grid, dim3 bloc
     }
   }
   ProfRec rec;
-  const int terms = g_terms_next;
-  g_terms_next = 0;
   if (g_prof) {
     rec.name = name;
     rec.terms = terms;
@@ -954,7 +955,7 @@ struct FnoModelPlan {
   };
   mutable std::mutex call_mu;
   mutable std::vector<std::pair<const void*, CallState>> calls;      // most recent last; capped (kMaxCalls)
-  static const size_t kMaxCalls = 64;
+  static const size_t kMaxCalls = 4096;
   void put_call(const void* saved, const CallState& cs) const {
     std::lock_guard<std::mutex> lk(call_mu);
     for (size_t i = 0; i < calls.size(); ++i)
@@ -962,16 +963,21 @@ struct FnoModelPlan {
     if (calls.size() >= kMaxCalls) calls.erase(calls.begin());
     calls.emplace_back(saved, cs);
   }
-  CallState get_call(const void* saved) const {
+  // miss (`found` = false): the buffer was evicted (more than kMaxCalls forwards since) or autograd handed `saved` back at another
+  // address (saved_tensors_hooks, offload, checkpoint repack).  The caller then falls back to what a forward pass of this plan
+  // does under the current switches for u0_skipped (model_backward_impl) and to the three-term paths, which need no bounds.
+  CallState get_call(const void* saved, bool* found) const {
     std::lock_guard<std::mutex> lk(call_mu);
     for (size_t i = calls.size(); i-- > 0;)
-      if (calls[i].first == saved) return calls[i].second;
+      if (calls[i].first == saved) { *found = true; return calls[i].second; }
+    *found = false;
     return CallState();
   }
 };
 
 static const int kHID = 256;
 // magnitude bounds kept at the end of the forward's `saved` buffer (fno_dev.h "h2"): [0] max |u_L| (projection input), [1] max |dy|
+static_assert(8 + FNO_MAX_LAYERS + 1 <= 32 && 32 + FNO_MAX_LAYERS + 1 <= 59, "bound slots: [8, 32) forward |u_l|, [32, 59) backward |g_l|, [59, 63) projection scalars");
 static const int kNAmax = 64;      // [1] max |dy|, [2] max |W1|, [3] max |w2|, [6] max |g| (backward chain), [7] max |x| (model input), [8 + l] max |u_l|
 // persistent-grid size per CU of the forward kernels (= workgroups that fit: registers / LDS)
 #ifndef FNO_GRID_LIFT
@@ -1189,11 +1195,13 @@ template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a_in) {
   size_t lds2 = 0;
   const PwFwdArgs& a = a_in;
+  // profile label: block 0 with the lifting recomputed reads the <= 4-channel model input instead of u_0 (bench.py prices it so)
+  const char* nm = a_in.lw ? "k_pw_fwd_block0" : "k_pw_fwd_block";
   if (blk_fwd_t_ok<C>(p, a_in, &lds2)) {
     const dim3 g2(std::min(a.ntiles, (g_grid_bf2 > 0 ? g_grid_bf2 : (C == 64 ? 2 : 3)) * p->ncu)), blk((C / 32) * 2 * 64);
     const int epi = a.x1 ? (a.act_out ? 2 : 1) : 0;
     // two workgroups per CU: the one dispatched first gets the larger share of the CU's tiles (pair_share, fno_dev.h)
-    static const int share_bf = getenv("FNO_BF_SHARE") ? atoi(getenv("FNO_BF_SHARE")) : 18;      // of 32; 0 / 16 = even
+    static const int share_bf = getenv("FNO_BF_SHARE") ? std::min(32, std::max(0, atoi(getenv("FNO_BF_SHARE")))) : 18;      // of 32; 0 / 16 = even
     PwFwdArgs a = a_in;
     a.share32 = ((int)g2.x == 2 * p->ncu) ? share_bf : 0;
     // (template flags: LIFT, RELU, ACT_IN, EPI, ADD - k_block_fwd2.h; other combinations keep k_pw_fwd_x3)
@@ -1201,9 +1209,9 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
     const bool h2k = g_h2 && g_h2_blocks && g_h2_fwd_blocks && a.xmax && kz > 0 && !a.add && !a.relu_out;      // two-term fp16 variants: the model path's combinations
 #define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
     if (h2k && !(RELU_) && !(ADD_)) \
-      return GT(2), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
-    if (kz == 0) return GT(3), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
-    return GT(3), launch("k_pw_fwd_block", k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
+      return GT(2), launch(nm, k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
+    if (kz == 0) return GT(3), launch(nm, k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
+    return GT(3), launch(nm, k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
     if (a.lw && !a.relu_out && !a.add) {
       if (epi == 2) BF2(true, false, false, 2, false);
       if (epi == 1) BF2(true, false, false, 1, false);
@@ -1222,20 +1230,20 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
                      (p->loose && a.z ? (size_t)2 * a.K2in * C * 2 * 4 : 0);      // two more spectral rows per tile
   if (p->loose && !a.relu_out)
-    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch(nm, k_pw_fwd_x3<C, 128, FNO_NTW_PWX, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   if (a.lw && !a.relu_out)
-    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch(nm, k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, true>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
   if (a.relu_out) {
     if (p->NPX != 128 || p->loose || a.lw) return fail(FNO_EUNSUPPORTED, "ReLU output: 128-pixel tiles of whole rows, no fused lifting");
-    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, false, true>, dim3(grid),
+    return GT(3), launch(nm, k_pw_fwd_x3<C, 128, FNO_NTW_PWX, false, false, true>, dim3(grid),
                   dim3((C / 32) * (4 / FNO_NTW_PWX) * 64), lds, st, a);
   }
   if (p->NPX == 128)
-    return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
+    return GT(3), launch(nm, k_pw_fwd_x3<C, 128, FNO_NTW_PWX>, dim3(grid), dim3((C / 32) * (4 / FNO_NTW_PWX) * 64),
                   lds, st, a);
-  return GT(3), launch("k_pw_fwd_block", k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
+  return GT(3), launch(nm, k_pw_fwd_x3<C, 256, 2>, dim3(grid), dim3((C / 32) * 4 * 64), lds, st, a);
 }
 static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a) {
   if (p->loose && !g_gemm_x3) return fail(FNO_EUNSUPPORTED, "block stacks on loose rows need the split-precision GEMM mode");
@@ -1269,6 +1277,9 @@ template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a_in, bool* published = nullptr) {
   static const int kx_f32 = getenv("FNO_BBWD_KEXT_F32") ? 1 : 0;      // A/B switch: the K-extension of k_block_bwd_g2 as fp32 MFMAs
   BlkBwdArgs a = a_in;
+  // profile labels: block 0 behind a lifting layer reads g and the model input and writes no gradient tile unless dx is asked for
+  const char* nm = (a_in.xin && !a_in.gout) ? "k_block_bwd0" : "k_block_bwd";
+  const char* nm_kch = "k_block_bwd_kch";
   const size_t pitch = p->NPX + 4;
   const bool h2 = g_h2 && g_h2_blocks && a.gmax_in && a.umax;      // two-term fp16 variants (operand bounds known)
   const int g2_terms = h2 ? 2 : 3;
@@ -1278,7 +1289,7 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   if (a.drop_seed) {      // dropout of the spectral branch (one-layer stacks with a tail, fno_model_*_tail)
     if (p->loose || a.lw || a.xin || !g_gemm_x3 || p->NPX != 128 || bbwd_t_lds(C, a) > 160 * 1024)
       return fail(FNO_EUNSUPPORTED, "spectral-branch dropout: split-precision GEMM mode, 128-pixel tiles of whole rows, no lifting");
-    return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch(nm, k_block_bwd_t<C, 128, false, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_t_lds(C, a), st, a);
   }
   if (p->loose) {
@@ -1298,8 +1309,8 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       ldsl = base + kch * per_mode;
     }
     if (v1)
-      return GT(3), launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
-    return GT(3), launch(al.kch ? "k_block_bwd_kch" : "k_block_bwd", k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+      return GT(3), launch(al.kch ? nm_kch : nm, k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
+    return GT(3), launch(al.kch ? nm_kch : nm, k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
   }
   // C = 64, rows of 32 / 64 / 128 pixels: two independent 4-wave groups per workgroup (k_block_bwd_g2)
   static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
@@ -1311,14 +1322,14 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       const bool two = a.x1g && a.W == 128 && a.NJ == 2;
       if (a.lw && !a.x1g && !a.gadd) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
-        return GT(3), launch("k_block_bwd", k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        return GT(3), launch(nm, k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
       // (gradient addends and two 16-output blocks per wave do not fit the register budget yet: k_block_bwd_t takes those)
       if (!a.lw && !a.xin && !a.gadd && !two) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
-        return GT(3), launch("k_block_bwd", k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        return GT(3), launch(nm, k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
     }
   }
@@ -1327,26 +1338,26 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       return fail(FNO_EUNSUPPORTED, "block 0 cannot recompute the lifting in this GEMM mode (the forward pass skipped u_0)");
     if (!v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
       if (published) *published = a.gmax_out != nullptr;
-      if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-      return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+      if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+      return GT(3), launch(nm, k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
     }
-    return GT(3), launch("k_block_bwd", k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch(nm, k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
     if (published) *published = a.gmax_out != nullptr;
-    if (h2) return GT(2), launch("k_block_bwd", k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-    return GT(3), launch("k_block_bwd", k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    return GT(3), launch(nm, k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
   }
   if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
-    return GT(3), launch("k_block_bwd", k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
+    return GT(3), launch(nm, k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
                   bbwd_x3_lds(C, 128, a), st, a);
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
                       (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
                       (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
   if (p->NPX == 128)
-    return GT(1), launch("k_block_bwd", k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
-  return GT(1), launch("k_block_bwd", k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);
+    return GT(1), launch(nm, k_block_bwd<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), lds, st, a);
+  return GT(1), launch(nm, k_block_bwd<C, 256>, dim3(grid), dim3(BlkBwdCfg<C, 256>::NW * 64), lds, st, a);
 }
 // *published (if given): the launched kernel left max |gout| at a.gmax_out (the second-generation kernels do)
 static int launch_bbwd(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a, bool* published = nullptr) {
@@ -1365,7 +1376,7 @@ static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
     // independent waves, four per SIMD (k_projection_h2.h): two workgroups per CU
     constexpr int NWV = 12;
     const int ncols = a.ntiles * 4;
-    static const int share_pf = getenv("FNO_PFW_SHARE") ? atoi(getenv("FNO_PFW_SHARE")) : 18;      // of 32; 0 / 16 = even (pair_share)
+    static const int share_pf = getenv("FNO_PFW_SHARE") ? std::min(32, std::max(0, atoi(getenv("FNO_PFW_SHARE")))) : 18;      // of 32; 0 / 16 = even (pair_share)
     const int g = std::min((ncols + NWV - 1) / NWV, 2 * p->ncu);
     ProjFwdArgs aw = a;
     aw.share32 = g == 2 * p->ncu ? share_pf : 0;
@@ -1424,8 +1435,23 @@ static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsi
   if (t_order) return launch("k_pack_w1_x3", k_pack_w1_t<3>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
   return launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
 }
+// third-generation projection backward (k_projection3.h: one 16-wave workgroup per CU, four waves per SIMD): 64 channels, one
+// output channel, two fp16 terms (every operand bound published), rows of 32 / 64 / 128 floats or no row-DFT epilogue.
+// FNO_PBWD_NO_Q=1: the A/B switch back to k_proj_bwd_t
+static bool use_pbwd_q(const FnoModelPlan* p, int C, const ProjBwdArgs& a) {
+  static const int no_q = getenv("FNO_PBWD_NO_Q") ? 1 : 0;
+  if (no_q || C != 64 || !a.wa1 || !a.amax || !a.xmax || !use_pbwd_t(C, a.CO, p->NPX)) return false;
+  if (a.x1g && !(a.W == 32 || a.W == 64 || a.W == 128)) return false;
+  if (a.x1g && 4 * (64 / std::min(a.W, 64)) * a.NJ > 8) return false;      // row-DFT jobs of a half tile: one per spare wave
+  return proj_bwd_q_lds(kHID, a.W, a.NJ, a.x1g != nullptr) <= 160 * 1024;
+}
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
+  if constexpr (C == 64) {
+    if (use_pbwd_q(p, C, a))
+      return GT(2), launch("k_proj_bwd", k_proj_bwd_q<kHID, false>, dim3(grid), dim3(1024),
+                           proj_bwd_q_lds(kHID, a.W, a.NJ, a.x1g != nullptr), st, a);
+  }
   if (a.wa1 && a.amax && use_pbwd_t(C, a.CO, p->NPX))      // two fp16 terms: same LDS carve with two planes per image
     return GT(2), launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false, 2>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
@@ -1491,7 +1517,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   // two-term fp16 GEMMs with published magnitude bounds: from 1024 tiles up - below that the kernels are latency-bound and
   // the bound bookkeeping (one more launch, the weight scans in the prologues) costs more than three matrix products
   // save (BASELINE config 1, 128 tiles: 0.27 -> 0.22 ms per step without it)
-  const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= 32 && (size_t)B * g.PW >= ((size_t)1 << 17);
+  const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= FNO_MAX_LAYERS && (size_t)B * g.PW >= ((size_t)1 << 17);
   if (h2 && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   {
     CornerPtrsL cp;
@@ -1647,7 +1673,15 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   JobList jobs;
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
-  FnoModelPlan::CallState cs = p->get_call(saved);      // what the forward pass that filled `saved` published
+  bool cs_found = false;
+  FnoModelPlan::CallState cs = p->get_call(saved, &cs_found);      // what the forward pass that filled `saved` published
+  if (!cs_found) {
+    // an unknown buffer: u_0 was written or not exactly as a forward of this plan decides it (a default of "written" would let
+    // block 0 read memory the forward never filled); no bounds are assumed published
+    static const int strict = getenv("FNO_STRICT_SAVED") ? 1 : 0;
+    if (strict) return fail(FNO_EINVAL, "fno_model_backward: `saved` buffer %p was not filled by a forward pass of this plan", saved);
+    cs.u0_skipped = has_lift && lift_fused(p);
+  }
   bool gvalid = false;      // amax[32 + l + 1] bounds the gradient the next block kernel reads (two-term fp16 GEMMs)
   float* amax_b = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
   if (l_hi < L - 1 && g_gemm_x3 && g_h2 && cs.h2_fwd) gvalid = cs.gchain_valid;      // a later part: left by the previous part's last kernel
@@ -1673,7 +1707,10 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   float* bwd_b = amax + 59;
   bool db2_done = false;
   const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && cs.h2_fwd;      // (this buffer's forward published max |u_L|)
-  if (h2 && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
+  // cleared whenever ANY slot of the range is written in this pass: the projection's scalars (h2) or the chain of gradient
+  // bounds the layer loop hands out (same condition as there) - a second backward on the same `saved` must not keep the first one's
+  const bool chain = g_gemm_x3 && g_h2 && cs.h2_fwd && L <= 24;
+  if ((h2 || chain) && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   if (h2) {
     // (one output channel: the same launch leaves 256 partial sums of dy = the bias gradient's partial slabs; k_channel_sums
     // below is then not launched)
@@ -1699,8 +1736,9 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
   jobs.add(w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C);
-  jobs.add(w.db1_part, gr->proj_b1, s.grid * (p->NPX / 32), 1, kHID, kHID, kHID);
-  jobs.add(w.dw2_part, gr->proj_w2, s.grid * (p->NPX / 32), d.Cout, kHID, kHID, kHID);
+  const int pslabs = use_pbwd_q(p, C, pb) ? 1 : p->NPX / 32;      // db1 / dW2 partial slabs per workgroup
+  jobs.add(w.db1_part, gr->proj_b1, s.grid * pslabs, 1, kHID, kHID, kHID);
+  jobs.add(w.dw2_part, gr->proj_w2, s.grid * pslabs, d.Cout, kHID, kHID, kHID);
   if (!db2_done) LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
   jobs.add(w.db2_part, gr->proj_b2, db2_done ? 256 : 64, 1, d.Cout, d.Cout, d.Cout);
   if (p->loose) LAUNCHCHK(row_forward(st, g, p->t.tfwd_b, p->t.tT[1], p->t.K2P, B, C, w.ga, w.x1));   // dL/du_L's row spectrum

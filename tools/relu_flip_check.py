@@ -3,7 +3,7 @@ the hidden layer, db1[h] = sum_px [P1[h, px] > 0], is an INTEGER count per hidde
 difference from the float64 count is the net number of flipped decisions; sum |diff| over units bounds the flips from below.
 Compared: the engine's projection backward (the mode given by the environment: default two fp16 terms where the bounds
 exist, FNO_NO_H2=1 three bf16 terms, FNO_GEMM_F32=1 fp32 MFMA) and torch float32 on the CPU.  Usage (GPU box):
-   [FNO_NO_H2=1 | FNO_GEMM_F32=1] python tools/relu_flip_test.py"""
+   [FNO_NO_H2=1 | FNO_GEMM_F32=1] python tools/relu_flip_check.py"""
 import os, sys
 import numpy as np
 import torch
