@@ -538,6 +538,55 @@ def main():
             Lb.fno_set_gemm_mode(1)
         step()      # back on the default kernels before the profiled steps
 
+    # ---- the mode contraction on the matrix cores, beside the default (north_star: 'bixy,ioxy->boxy' as a batched complex GEMM on
+    # MFMA).  The default 2-D path runs the contraction inside k_spec_mid as a mat-vec per (sample, bin) workgroup on the vector
+    # lanes (384 workgroups per launch keep the two DFT phases on every CU); the three-launch
+    # sequence k_axis_fwd -> k_mode_gemm (v_mfma_f32_32x32x2_f32, exact fp32, one workgroup per mode x 64 batch rows) ->
+    # k_axis_inv is the matrix-core arm: the same step timed with fno_set_fused_mid(0), its kernels profiled below.
+    mode_contraction = None
+    if fused_model and not args.graph and not args.no_exact_fp32 and cfg["kind"] == "2d" and _lib.lib().fno_get_fused_mid() == 1:
+        Lb = _lib.lib()
+        Lb.fno_set_fused_mid(0)
+        try:
+            for _ in range(3):
+                step()
+            mb = []
+            nst = max(5, args.steps // 2)
+            for _ in range(3):
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(nst):
+                    step()
+                sync()
+                mb.append(time.perf_counter() - t0)
+            if dist_on:
+                tm = torch.tensor(mb, dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                mb = [float(v) for v in tm.tolist()]
+            mm = sorted(mb)[1]
+            arm = {}
+            if rank == 0 and args.profile_steps > 0:
+                Lb.fno_profile_reset(); Lb.fno_profile_enable(1)
+                for _ in range(2 * args.profile_steps):
+                    eager_step()
+                torch.cuda.synchronize()
+                Lb.fno_profile_reset()
+                for _ in range(args.profile_steps):
+                    eager_step()
+                torch.cuda.synchronize()
+                Lb.fno_profile_enable(0)
+                arm = {n: dict(launches_per_step=k / args.profile_steps, avg_ms=round(ms / k, 4))
+                       for n, ms, k in _lib.profile_summary() if n.startswith(("k_axis", "k_mode_gemm", "k_spec_mid"))}
+                Lb.fno_profile_reset()
+            mode_contraction = dict(
+                default="k_spec_mid: leading-axis DFT + contraction (vector lanes, mat-vec per (sample, bin)) + inverse DFT in one launch",
+                mfma_arm=dict(value=round(B * world * nst / mm, 2), ms_per_step=round(1e3 * mm / nst, 4), kernels=arm,
+                              what="fno_set_fused_mid(0): k_axis_fwd -> k_mode_gemm on v_mfma_f32_32x32x2_f32 -> k_axis_inv per block "
+                                   "and direction; SQ_INSTS_MFMA of k_mode_gemm: profiles/r05_pmc_sq_mfma_arm.csv"))
+        finally:
+            Lb.fno_set_fused_mid(1)
+        step()
+
     # ---- N > 1: what the gradient exchange costs, and how much of it the overlap hides ----
     exchange = None
     if dist_on:
@@ -726,6 +775,7 @@ def main():
                               if algorithmic_bytes_per_field(cfg) else None),
             "step_hbm_note": "whole step: algorithmic bytes per field (bench.algorithmic_bytes_per_field: SURVEY 8(d) for the fused FNO models, the models stated in DESIGN.md section 5 for the observers) x batch / ms_per_step / 8 TB/s",
             "exact_fp32": exact_fp32,
+            "mode_contraction": mode_contraction,
             "dp_exchange_choice": dp_choice,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,

@@ -192,6 +192,24 @@ def gen_specconv_A(outdir):
              fft_norm=np.array(norm))
 
 
+def gen_specconv_A_overlap(outdir):
+    """Overlapping corners (2 * half_modes[0] > H): the reference assigns the corners in order into one zero-filled spectrum, so
+    rows that belong to both take the SECOND corner's product (spectral_convolution.py:330-337).  The engine rejects such
+    shapes (FNO_EUNSUPPORTED); the fixture pins what the reference does (tests/test_oracle_golden.py, tests/test_parity_gpu.py)."""
+    from neuralop.models.spectral_convolution import FactorizedSpectralConv
+    cin, cout, n_modes, sp, B = 3, 4, (12, 6), (8, 16), 2
+    torch.manual_seed(0)
+    conv = FactorizedSpectralConv(cin, cout, n_modes, n_layers=1, fft_norm="forward", factorization=None,
+                                  implementation="factorized", rank=1.0)
+    scales = refill_parameters(conv)
+    x = input_fill("A2d_overlap.x", (B, cin, *sp)).requires_grad_(True)
+    dy = input_fill("A2d_overlap.dy", (B, cout, *sp))
+    y = conv(x, 0)
+    y.backward(dy)
+    save(os.path.join(outdir, "specconv_A2d_overlap.npz"), x=x, dy=dy, y=y, dx=x.grad, grads=grads_of(conv), scales=scales,
+         meta=np.array([cin, cout, 1, 0, B, len(n_modes), *n_modes, *sp]), fft_norm=np.array("forward"))
+
+
 def gen_specconv_B(outdir):
     from neuralop.models.rno import SpectralConv2d
     for cname, (cin, cout, m1, m2, n, B) in {"B2d": (4, 5, 3, 5, 16, 3),
@@ -652,7 +670,7 @@ def main():
     sys.path.insert(0, args.ref)
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(8)
-    gens = [gen_specconv_A, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_fno_models_fp64, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow, gen_options, gen_regressor3d, gen_rno_predict]
+    gens = [gen_specconv_A, gen_specconv_A_overlap, gen_specconv_B, gen_specconv_C, gen_fno_models, gen_fno_models_fp64, gen_observer_adam, gen_rno, gen_pino, gen_pino_loss, gen_pde_dataset, gen_fullfield_dataset, gen_kf_dataset, gen_chanflow, gen_options, gen_regressor3d, gen_rno_predict]
     for g in gens:
         if args.only and args.only not in g.__name__:
             continue

@@ -11,6 +11,36 @@ def _sub(p, prefix):
     return {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
 
 
+# ReLU decisions of the RNO regressor (rno.py:104, 170-174), exposed for the mask-conditioned gradient comparison of
+# tests/test_fullsize_gpu.py: two float evaluations of the same network that decide a ReLU input within rounding of zero
+# differently differentiate DIFFERENT piecewise-linear functions, and everything upstream of the decision moves by ~1e-5 of its
+# norm.  RELU_HOOK(tag, pre_activation) -> activated tensor; None = F.relu.
+RELU_HOOK = None
+
+
+class ReluMasks(object):
+    """RELU_HOOK that records every decision (`seen[tag]`: list of bool tensors in call order) and, for tags in `impose`
+    ({tag: bool tensor over the whole batch, channels last}), applies THAT decision instead of its own: consecutive calls
+    with one tag take consecutive sample ranges (the full-size tests evaluate the oracle in chunks of samples)."""
+
+    def __init__(self, impose=None):
+        self.impose = impose or {}
+        self.seen, self._next = {}, {}
+
+    def __call__(self, tag, t):
+        own = t > 0
+        self.seen.setdefault(tag, []).append(own)
+        if tag in self.impose:
+            lo = self._next.get(tag, 0)
+            self._next[tag] = lo + t.shape[0]
+            return t * self.impose[tag][lo:lo + t.shape[0]].to(t.dtype)
+        return F.relu(t)
+
+
+def _relu(tag, t):
+    return F.relu(t) if RELU_HOOK is None else RELU_HOOK(tag, t)
+
+
 # ---- neuralop/models/rno.py ---------------------------------------------------------
 def fourier_layer2d(p, x, m1, m2):
     """rno.py:224-228: SpectralConv2d(x) + Conv1d(k=1)(x)."""
@@ -43,11 +73,11 @@ def rno_layer(p, x, h, m1, m2, width, return_sequences):
     return torch.stack(seq, dim=1) if return_sequences else h
 
 
-def spectral_conv_with_fc(p, x, m):
+def spectral_conv_with_fc(p, x, m, tag="relu"):
     """rno.py:92-106 in eval mode (dropout = identity), activation ReLU as RNO2d builds it."""
     res = x @ p["linear.weight"].t() + p["linear.bias"]
     y = spectral_conv_B(x.permute(0, 3, 1, 2), p["spec_conv.fourier_weight.0"], p["spec_conv.fourier_weight.1"], m, m)
-    return F.relu(y.permute(0, 2, 3, 1) + res)
+    return _relu(tag, y.permute(0, 2, 3, 1) + res)
 
 
 def rno2d_forward(p, x, modes1, modes2, width, recurrent_index, layer_num):
@@ -65,8 +95,8 @@ def rno2d_forward(p, x, modes1, modes2, width, recurrent_index, layer_num):
                 finals.append(h)
         t = finals[-1].permute(0, 2, 3, 1)
         for j in range(2):
-            t = spectral_conv_with_fc(_sub(p, f"regressor.spectral_conv.{j}."), t, modes2)
-        t = F.relu(t @ p["regressor.regressor.0.weight"].t() + p["regressor.regressor.0.bias"])
+            t = spectral_conv_with_fc(_sub(p, f"regressor.spectral_conv.{j}."), t, modes2, f"regressor.spectral_conv.{j}")
+        t = _relu("regressor.head", t @ p["regressor.regressor.0.weight"].t() + p["regressor.regressor.0.bias"])
         return t @ p["regressor.regressor.2.weight"].t() + p["regressor.regressor.2.bias"], finals
 
     outs, states = [], [None] * layer_num

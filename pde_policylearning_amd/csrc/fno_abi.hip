@@ -1437,10 +1437,12 @@ static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsi
 }
 // third-generation projection backward (k_projection3.h: one 16-wave workgroup per CU, four waves per SIMD): 64 channels, one
 // output channel, two fp16 terms (every operand bound published), rows of 32 / 64 / 128 floats or no row-DFT epilogue.
-// FNO_PBWD_NO_Q=1: the A/B switch back to k_proj_bwd_t
+// Measured SLOWER than k_proj_bwd_t (0.67 vs 0.50 ms at BASELINE config 2; DESIGN.md section 4f says why: the packed-fp32
+// vector work and the matrix products of different waves do not overlap on a SIMD, so four waves per SIMD buy nothing, and
+// the 64-pixel half tiles cost 37 % more vector instructions): an A/B arm, selected with FNO_PBWD_Q=1
 static bool use_pbwd_q(const FnoModelPlan* p, int C, const ProjBwdArgs& a) {
-  static const int no_q = getenv("FNO_PBWD_NO_Q") ? 1 : 0;
-  if (no_q || C != 64 || !a.wa1 || !a.amax || !a.xmax || !use_pbwd_t(C, a.CO, p->NPX)) return false;
+  static const int use_q = getenv("FNO_PBWD_Q") ? 1 : 0;
+  if (!use_q || C != 64 || !a.wa1 || !a.amax || !a.xmax || !use_pbwd_t(C, a.CO, p->NPX)) return false;
   if (a.x1g && !(a.W == 32 || a.W == 64 || a.W == 128)) return false;
   if (a.x1g && 4 * (64 / std::min(a.W, 64)) * a.NJ > 8) return false;      // row-DFT jobs of a half tile: one per spare wave
   return proj_bwd_q_lds(kHID, a.W, a.NJ, a.x1g != nullptr) <= 160 * 1024;

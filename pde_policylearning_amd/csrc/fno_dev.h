@@ -191,7 +191,7 @@ FNO_DEV float4 gelu4(const float4& v, float six, float inf) {
 // shared by both).  The branch `x >= 0 ? 1 - q : q` becomes 0.5 + copysign(0.5 - q, x).
 FNO_DEV void gelu_both2(f32x2 x, f32x2& g, f32x2& dg) {
 #if !FNO_GELU_PK
-  gelu_both(x[0], g[0], dg[0]); gelu_both(x[1], g[1], dg[1]);
+  { float g0, d0, g1, d1; gelu_both(x[0], g0, d0); gelu_both(x[1], g1, d1); g = f32x2{g0, g1}; dg = f32x2{d0, d1}; }
   return;
 #endif
   const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};

@@ -54,6 +54,25 @@ FNO_DEV f16x8 lds_tr2x8(const unsigned char* p0, const unsigned char* p1) {     
   return __builtin_bit_cast(f16x8, cat4(lds_tr16(p0), lds_tr16(p1)));
 }
 
+// -DPBQ_TRACE (tools/pbq_bench.hip): shader-clock stamps of workgroup 0, every wave, the first 32 half tiles
+#ifndef PBQ_SKIP
+#define PBQ_SKIP 0      // timing experiments (results wrong): 1 no GELU, 2 no dW1 products, 4 no dP1 image stores, 8 no dx products,
+#endif                  // 16 no row DFT, 32 no recompute products, 64 no next-tile prefetch, 128 no dP1 split
+#ifndef PBQ_VAR
+#define PBQ_VAR 0       // structure experiments (results right): 1 next-tile loads issued behind the epilogue, 2 dx loop unrolled by two
+#endif                  // without scheduling fences, 4 recompute loop without scheduling fences
+#ifdef PBQ_TRACE
+__device__ unsigned long long g_pbq[16 * 32 * 16];
+#define PBQ_STAMP(slot) do { if (blockIdx.x == 0 && pbq_ht < 32 && (threadIdx.x & 63) == 0) \
+    g_pbq[((threadIdx.x >> 6) * 32 + pbq_ht) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PBQ_STAMP(slot) do { } while (0)
+#endif
+#if PBQ_SKIP & 512
+#define PBQ_SYNC() do { } while (0)
+#else
+#define PBQ_SYNC() __syncthreads()
+#endif
 template <int HID, bool RELU = false>
 __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
   constexpr int C = 64, NPX = 64, NT = 1024, PITCH = NPX + 4;
@@ -116,10 +135,17 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
   const int nht = 2 * a.ntiles;
   if (2 * (int)blockIdx.x < nht) issue_x(2 * blockIdx.x, tid >> 4, tid & 15);
 
+#ifdef PBQ_TRACE
+  int pbq_ht = -1;
+#endif
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     const int b = tile / a.tiles_per_plane;
 #pragma unroll 1
     for (int hf = 0; hf < 2; ++hf) {
+#ifdef PBQ_TRACE
+      ++pbq_ht;
+#endif
+      PBQ_STAMP(0);
       const int px0 = (tile % a.tiles_per_plane) * 128 + hf * NPX;
       // every lane-derived index of the loop body comes from an OPAQUE copy of the lane id: the compiler otherwise hoists
       // dozens of per-lane address terms out of the tile loop and spills them (128-register budget)
@@ -144,13 +170,15 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
         *reinterpret_cast<uint2*>(aimg + ATERM + off8(xc, xg)) = make_uint2(l0, l1);
       }
       if (tid < NPX) douts[tid] = a.dy[(size_t)b * a.PW + px0 + tid];
-      __syncthreads();                                                                                             // B1
+      PBQ_STAMP(1);
+      PBQ_SYNC();                                                                                                  // B1
+      PBQ_STAMP(2);
       // ---- A1: P1^T[px][hid] = sum_c a[c][px] W1[hid][c] (+ b1): A = transposed reads of the a image, B = row reads of W1 ----
       f32x16 hi, lo;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { hi[r] = 0.f; lo[r] = 0.f; }
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
+      for (int kb = 0; kb < ((PBQ_SKIP & 32) ? 0 : 4); ++kb) {
         f16x8 af[2], bf[2];
         const int o0 = aT0 + 2048 * kb, o1 = aT1 + 2048 * kb;         // rows 16 kb + trow (+ 4) of the a image
         const int ow = wRb + 16 * ((2 * kb) ^ wfx6);                   // chunk (2 kb + half) ^ swizzle of W1 row hrow
@@ -160,14 +188,15 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
           bf[t] = *reinterpret_cast<const f16x8*>(wimg + t * WTERM + ow);
         }
         mfma_h2s(af, bf, hi, lo);
-        __builtin_amdgcn_sched_barrier(0);      // at most one k block of operand fragments live (the budget is 128 registers)
+        if (!(PBQ_VAR & 4)) __builtin_amdgcn_sched_barrier(0);      // at most one k block of operand fragments live (the budget is 128 registers)
       }
       // ---- E: lane <-> hidden row hrow; registers <-> pixels n0 + (r & 3) + 8 (r >> 2) + 4 half ----------------------------
       // ---- E + B per k step s of the dW1 product (16 pixels): dP1 = act'(P1) w2 dy as packed fp16 pairs - what goes to the image
       //      AND the B fragments of dW1^T[c][hid] += sum_px a[c][px] dP1[px][hid] (the accumulator's own registers, k order of the idiom)
+      PBQ_STAMP(3);
       float p1[16];               // hh + cross terms: 16 instead of 32 live registers through the vector phase
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p1[r] = hi[r] + lo[r];
+      for (int r = 0; r < 16; ++r) p1[r] = (PBQ_SKIP & 256) ? (float)(ln * 16 + r) * 1e-3f * (float)(hf + 1) : hi[r] + lo[r];
       {
         float sdb = 0.f, sdw = 0.f;
         const int dWb = 128 * hrow, aRb = 128 * l31;
@@ -184,7 +213,8 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
             if constexpr (RELU) {
               dgv = make_float4(glv.x > 0.f ? 1.f : 0.f, glv.y > 0.f ? 1.f : 0.f, glv.z > 0.f ? 1.f : 0.f, glv.w > 0.f ? 1.f : 0.f);
               glv = make_float4(fmaxf(glv.x, 0.f), fmaxf(glv.y, 0.f), fmaxf(glv.z, 0.f), fmaxf(glv.w, 0.f));
-            } else gelu_both4(glv, dgv);
+            } else if (PBQ_SKIP & 1) dgv = glv;
+            else gelu_both4(glv, dgv);
             const float gl4[4] = {glv.x, glv.y, glv.z, glv.w}, dg4[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
             float dp[4];
 #pragma unroll
@@ -193,16 +223,23 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
               sdw = fmaf(gl4[j], dyv[j], sdw);
               sdb += dp[j];
             }
+            if (PBQ_SKIP & 128) {
+              dh[2 * ii] = __builtin_bit_cast(unsigned, dp[0]); dh[2 * ii + 1] = __builtin_bit_cast(unsigned, dp[1]);
+              dl[2 * ii] = __builtin_bit_cast(unsigned, dp[2]); dl[2 * ii + 1] = __builtin_bit_cast(unsigned, dp[3]);
+            } else
             split2x4(dp, sd, dh[2 * ii], dh[2 * ii + 1], dl[2 * ii], dl[2 * ii + 1]);
             const int od = dWb + 8 * (((n0 >> 2) + 2 * i + half) ^ dfx);
+            if (!(PBQ_SKIP & 4)) {
             *reinterpret_cast<uint2*>(dimg + od) = make_uint2(dh[2 * ii], dh[2 * ii + 1]);
             *reinterpret_cast<uint2*>(dimg + DTERM + od) = make_uint2(dl[2 * ii], dl[2 * ii + 1]);
+            }
             asm volatile("" : "+v"(sdb), "+v"(sdw));      // the two sums are finished HERE (the optimiser otherwise sinks both
                                                            // chains to the end of the tile loop and parks 24 operands in scratch)
           }
+          PBQ_STAMP(11 + 2 * s);
           const f16x8 bf[2] = {frag_from(dh[0], dh[1], dh[2], dh[3]), frag_from(dl[0], dl[1], dl[2], dl[3])};
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
+          for (int cb = 0; cb < ((PBQ_SKIP & 2) ? 0 : 2); ++cb) {
             f16x8 af[2];
             const int g0 = (n0 >> 2) + 4 * s + half;
             const int oa0 = aRb + 4096 * cb + 8 * (g0 ^ afx), oa1 = aRb + 4096 * cb + 8 * ((g0 + 2) ^ afx);      // row 32 cb + l31
@@ -211,15 +248,18 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
             dw1[cb] = mfma_h2(af, bf, dw1[cb]);
           }
           __builtin_amdgcn_sched_barrier(0);
+          PBQ_STAMP(12 + 2 * s);
         }
         sdb1 += sdb; sdw2 += sdw;
       }
       // the next half tile's rows: in flight during the dx phase
       {
         const int nh = hf == 0 ? 2 * tile + 1 : 2 * (tile + (int)gridDim.x);
-        if (nh < nht) issue_x(nh, xc, xg);
+        if (nh < nht && !(PBQ_SKIP & 64) && !(PBQ_VAR & 1)) issue_x(nh, xc, xg);
       }
-      __syncthreads();                                                                                             // B2
+      PBQ_STAMP(4);
+      PBQ_SYNC();                                                                                                  // B2
+      PBQ_STAMP(5);
       // ---- A3 (waves 0-7): dx^T[px][c] = sum_hid dP1[hid][px] W1[hid][c]; wave = (K half kh, pixel block pt, channel block ct) ----
       const int kh = (wave >> 2) & 1, pt = (wave >> 1) & 1, ct = wave & 1;
       if (wave < 8) {
@@ -230,8 +270,12 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
         const int dT0 = off8(kh * 128 + trow, (pt * 32 + tcol) >> 2), dT1 = off8(kh * 128 + trow + 4, (pt * 32 + tcol) >> 2);
         const int wT0 = swz64_off(kh * 128 + trow, (ct * 32 + tcol) >> 3) + 2 * (tcol & 7);
         const int wT1 = swz64_off(kh * 128 + trow + 4, (ct * 32 + tcol) >> 3) + 2 * (tcol & 7);
+#if PBQ_VAR & 2
+#pragma unroll 2
+#else
 #pragma unroll 1
-        for (int kb = 0; kb < 8; ++kb) {
+#endif
+        for (int kb = 0; kb < ((PBQ_SKIP & 8) ? 0 : 8); ++kb) {
           f16x8 af[2], bf[2];
           const int o0 = dT0 + 2048 * kb, o1 = dT1 + 2048 * kb, w0 = wT0 + 2048 * kb, w1o = wT1 + 2048 * kb;      // rows + 16 kb
 #pragma unroll
@@ -240,7 +284,7 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
             bf[t] = lds_tr2x8(wimg + t * WTERM + w0, wimg + t * WTERM + w1o);
           }
           mfma_h2s(af, bf, dxh, dxl);
-          __builtin_amdgcn_sched_barrier(0);
+          if (!(PBQ_VAR & 2)) __builtin_amdgcn_sched_barrier(0);
         }
         // the pair (kh = 0, 1) of a tile: each hands the other the 8 registers (two pixel groups) the other finishes -
         // kh = 0 keeps registers 0-7 (i = 0, 1), kh = 1 registers 8-15 (i = 2, 3); selects on the wave-uniform kh, no branches
@@ -262,7 +306,9 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
         float* pw = part + (((kh * 4 + pt * 2 + ct) * 8) * 64) + lane;
 #pragma unroll
         for (int q = 0; q < 8; ++q) pw[q * 64] = give[q];
-        __syncthreads();                                                                                           // B4
+        PBQ_STAMP(6);
+        PBQ_SYNC();                                                                                                // B4
+        PBQ_STAMP(7);
         const float* pr = part + ((((1 - kh) * 4 + pt * 2 + ct) * 8) * 64) + lane;
         const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + pt * 32 + 16 * kh + 4 * half;
         float* r3p = r3 + crow * PITCH + pt * 32 + 16 * kh + 4 * half;
@@ -281,10 +327,18 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
           if (a.x1g) st4(r3p + 8 * ii, v);
         }
       } else {
-        __syncthreads();                                                                                           // B4
+        PBQ_STAMP(6);
+        PBQ_SYNC();                                                                                                // B4
+        PBQ_STAMP(7);
       }
-      __syncthreads();             // B5: the exchange buffer (= the a image) and the dP1 image are free; the gout half tile is complete
-      if (a.x1g) {
+      if (PBQ_VAR & 1) {
+        const int nh = hf == 0 ? 2 * tile + 1 : 2 * (tile + (int)gridDim.x);
+        if (nh < nht && !(PBQ_SKIP & 64)) issue_x(nh, xc, xg);
+      }
+      PBQ_STAMP(8);
+      PBQ_SYNC();                  // B5: the exchange buffer (= the a image) and the dP1 image are free; the gout half tile is complete
+      PBQ_STAMP(9);
+      if (a.x1g && !(PBQ_SKIP & 16)) {
         // ---- row DFT of the gout half tile (waves 8-15): X1[b, row, k, c] = sum_w g[c][w] (tfwd[2k][w] + i tfwd[2k+1][w]) ----
         // job = (16-channel block nt, row segment rr of SEG floats, 16-output block jt); rows of 128 floats span both halves:
         // the first half's sums wait in dcar (same wave, same lanes in both halves)
@@ -326,6 +380,7 @@ __global__ void __launch_bounds__(1024) k_proj_bwd_q(ProjBwdArgs a) {
             }
           }
         }
+        PBQ_STAMP(10);
         // (no barrier: the gout half tile sits in the dP1 image, which the next half tile writes only behind its commit barrier)
       }
     }

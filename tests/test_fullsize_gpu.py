@@ -18,12 +18,13 @@ from tests.util import rel_l2
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-# An ill-conditioned gradient is allowed BUDGET_SLACK x the float32 oracle's own distance from float64.  Why 2 and not 1.25:
-# at RNO2d's full size the distance of EITHER float32 evaluation is set by a handful of ReLU decisions of the regressor within
-# rounding of a tie, upstream of every tensor; over four data sets and two engine compositions the engine / torch ratio is
-# 0.1 - 2.1 with all tensors of a run moving together (profiles/r04_rno_gradient_error_by_seed.txt, DESIGN.md section 4e:
-# every kernel switch, fp32 forward per layer family, mask-decision counts against float64 - no kernel owns the factor).
-BUDGET_SLACK = 2.0
+# An ill-conditioned gradient is allowed BUDGET_SLACK x the float32 oracle's own distance from float64.  Round 4 needed 2.0 for
+# RNO2d: two float evaluations that decide a ReLU input of the regressor within rounding of zero differently differentiate
+# different piecewise-linear functions, and every tensor upstream moves together by ~1e-5.  Round 5
+# compares MASK-CONDITIONED instead: the float64 / float32 oracles take the ENGINE's decisions for the regressor's two
+# spectral layers (oracle/observers_oracle.py::ReluMasks; read off the engine's layer outputs), so all three evaluations
+# differentiate the same function and what is left is arithmetic.
+BUDGET_SLACK = 1.25
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +75,7 @@ def _rounded_inputs(params, x, seed=1):
     return {k: move(v) for k, v in params.items()}, move(x)
 
 
-def _compare(model, y, params, y64, g64, g32, gcond=None):
+def _compare(model, y, params, y64, g64, g32, gcond=None, slack=BUDGET_SLACK):
     """gcond: the float64 gradients of the problem with inputs moved by one float32 rounding (_rounded_inputs); where given,
     the budget of an ill-conditioned gradient is BUDGET_SLACK x the larger of the reference's own float32 error and that
     conditioning floor (the float32 error alone is ONE draw: for the scalar biases of the RNO cell it moved between 4e-6
@@ -89,12 +90,18 @@ def _compare(model, y, params, y64, g64, g32, gcond=None):
         # parameters are held to the floor of the worst-conditioned tensor of the same model
         top = max(floor.values())
         floor = {name: (top if g64[name].size == 1 else f) for name, f in floor.items()}
+    rows = []
     for name, prm in model.named_parameters():
         got = prm.grad
         got = (torch.view_as_real(got) if got.is_complex() else got).detach().cpu().numpy()
         e, e32 = rel_l2(got, g64[name]), floor[name]
-        assert np.isfinite(got).all() and e < max(TOL, BUDGET_SLACK * e32), (name, e, e32)
+        rows.append((name, e, e32, bool(np.isfinite(got).all())))
         worst = max(worst, (name, e), key=lambda t: t[1])
+    # the whole table first (pytest shows it when an assertion below fails; profiles/r05_fullsize_budget_ratios.txt is a copy)
+    for name, e, e32, fin in rows:
+        print(f"  {name:60s} engine {e:.3e}  floor {e32:.3e}  ratio {e / max(e32, 1e-30):5.2f}{'' if e >= TOL else '  (< 1e-5)'}")
+    for name, e, e32, fin in rows:
+        assert fin and e < max(TOL, slack * e32), (name, e, e32)
     print(f"worst gradient vs float64 oracle: {worst[0]} {worst[1]:.2e}")
 
 
@@ -116,23 +123,50 @@ def test_fno2d_config2_fullsize_vs_oracle(dev):
 
 
 def test_rno2d_config3_fullsize_vs_oracle(dev):
-    """BASELINE config 3 as named: RNO2d(12, 12, 64, layer_num 1), 128 x 128, 32 fields per GPU, eval mode (dropout off)."""
+    """BASELINE config 3 as named: RNO2d(12, 12, 64, layer_num 1), 128 x 128, 32 fields per GPU, eval mode (dropout off).
+    Mask-conditioned: the engine runs first, the ReLU decisions of its two spectral regressor layers (output > 0) are imposed on
+    every oracle evaluation (the fused ReLU head never materialises its hidden tensor: its decisions are the oracle's own -
+    tools/relu_flip_check.py counted 0 of 134 M differing from float64)."""
     from pde_policylearning_amd.libs.models.rno_models import RNO2dObserver
     torch.manual_seed(0)
     model = RNO2dObserver(12, 12, 64, 0, layer_num=1).eval()
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
     x = torch.from_numpy(fill_named("c3full.x", (32, 1, 128, 128, 1), 1.0))
     tgt = torch.from_numpy(fill_named("c3full.t", (32, 128, 128, 1), 1.0))
-    fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
-    y64, g64 = _oracle(fwd, params, x, tgt, torch.float64, 8)
-    _, g32 = _oracle(fwd, params, x, tgt, torch.float32, 8)
-    # (the recurrent cell's gradients answer a float32 rounding of the inputs with 2e-5 .. 1e-4: conditioning floor)
-    pr, xr = _rounded_inputs(params, x)
-    _, gcond = _oracle(fwd, pr, xr, tgt, torch.float64, 8)
     model = model.to(dev)
+    masks = {}
+    for j, layer in enumerate(model.regressor.spectral_conv):
+        def wrapped(a, _f=layer.forward_channels_first, _j=j):
+            out = _f(a)
+            masks[f"regressor.spectral_conv.{_j}"] = (out.detach() > 0).permute(0, 2, 3, 1).cpu()      # channels last, as the oracle
+            return out
+        layer.forward_channels_first = wrapped
     y = model(x.to(dev))
     O.lp_loss_rel_sum(y, tgt.to(dev).reshape(y.shape)).backward()
-    _compare(model, y, params, y64, g64, g32, gcond)
+    assert len(masks) == 2, "the regressor did not take the engine's channels-first path"
+
+    def conditioned(prm, xin, dtype):
+        OO.RELU_HOOK = hook = OO.ReluMasks(impose=masks)
+        try:
+            out = _oracle(fwd, prm, xin, tgt, dtype, 8)
+        finally:
+            OO.RELU_HOOK = None
+        return out + (hook,)
+    fwd = lambda p, xc: OO.rno2d_forward(p, xc, 12, 12, 64, 0, 1)
+    y64, g64, hook = conditioned(params, x, torch.float64)
+    flips = {t: int(sum((own != masks[t][8 * i:8 * i + 8]).sum() for i, own in enumerate(seen))) for t, seen in hook.seen.items() if t in masks}
+    print("ReLU decisions of the engine that differ from the float64 oracle's own:", flips, "of", {t: m.numel() for t, m in masks.items()})
+    _, g32, _ = conditioned(params, x, torch.float32)
+    # (the recurrent cell's gradients answer a float32 rounding of the inputs with 2e-5 .. 1e-4: conditioning floor)
+    pr, xr = _rounded_inputs(params, x)
+    _, gcond, _ = conditioned(pr, xr, torch.float64)
+    # Measured in round 5 with the masks imposed (profiles/r05_fullsize_budget_ratios.txt): the engine's decisions differ from
+    # float64's own in 3 + 2 of 2 x 33.5 M, and every tensor sits between 1.0 and 1.59 x its floor (regressor 1.5-1.6, cell
+    # 1.3-1.5; floors 1.0e-5 .. 2.8e-4) where the unconditioned comparison of round 4 saw up to 2.07 x on other data sets.  So
+    # the ReLU ties were part of it, not all: what is left moves every tensor TOGETHER (a coherent ~2e-5 against the float32
+    # oracle's ~1.2e-5), i.e. one float32 draw against another of a quantity whose float32 rounding floor is itself above
+    # 1e-5.  1.75 here (2.0 in round 4), 1.25 for the FNO models.
+    _compare(model, y, params, y64, g64, g32, gcond, slack=1.75)
 
 
 def test_fno3d_config4_fullsize_vs_oracle(dev):
@@ -173,7 +207,7 @@ def test_training_gradients_are_bitwise_repeatable(dev, which):
         run = lambda: model(x)
     elif which == "fno3d_cfg4":
         model = FNO3d(8, 8, 8, 32, in_channels=3, out_channels=1).to(dev)
-        x = torch.from_numpy(fill_named("rep.x", (8, 3, 64, 64, 64), 1.0)).to(dev)
+        x = torch.from_numpy(fill_named("rep.x", (16, 3, 64, 64, 64), 1.0)).to(dev)      # the full per-GPU batch of config 4
         run = lambda: model(x)
     elif which == "rno2d_cfg3":
         model = RNO2d(12, 12, 64, 0, layer_num=1).to(dev).eval()      # (eval: the regressor's dropout draws a new mask per call)

@@ -21,7 +21,7 @@ def _t(a, grad=False):
     return t.requires_grad_(True) if grad else t
 
 
-@pytest.mark.parametrize("case", ["A2d", "A2d_ortho_odd", "A2d_backward", "A3d"])
+@pytest.mark.parametrize("case", ["A2d", "A2d_ortho_odd", "A2d_backward", "A3d", "A2d_overlap"])
 def test_specconv_A(case):
     g = load_golden("specconv_" + case)
     meta = [int(v) for v in g["meta"]]
@@ -41,6 +41,11 @@ def test_specconv_A(case):
     for i in range(nw):
         assert rel_l2(torch.view_as_real(ws[i].grad), g["grads"][f"weight.{nw * idx + i}.tensor"]) < TOL
     assert rel_l2(bias.grad, g["grads"]["bias"]) < TOL
+    if case == "A2d_overlap":
+        # 2 * half_modes[0] = 12 > H = 8: rows 2..5 belong to both corners and take the SECOND corner's product, the first
+        # corner's weights get no gradient from them (spectral_convolution.py:330-337: in-order slice assignment) - the oracle
+        # restates the assignment order; the closed-form backward below assumes disjoint corners and the engine rejects the shape
+        return
     # hand-derived backward formulas agree with autograd
     dx2, dws2 = O.spectral_conv_A_backward(x.detach(), [w.detach() for w in ws], _t(g["dy"]),
                                            [m // 2 for m in n_modes], norm)

@@ -222,6 +222,10 @@ def _fno_params(C, L, half_modes, cin=3, cout=1, seed_tag="p"):
     return {k: torch.from_numpy(fill_named(seed_tag + k, s, sc[k])) for k, s in shapes.items()}
 
 
+# Round 5 tried 1.25: five cases sit between 1.26 and 1.87 x the float32 oracle's own distance on tensors where that distance is
+# itself above 1e-5 (dead-mode spectral weights, the 1e-6-scaled input: profiles/r05_hostile_errors.txt and
+# r05_fullsize_budget_ratios.txt hold every achieved number).  On such tensors both float32 evaluations are draws of a
+# conditioned quantity; the engine's split-precision GEMMs are ~1.5 x noisier there than torch's CPU float32, never 2 x.
 BUDGET_SLACK = 2.0
 
 
