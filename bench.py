@@ -91,8 +91,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r04_pmc_traffic.json"
-PMC_SQ_CSV = "r04_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r05_pmc_traffic.json"
+PMC_SQ_CSV = "r05_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 def source_hash():

@@ -28,7 +28,7 @@ fi
 [ "$quick" = "bench" ] && exit 0
 prof() {   # prof <name> <bench args...>: kernel-trace stats of one workload
   local name=$1; shift
-  $T rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_$name -- python3 bench.py "$@" --no-cpu-baseline > $out/${tag}_stats_$name.log 2>&1
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_$name -- python3 bench.py "$@" --no-cpu-baseline --no-exact-fp32 > $out/${tag}_stats_$name.log 2>&1
   cp $(ls $out/${tag}_stats_$name/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats_$name.csv
   echo "stats $name done" >> $out/${tag}_progress.log
 }
@@ -41,7 +41,7 @@ prof rno2d --config rno2d_128x128_w64_m12_b32 --steps 10 --warmup 3
 prof pino_finetune_256 --config pino_finetune_256x256x65_w64_m20_b1 --steps 5 --warmup 2
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 > /dev/null 2>&1
+  $T rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --profile-steps 0 > /dev/null 2>&1
   cp $(ls $out/${tag}_pmc_$c/*/*counter_collection.csv | head -1) $out/${tag}_pmc_$(echo $c | tr A-Z a-z).csv
   echo "pmc $c done" >> $out/${tag}_progress.log
 done
@@ -50,10 +50,15 @@ i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAVES"; do
   i=$((i+1))
-  $T rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/${tag}_pmc_sq$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0 > /dev/null 2>&1
+  $T rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/${tag}_pmc_sq$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --profile-steps 0 > /dev/null 2>&1
   echo "pmc sq$i done" >> $out/${tag}_progress.log
 done
 python3 tools/pmc_sq.py $out/${tag}_pmc_sq1 $out/${tag}_pmc_sq2 > $out/${tag}_pmc_sq.csv 2>> $out/${tag}_bench.err
+# the matrix-core arm of the mode contraction (three launches per block and direction, k_mode_gemm on v_mfma_f32_32x32x2_f32):
+# SQ_INSTS_MFMA / pipe-busy of k_mode_gemm at the headline workload (bench.py reports the arm's step time as mode_contraction.mfma_arm)
+FNO_NO_FUSED_MID=1 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_sq3 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --profile-steps 0 > /dev/null 2>&1
+python3 tools/pmc_sq.py $out/${tag}_pmc_sq3 > $out/${tag}_pmc_sq_mfma_arm.csv 2>> $out/${tag}_bench.err
+echo "pmc mfma arm done" >> $out/${tag}_progress.log
 # the raw rocprofv3 trees are large: keep the summaries only
-rm -rf $out/${tag}_stats_* $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_pmc_sq1 $out/${tag}_pmc_sq2 2>/dev/null
+rm -rf $out/${tag}_stats_* $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_pmc_sq1 $out/${tag}_pmc_sq2 $out/${tag}_pmc_sq3 2>/dev/null
 tail -c 400 $out/${tag}_bench.json
