@@ -228,3 +228,46 @@ def test_train_observer_yaml_rno_sequences_vs_oracle(dev, tmp_path, monkeypatch)
             test = float(loss_of(16, 20))
         assert abs(hist[ep]["train_l2"] - tot / 8) < 2e-4 * (tot / 8), (ep, hist[ep], tot / 8)
         assert abs(hist[ep]["test_l2"] - test / 2) < 2e-4 * (test / 2), (ep, hist[ep], test / 2)
+
+
+def test_backward_survives_relocated_saved_buffer(dev):
+    """The forward pass records what it left in its `saved` buffer (u_0 skipped by the fused lifting, magnitude bounds published)
+    under the buffer's ADDRESS (csrc/fno_abi.hip FnoModelPlan::CallState).  autograd may hand the buffer back at another address
+    (saved_tensors_hooks: offload, checkpoint repack): the backward must then still know that u_0 was never written - block 0 would
+    read uninitialised memory otherwise - and fall back to the kernels that need no published bounds.  Every gradient
+    against the undisturbed pass; config 2's shape, where the lifting IS fused and the two-term GEMMs ARE on."""
+    from oracle.detfill import fill_named
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    torch.manual_seed(0)
+    model = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev)
+    x = torch.from_numpy(fill_named("reloc.x", (8, 3, 128, 128), 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("reloc.t", (8, 1, 128, 128), 1.0)).to(dev)
+
+    def grads(relocate):
+        model.zero_grad(set_to_none=True)
+        if relocate:
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone(), lambda t: t):
+                y = model(x)
+        else:
+            y = model(x)
+        O.lp_loss_rel_sum(y, tgt).backward()
+        return y.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    y0, g0 = grads(False)
+    y1, g1 = grads(True)
+    assert torch.equal(y0, y1)
+    for n in g0:
+        a, b = g1[n].double(), g0[n].double()
+        assert torch.isfinite(a).all() and float((a - b).norm() / b.norm()) < 5e-6, n
+
+
+def test_opt_in_projection_backward_arm_matches_default():
+    """k_proj_bwd_q (csrc/k_projection3.h: 16 waves, four per SIMD; FNO_PBWD_Q=1) is an A/B arm that the default never runs: every
+    gradient of a config-2-shaped step from a process with the switch against one without (tools/pbq_check.py; the switch is read
+    once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pbq_check.py"), "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "k_proj_bwd per launch" in r.stdout

@@ -264,3 +264,29 @@ def test_chanflow_rhs_and_pde_loss_golden(tag):
         assert abs(float(loss.detach()) - float(g[f"loss_{dn}"])) < 10 * tol * abs(float(g[f"loss_{dn}"]))
         loss.backward()
         assert rel_l2(V.grad.reshape(-1)[::stride].numpy(), g[f"gradV_{dn}"]) < 10 * tol, dn
+
+
+def test_relu_mask_hook_records_and_imposes():
+    """oracle/observers_oracle.py::ReluMasks (the mask-conditioned RNO comparison of tests/test_fullsize_gpu.py): recorded
+    decisions equal `pre > 0`; imposed decisions replace the oracle's own in value and gradient, consecutive calls taking
+    consecutive sample ranges."""
+    from oracle import observers_oracle as OO
+    t = torch.tensor([[-1.0, 2.0], [3.0, -4.0], [0.5, -0.5], [-2.0, 1.0]], requires_grad=True)
+    rec = OO.ReluMasks()
+    OO.RELU_HOOK = rec
+    try:
+        assert torch.equal(OO._relu("a", t[:2]), torch.relu(t[:2])) and torch.equal(OO._relu("a", t[2:]), torch.relu(t[2:]))
+    finally:
+        OO.RELU_HOOK = None
+    assert torch.equal(torch.cat(rec.seen["a"]), t > 0)
+    forced = torch.tensor([[True, False], [False, True], [True, True], [False, False]])
+    imp = OO.ReluMasks(impose={"a": forced})
+    OO.RELU_HOOK = imp
+    try:
+        out = torch.cat([OO._relu("a", t[:2]), OO._relu("a", t[2:])])
+    finally:
+        OO.RELU_HOOK = None
+    assert torch.equal(out, t.detach() * forced)
+    out.sum().backward()
+    assert torch.equal(t.grad, forced.float())
+    assert torch.equal(OO._relu("a", t.detach()), torch.relu(t.detach()))      # hook removed: plain ReLU again
