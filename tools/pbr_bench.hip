@@ -2,13 +2,24 @@
 // (64 samples x 64 channels x 128 x 128): random operands, HIP-event time per launch, and with -DPBQ_TRACE the average cycles
 // between the phase stamps of workgroup 0 per wave.  Results are NOT checked here (tools/pbq_check.py does that through the
 // library).   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DPBQ_TRACE] tools/pbq_bench.hip -o /tmp/pbq_bench && /tmp/pbq_bench
+#ifdef USE_R3
+#include "experiments/k_proj_bwd_roles3.h"
+#else
 #include "experiments/k_proj_bwd_roles.h"
-#ifndef USE_T
+#endif
+#if defined(USE_R3)
+#define KERN k_proj_bwd_r3<256, false>
+#define KNAME "k_proj_bwd_r3 (two vector + one matrix wave per SIMD)"
+#define NTHREADS 768
+#elif !defined(USE_T)
 #define KERN k_proj_bwd_r<256, false>
 #define KNAME "k_proj_bwd_r"
 #else
 #define KERN k_proj_bwd_t<64, 256, false, 2>
 #define KNAME "k_proj_bwd_t"
+#endif
+#ifndef NTHREADS
+#define NTHREADS 512
 #endif
 #include <cstdio>
 #include <cstring>
@@ -48,18 +59,20 @@ int main(int argc, char** argv) {
   a.wa1 = wa1; a.wa3 = wa3;
   a.PW = PW; a.W = W; a.P = P; a.K2out = K2; a.NJ = NJ; a.CO = 1; a.act_in = 0;
   a.tiles_per_plane = PW / 128; a.ntiles = B * a.tiles_per_plane;
-  #ifdef USE_T
+  #if defined(USE_R3)
+  const size_t lds = proj_bwd_r3_lds(W, NJ, true);
+#elif defined(USE_T)
   const size_t lds = (size_t)2 * C * 256 + 2 * 2 * 64 * 256 + 128 * 4 + (size_t)16 * NJ * (W + 4) * 4;      // pbwd_t_lds (fno_abi.hip)
 #else
   const size_t lds = proj_bwd_r_lds(W, NJ, true);
 #endif
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((KERN), dim3(grid), dim3(512), lds, 0, a);
+  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((KERN), dim3(grid), dim3(NTHREADS), lds, 0, a);
   CK(hipDeviceSynchronize());
   const int N = 20;
   hipEventRecord(e0);
-  for (int it = 0; it < N; ++it) hipLaunchKernelGGL((KERN), dim3(grid), dim3(512), lds, 0, a);
+  for (int it = 0; it < N; ++it) hipLaunchKernelGGL((KERN), dim3(grid), dim3(NTHREADS), lds, 0, a);
   hipEventRecord(e1);
   CK(hipDeviceSynchronize());
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -67,9 +80,9 @@ int main(int argc, char** argv) {
 
 #ifdef PBR_TRACE
   {
-    std::vector<unsigned long long> tr(8 * 8 * 8 * 4);
+    std::vector<unsigned long long> tr(12 * 8 * 8 * 4);
     CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_pbr), tr.size() * 8));
-    for (int w : {0, 3, 4, 7}) {
+    for (int w : {0, 3, 4, 7, NTHREADS / 64 - 1}) {
       printf("wave %d (%s):\n", w, w < 4 ? "matrix" : "vector");
       for (int t = 2; t < 5; ++t) {
         const unsigned long long* r = &tr[((w * 8 + t) * 8) * 4];
