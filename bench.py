@@ -392,10 +392,19 @@ def main():
     if args.gpus != world and not force_dist:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU path)"
+    # FNO_BENCH_ONE_DEVICE=1 + FNO_BENCH_BACKEND=gloo: every rank on device 0, gloo instead of RCCL - a self-test of the WHOLE N > 1
+    # flow (probe of the exchange arms, timed blocks, extra arms, profiled steps with their collectives) on a one-GPU box, where RCCL
+    # cannot place two ranks; the numbers of such a run mean nothing
+    backend = os.environ.get("FNO_BENCH_BACKEND", "nccl")
+    if os.environ.get("FNO_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pde_policylearning_amd import _lib
     from pde_policylearning_amd.neuralop.models import FNO2d, FNO3d
@@ -565,7 +574,7 @@ def main():
                 mb = [float(v) for v in tm.tolist()]
             mm = sorted(mb)[1]
             arm = {}
-            if rank == 0 and args.profile_steps > 0:
+            if args.profile_steps > 0:       # (every rank runs the profiled steps: they contain the gradient exchange)
                 Lb.fno_profile_reset(); Lb.fno_profile_enable(1)
                 for _ in range(2 * args.profile_steps):
                     eager_step()
@@ -604,7 +613,8 @@ def main():
     # ---- per-kernel timing with HIP events on the launch stream (separate profiled steps) ----
     roofline = None
     kernels = []
-    if rank == 0 and args.profile_steps > 0:
+    # (every rank runs the profiled steps - for N > 1 they contain the collective of the gradient exchange; rank 0 reports)
+    if args.profile_steps > 0:
         L = _lib.lib()
         L.fno_profile_reset()
         L.fno_profile_enable(1)
@@ -757,7 +767,8 @@ def main():
             "value_max": round(B * world * args.steps / min(blocks), 2),
             "ms_per_step_all": [round(1e3 * b / args.steps, 4) for b in blocks],
             "n_ranks": dist.get_world_size() if dist_on else 1,      # RCCL ranks seen by torch.distributed
-            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist_on else None,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist_on and backend == "nccl" else None,
+            "backend": backend if dist_on else None,
             "allreduce_ms_total": exchange[0] if exchange else None,
             "allreduce_ms_exposed": exchange[1] if exchange else None,
             "gradient_exchange": {"bucket_bytes": 4 * bucket.flat.numel(), "wire_bytes_per_rank_per_step": bucket.planned_wire_bytes(),
