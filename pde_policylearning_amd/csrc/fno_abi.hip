@@ -567,11 +567,13 @@ static int plane_rc(int nrest) { int rc = 64; while (rc > 8 && rc / 2 >= nrest) 
 static size_t plane_blocks(const Geom& g, int Cin, int Cout, int nrest, int rc) {
   return (size_t)(1 << g.nlead) * g.Klast * ((Cin + 7) / 8) * ((Cout + 7) / 8) * ((nrest + rc - 1) / rc);
 }
+// zero64 (or null): kNAmax bound slots to clear before anything behind this launch runs (the tiled kernel does it itself)
 static int pack_w_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const CornerPtrsL& cp, int L, float* wp, float* wpt,
-                         size_t stride) {
+                         size_t stride, float* zero64 = nullptr) {
   const ModeMap mm = make_modemap(g, Cin, Cout);
   const int nrest = nrest_of(g);
   if (g.w_planes) {
+    if (zero64 && hipMemsetAsync(zero64, 0, 64 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
     const int rc = plane_rc(nrest);
     const size_t blocks = plane_blocks(g, Cin, Cout, nrest, rc);
     if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight pack grid too large");
@@ -583,7 +585,7 @@ static int pack_w_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const
   const size_t blocks = (size_t)(1 << g.nlead) * nrest * (Cin / ti);
   if (blocks > 0x7fffffffull) return fail(FNO_EUNSUPPORTED, "weight pack grid too large");
   return launch("k_pack_w", k_pack_w_tiled, dim3((unsigned)blocks, L), dim3(256), (size_t)ti * Cout * (g.wl_stride + 1) * 8, st, cp,
-                (float2*)wp, (float2*)wpt, mm, stride / 2, nrest, ti);
+                (float2*)wp, (float2*)wpt, mm, stride / 2, nrest, ti, zero64);
 }
 static int unpack_dw_layers(hipStream_t st, const Geom& g, int Cin, int Cout, const float* dwp, const CornerPtrsMutL& cp, int L,
                             size_t stride) {
@@ -952,6 +954,7 @@ struct FnoModelPlan {
     bool h2_fwd = false;         // max |u_L| was published behind the saved tensors (two-term fp16 projection / block backward)
     bool h2_u0 = false;          // ... and the bound of |u_0| (fused lifting)
     bool gchain_valid = false;   // the last backward part left max |g| of its output gradient (amax[32 + l_lo])
+    bool bwd_clean = false;      // the forward cleared all bound slots and no backward pass has written its range [32, 64) since
   };
   mutable std::mutex call_mu;
   mutable std::vector<std::pair<const void*, CallState>> calls;      // most recent last; capped (kMaxCalls)
@@ -1520,7 +1523,9 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   // the bound bookkeeping (one more launch, the weight scans in the prologues) costs more than three matrix products
   // save (BASELINE config 1, 128 tiles: 0.27 -> 0.22 ms per step without it)
   const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= FNO_MAX_LAYERS && (size_t)B * g.PW >= ((size_t)1 << 17);
-  if (h2 && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
+  static_assert(kNAmax == 64, "k_pack_w_tiled clears 64 slots");
+  // cleared by the weight pack's first workgroup (the first launch of the pass), by a fill when that kernel is not the one that runs
+  if (h2 && g_pack_flat && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
   {
     CornerPtrsL cp;
     memset(&cp, 0, sizeof(cp));
@@ -1530,7 +1535,8 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     const size_t n = (size_t)g.Ktot * C * C;
     // the matrix-core adjoint reads wps; the fused middle's adjoint streams the transposed copy
     if (!g_pack_flat)
-      LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) && !fused_mid_shape_ok(g, C) ? nullptr : wpts, s.n_wp));
+      LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) && !fused_mid_shape_ok(g, C) ? nullptr : wpts, s.n_wp,
+                              h2 ? amax : nullptr));
     else
     LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
                      (float2*)wps, (float2*)wpts, mm, n));
@@ -1607,6 +1613,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   pa.tiles_per_plane = g.PW / 128; pa.ntiles = B * pa.tiles_per_plane;
   pa.xmax = (h2 && L > 0) ? amax + 8 + L : nullptr;
   cs.h2_fwd = pa.xmax != nullptr;
+  cs.bwd_clean = h2;
   cs.h2_u0 = h2 && lift_xmax && g_h2;
   p->put_call(saved, cs);
   const int pgrid = std::min(pa.ntiles, FNO_GRID_PF * p->ncu);
@@ -1707,16 +1714,28 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   // the start of the pass (round 3 issued five small ones per step; the forward's memset of all 64 slots is the other one)
   float* amax = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
   float* bwd_b = amax + 59;
-  bool db2_done = false;
+  bool db2_done = false, w1_packed = false;
   const bool h2 = g_gemm_x3 && g_h2 && use_pbwd_t(C, d.Cout, p->NPX) && cs.h2_fwd;      // (this buffer's forward published max |u_L|)
   // cleared whenever ANY slot of the range is written in this pass: the projection's scalars (h2) or the chain of gradient
   // bounds the layer loop hands out (same condition as there) - a second backward on the same `saved` must not keep the first one's
   const bool chain = g_gemm_x3 && g_h2 && cs.h2_fwd && L <= 24;
-  if ((h2 || chain) && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
+  // (not after a forward that has just cleared all 64 slots: one 4.5 us fill less per step; a second backward on the same
+  // `saved`, or an unknown buffer, clears)
+  if ((h2 || chain) && !(cs_found && cs.bwd_clean) && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess)
+    return fail(FNO_EHIP, "memset of the magnitude bounds");
   if (h2) {
     // (one output channel: the same launch leaves 256 partial sums of dy = the bias gradient's partial slabs; k_channel_sums
     // below is then not launched)
     db2_done = d.Cout == 1;
+    // the scan and the split of W1 into its two fp16 terms share a launch (FNO_SPLIT_PROLOGUE=1: the two launches of round 4)
+    static const int split_prologue = getenv("FNO_SPLIT_PROLOGUE") ? 1 : 0;
+    if (!split_prologue) {
+      const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;
+      LAUNCHCHK(launch("k_absmax", k_absmax3_pack_w1, dim3(256 + 8 + 1 + (nitems + 255) / 256), dim3(256), 0, st, dy,
+                       (size_t)B * d.Cout * g.PW, 256, prm->proj_w1, 8, prm->proj_w2, (size_t)d.Cout * kHID, 1, bwd_b + 1,
+                       db2_done ? w.db2_part : nullptr, w.wa1, w.wa3, kHID, C));
+      w1_packed = true;
+    } else
     LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
                      (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, bwd_b + 1, db2_done ? w.db2_part : nullptr));
     pb.amax = bwd_b; pb.xmax = amax + 8 + L;
@@ -1726,7 +1745,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     gvalid = true;
   }
   if (g_gemm_x3) {
-    LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? bwd_b + 2 : nullptr));
+    if (!w1_packed) LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? bwd_b + 2 : nullptr));
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
@@ -1754,6 +1773,19 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     float* t = gnext; gnext = gspare; gspare = t;
   }
   const int ks = bbwd_ksplit(p);
+  auto unpack_spec_grads = [&](hipStream_t su) -> int {      // packed dW of this part's layers -> the corner gradients
+    CornerPtrsMutL cp;
+    memset(&cp, 0, sizeof(cp));
+    for (int l = l_lo; l <= l_hi; ++l)
+      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l - l_lo][c] = (float2*)gr->spec_w[l][c];
+    const ModeMap mm = make_modemap(g, C, C);
+    size_t per = (size_t)g.modes[0] * g.wl_stride;
+    if (g.nlead == 2) per *= g.modes[1];
+    const size_t n = (size_t)(1 << g.nlead) * C * C * per;
+    if (!g_pack_flat) return unpack_dw_layers(su, g, C, C, w.dwp + (size_t)l_lo * s.n_wp, cp, l_hi - l_lo + 1, s.n_wp);
+    return launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), l_hi - l_lo + 1), dim3(256),
+                  0, su, (const float2*)(w.dwp + (size_t)l_lo * s.n_wp), cp, mm, (size_t)g.Ktot * C * C);
+  };
   static const int no_batch_dw = getenv("FNO_NO_BATCH_DW") ? 1 : 0;       // A/B switch: one weight-gradient contraction per layer
   const bool batch_dw = !no_batch_dw && l_hi > l_lo && mode_gemm_members_ok(C, C) && g_mode_mfma &&
                         !(g_mode_gemv && B <= 4 && (long)g.Ktot * C * C >= (1L << 21));
@@ -1810,6 +1842,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     { float* t = gnext; gnext = gspare; gspare = t; }
   }
   cs.gchain_valid = gvalid;
+  cs.bwd_clean = false;
   p->put_call(saved, cs);
   if (dx && has_lift && l_lo == 0) {      // dL/dx = W_l^T dL/du_0 (gcur is block 0's output gradient after the rotation)
     const size_t n4 = (size_t)B * g.PW / 4;
@@ -1820,21 +1853,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     LAUNCHCHK(mode_gemm_dw(st, hats + (size_t)l_lo * s.n_hat, w.ohat + (size_t)l_lo * s.n_hat, w.dwp + (size_t)l_lo * s.n_wp, B,
                            g.Ktot, C, C, l_hi - l_lo + 1, s.n_hat, s.n_hat, s.n_wp));
   LAUNCHCHK(jobs.run(st));
-  {
-    CornerPtrsMutL cp;
-    memset(&cp, 0, sizeof(cp));
-    for (int l = l_lo; l <= l_hi; ++l)
-      for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l - l_lo][c] = (float2*)gr->spec_w[l][c];
-    const ModeMap mm = make_modemap(g, C, C);
-    size_t per = (size_t)g.modes[0] * g.wl_stride;
-    if (g.nlead == 2) per *= g.modes[1];
-    const size_t n = (size_t)(1 << g.nlead) * C * C * per;
-    if (!g_pack_flat) LAUNCHCHK(unpack_dw_layers(st, g, C, C, w.dwp + (size_t)l_lo * s.n_wp, cp, l_hi - l_lo + 1, s.n_wp));
-    else
-    LAUNCHCHK(launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), l_hi - l_lo + 1), dim3(256),
-                     0, st, (const float2*)(w.dwp + (size_t)l_lo * s.n_wp), cp, mm, (size_t)g.Ktot * C * C));
-  }
-  return FNO_OK;
+  return unpack_spec_grads(st);
 }
 
 // ===========================================================================

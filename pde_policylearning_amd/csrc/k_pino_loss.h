@@ -17,6 +17,11 @@
 
 FNO_DEV float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 FNO_DEV void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The thread index as a value the optimiser cannot see through: what is derived from it INSIDE the loop over the five derived
+// fields (grid offsets, bit-reversed wave numbers, the multiplier's kx / ky / lap of 16 items per thread at 128 x 128) is
+// then recomputed per field instead of being hoisted out of the loop and kept live across it - that hoisting is what spilled
+// 248 / 572 bytes per lane at the 128 registers a 16-wave workgroup gets (round 4 register table).
+FNO_DEV int opaque_tid(int tid) { asm volatile("" : "+v"(tid)); return tid; }
 
 // N-point FFTs of the N lines `G + line * line_stride` (elements `elem_stride` apart) by NWV waves.
 // tw[k] = exp(-2 pi i k / N), k < N/2.
@@ -25,9 +30,15 @@ FNO_DEV void fft_lines(float2* G, int line_stride, int elem_stride, const float2
   constexpr int LPL = N / 2;            // butterflies (lanes) per line
   constexpr int LW = 64 / LPL;          // lines per wave pass
   static_assert(LW >= 1, "N <= 128");
-  const int j = lane % LPL, sub = lane / LPL;
+  const int sub = lane / LPL;
+  // (N = 128: the butterfly offsets of all seven stages are the same for every line; hoisted out of the line loop they hold ~25
+  // registers per direction for the whole kernel, which has 128 per lane - the lane's butterfly index is made opaque per line so that
+  // they are recomputed per line: a handful of integer operations beside four LDS accesses per stage)
+  const int jl = lane % LPL;
   for (int line = wave * LW + sub; line < N; line += NWV * LW) {
     float2* L = G + line * line_stride;
+    int j = jl;
+    if (N >= 128) asm volatile("" : "+v"(j));
     if (!INVERSE) {
 #pragma unroll
       for (int h = N / 2; h >= 1; h >>= 1) {
@@ -76,14 +87,12 @@ FNO_DEV float2 pino_mult(int f, int ix, int iy) {
   const float ky = (float)(jy < N / 2 ? jy : jy - N);
   float lap = kx * kx + ky * ky;
   if (jx == 0 && jy == 0) lap = 1.0f;
-  float re = 0.f, im = 0.f;
-  switch (f) {
-    case 0: im = ky / lap; break;
-    case 1: im = kx; break;
-    case 2: im = -kx / lap; break;
-    case 3: im = ky; break;
-    default: re = -lap; break;
-  }
+  // branch-free in f (uniform selects): the switch over f inside the fully unrolled per-thread loops was unswitched into ~400
+  // basic blocks per kernel.  Same values: the numerator is exactly +-kx or ky, the quotient the same division.
+  const float cx = f == 1 ? 1.f : (f == 2 ? -1.f : 0.f), cy = (f == 0 || f == 3) ? 1.f : 0.f;      // (uniform: scalar registers)
+  const float num = fmaf(cx, kx, cy * ky);                       // exactly +-kx, ky or 0: one of the coefficients is zero
+  const float im = num / ((f == 0 || f == 2) ? lap : 1.0f);      // (x / 1 is x: no branch around the division)
+  const float re = f == 4 ? -lap : 0.f;
   return make_float2(re, ext ? -im : im);
 }
 template <int N>
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(PinoCfg<N>::NT) k_pino_plane_fwd(PinoArgs a) {
     sincospif(-2.0f * (float)k / (float)N, &sn, &cs);      // exact argument (k / N is dyadic)
     tw[k] = make_float2(cs, sn);
   }
-  float acc[PPT], wre[PPT], wim[PPT], keep[PPT];
+  float acc[PPT], wre[PPT], wim[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int e = tid + NT * j, x = e / N, y = e % N;
@@ -141,22 +150,26 @@ __global__ void __launch_bounds__(PinoCfg<N>::NT) k_pino_plane_fwd(PinoArgs a) {
 #pragma unroll 1
   for (int f = 0; f < 5; ++f) {
     __syncthreads();
+    const int tf = opaque_tid(tid);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      const int e = tid + NT * j, p = e / N, q = e % N;
+      const int e = tf + NT * j, p = e / N, q = e % N;
       const float2 m = pino_mult<N>(f, brev_n<N>(p), brev_n<N>(q));
       G[p * P + q] = cmulf(m, make_float2(wre[j], wim[j]));
+      if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four items' temporaries in flight, not sixteen
     }
     __syncthreads();
     fft2_grid<N, true, NWV>(G, tw, wave, lane);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      const int e = tid + NT * j;
+      const int e = tf + NT * j;
       const float val = G[(e / N) * P + e % N].x * inv_n2;
-      if (f < 4) a.fields[(size_t)f * np + (size_t)plane * N * N + e] = val;
-      if (f == 0 || f == 2) keep[j] = val;                 // u_x, u_y
-      else if (f == 1 || f == 3) acc[j] = fmaf(keep[j], val, acc[j]);   // + u_x w_x, + u_y w_y
-      else acc[j] = fmaf(-nu, val, acc[j]);                // - nu lap(w)
+      float* fo = a.fields + (size_t)plane * N * N + e;
+      if (f < 4) fo[(size_t)f * np] = val;
+      // u_x / u_y of the step before come back from the field array this thread has just written (a register array carried
+      // across the loop became a 16-wide vector value the allocator spilled wholesale: 1144 bytes per lane)
+      if (f == 1 || f == 3) acc[j] = fmaf(fo[(size_t)(f - 1) * np], val, acc[j]);   // + u_x w_x, + u_y w_y
+      else if (f == 4) acc[j] = fmaf(-nu, val, acc[j]);    // - nu lap(w)
     }
   }
   float ss = 0.f;
@@ -196,32 +209,37 @@ __global__ void __launch_bounds__(PinoCfg<N>::NT) k_pino_plane_bwd(PinoArgs a) {
   }
   const float gs = a.coef_f[b] * (a.g_f ? a.g_f[0] : 1.0f);
   const float nu = a.visc[b];
-  float g[PPT], dre[PPT], dim_[PPT];
+  // (g = gs * residual is re-read with every field's partner instead of living in 16 more registers per thread across the
+  // loop: the 128 x 128 instantiation has 128 registers per lane and spilled exactly this array)
+  float dre[PPT], dim_[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    g[j] = gs * a.fields[(size_t)4 * np + (size_t)plane * N * N + tid + NT * j];
-    dre[j] = 0.f; dim_[j] = 0.f;
-  }
+  for (int j = 0; j < PPT; ++j) { dre[j] = 0.f; dim_[j] = 0.f; }
 #pragma unroll 1
   for (int f = 0; f < 5; ++f) {
     __syncthreads();
     // dL/dfield_f: u_x <- g w_x, w_x <- g u_x, u_y <- g w_y, w_y <- g u_y, lap w <- -nu g
     const int partner = f ^ 1;
+    const int tf = opaque_tid(tid);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      const int e = tid + NT * j;
-      const float gy = f < 4 ? g[j] * a.fields[(size_t)partner * np + (size_t)plane * N * N + e] : -nu * g[j];
+      const int e = tf + NT * j;
+      const float* fp = a.fields + (size_t)plane * N * N + e;
+      const float gj = gs * fp[(size_t)4 * np];
+      const float pv = fp[(size_t)(partner & 3) * np];      // (always a load, of a valid field: no branch per item; unused at f = 4)
+      const float gy = gj * (f < 4 ? pv : -nu);
       G[(e / N) * P + e % N] = make_float2(gy, 0.f);
+      if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     fft2_grid<N, false, NWV>(G, tw, wave, lane);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      const int e = tid + NT * j, p = e / N, q = e % N;
+      const int e = tf + NT * j, p = e / N, q = e % N;
       float2 m = pino_mult<N>(f, brev_n<N>(p), brev_n<N>(q));
       m.y = -m.y;
       const float2 v = cmulf(m, G[p * P + q]);
       dre[j] += v.x; dim_[j] += v.y;
+      if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four items' temporaries in flight, not sixteen
     }
   }
   __syncthreads();

@@ -18,12 +18,10 @@
 //   wb3[(((ch*4 + kb)*MT + cb)*3 + t)*64 + lane][j] = term t of W1[ch*64 + kb*16 + 8*(lane>>5) + j][cb*32 + (lane&31)]
 // NTERM = 2: two fp16 terms of h2_scale(*wmax) * W1 (fno_dev.h "h2"; wmax = device scalar max |W1|, k_absmax)
 template <int NTERM>
-__global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
-                            int HID, int C, const float* __restrict__ wmax) {
+FNO_DEV void pack_w1_t_item(const float* __restrict__ w1, unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
+                            int HID, int C, float sw, int it) {
   const int KB = C / 16, MT = C / 32;
   const int n1 = (HID / 32) * KB * 64, n3 = (HID / 16) * MT * 64;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  const float sw = NTERM == 2 ? h2_scale(*wmax) : 1.f;
   float v[8];
   bf16x8 f[NTERM];
   if (it < n1) {
@@ -45,17 +43,23 @@ __global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __rest
     for (int t = 0; t < NTERM; ++t) st8h(dst + t * 64 * 8, f[t]);
   }
 }
+template <int NTERM>
+__global__ void k_pack_w1_t(const float* __restrict__ w1, unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
+                            int HID, int C, const float* __restrict__ wmax) {
+  const float sw = NTERM == 2 ? h2_scale(*wmax) : 1.f;
+  pack_w1_t_item<NTERM>(w1, wa1, wb3, HID, C, sw, blockIdx.x * blockDim.x + threadIdx.x);
+}
 // max |x| of three arrays in one launch -> dst[0..2] (atomic max of the float pattern; zeroed by the caller): blocks
 // [0, g0) scan x0, [g0, g0 + g1) x1, the rest x2
 // sum0 (or null): the blocks of job 0 also leave the SUM of their share of x0 in sum0[block] (g0 partial sums, fixed order:
 // the bias gradient of a one-channel projection is the sum of dy, and this launch reads dy anyway)
-__global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
-                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst, float* __restrict__ sum0) {
+FNO_DEV void absmax3_block(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
+                           const float* __restrict__ x2, size_t n2, int g2, float* __restrict__ dst, float* __restrict__ sum0) {
   const int bi = blockIdx.x;
   const int job = bi < g0 ? 0 : (bi < g0 + g1 ? 1 : 2);
   const float* x = job == 0 ? x0 : (job == 1 ? x1 : x2);
   const size_t n = job == 0 ? n0 : (job == 1 ? n1 : n2);
-  const int b0 = job == 0 ? 0 : (job == 1 ? g0 : g0 + g1), nb = job == 0 ? g0 : (job == 1 ? g1 : (int)gridDim.x - g0 - g1);
+  const int b0 = job == 0 ? 0 : (job == 1 ? g0 : g0 + g1), nb = job == 0 ? g0 : (job == 1 ? g1 : g2);
   float m = 0.f, sm = 0.f;
   if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // 16-byte loads, four in flight per thread (the scalar
     const size_t n4 = n / 4, stride = (size_t)nb * blockDim.x;             // loop was 16 dependent 4-byte loads: 21 us per launch)
@@ -92,6 +96,43 @@ __global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const
     float r = threadIdx.x < nw ? wm[threadIdx.x] : 0.f;
     absmax_publish(r, dst + job);
   }
+}
+__global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
+                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst, float* __restrict__ sum0) {
+  absmax3_block(x0, n0, g0, x1, n1, g1, x2, n2, (int)gridDim.x - g0 - g1, dst, sum0);
+}
+// k_absmax3 and k_pack_w1_t<2> in ONE launch (round 5: two ~5 us launches at the head of every backward pass): blocks
+// [0, g0 + g1 + g2) are k_absmax3's, the rest split x1 = W1 (HID x C) into its two fp16 terms.  The split needs max |W1|, which
+// the scan blocks of the same launch are still producing: every split block takes the maximum over W1 itself (64 KB out of
+// L2, 16 loads per thread) - the same float the scan publishes in dst[1], so the kernels that read the bound see the scale
+// the fragments were made with.
+__global__ void __launch_bounds__(256) k_absmax3_pack_w1(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ w1,
+                                                         int g1, const float* __restrict__ x2, size_t n2, int g2,
+                                                         float* __restrict__ dst, float* __restrict__ sum0,
+                                                         unsigned short* __restrict__ wa1, unsigned short* __restrict__ wb3,
+                                                         int HID, int C) {
+  const int nscan = g0 + g1 + g2;
+  if ((int)blockIdx.x < nscan) {
+    absmax3_block(x0, n0, g0, w1, (size_t)HID * C, g1, x2, n2, g2, dst, sum0);
+    return;
+  }
+  float m = 0.f;
+  const int n4 = HID * C / 4;                        // (C is 32 or 64: whole float4s)
+  if ((reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const float4 a = ld4(w1 + 4 * i);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    }
+  } else {                                           // a parameter that is a view at an odd offset of a flat bucket
+    for (int i = threadIdx.x; i < 4 * n4; i += 256) m = fmaxf(m, fabsf(w1[i]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wmx[4];
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+  pack_w1_t_item<2>(w1, wa1, wb3, HID, C, h2_scale(m), ((int)blockIdx.x - nscan) * 256 + threadIdx.x);
 }
 
 // C = 32: the dx product's K (hidden rows) is split between the two wave groups (wave (hm, nt) contracts over rows

@@ -272,8 +272,11 @@ FNO_DEV int tile_mode_base(const ModeMap& mm, int corner, int rest) {        // 
   }
   return (rest + corner * mm.m[0]) * mm.K[1];
 }
+// zero64 (or null): 64 floats cleared by the first workgroup - the magnitude-bound slots the kernels BEHIND this launch publish
+// into (one fill launch less per forward pass)
 __global__ void __launch_bounds__(256) k_pack_w_tiled(CornerPtrsL cw, float2* __restrict__ wp, float2* __restrict__ wpt,
-                                                      ModeMap mm, size_t stride, int nrest, int TI) {
+                                                      ModeMap mm, size_t stride, int nrest, int TI, float* __restrict__ zero64) {
+  if (zero64 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;
   // TI consecutive input channels per workgroup: the transposed copy wpt[k][o][i] is then written in TI * 8-byte pieces
   // (whole 64-byte sectors at TI = 8) instead of lone 8-byte elements
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1265,6 +1268,11 @@ __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ 
 // of L2, then 25 MB of HBM writes, ~9 + 6 + 4 us with nothing overlapping: 29 us per launch against 32 us for the three
 // separate launches (rocprofv3; ~4.5 us of each launch is the fixed cost of a launch on this stack).  What it buys is
 // launches: BASELINE config 1 (launch-bound, hipGraph) runs 0.217 instead of 0.255 ms per step.
+// Round 5: the complex multiply-adds of the three phases as two v_pk_fma_f32 each (table entry broadcast through op_sel on
+// src0, bit-identical results) change nothing - phase 1 14.0-14.9 k cycles against 14.4-14.6 k, contraction 12.5-14.4 k
+// against 14.3-16 k, phase 3 7.3 k against 7.1 k, the launch 33.0 against 31.7 us on one box (HIP events): phases 1 and 3
+// wait for HBM (50 MB in ~9 us), the contraction for L2 (151 MB of weight rows in ~6 us = 25 TB/s); none of them for the
+// vector unit.  The scalar form stays.
 //   block (64, 8), grid (inner / 64, samples), LDS (8 + 2) * NK * 64 float2
 #ifndef FNO_MID_SKIP
 #define FNO_MID_SKIP 0        // timing experiments: 1 = no contraction, 2 = no phase 1 loads, 4 = no phase 3

@@ -868,6 +868,21 @@ def shard_batch(t, rank, world):
     return t[rank * per:(rank + 1) * per]
 
 
+_UNIT_GRADS = {}
+
+
+def _unit_gradient(loss):
+    """The implicit gradient of `loss.backward()` (ones_like of a scalar loss), kept per device and dtype; None (= torch's
+    own default) for anything that is not a scalar."""
+    if loss.dim() != 0:
+        return None
+    key = (loss.device, loss.dtype)
+    g = _UNIT_GRADS.get(key)
+    if g is None:
+        g = _UNIT_GRADS[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return g
+
+
 def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None):
     """zero_grad -> forward -> decode -> loss -> backward -> all-reduce -> optimizer step
     (run_pde_observers.py:185-193).  Returns the local loss tensor (no host sync)."""
@@ -889,7 +904,9 @@ def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=Non
         else:
             tgt = target
         loss = loss_fn(pred, tgt)
-    loss.backward()
+    # `loss.backward()` with the unit gradient it would build handed in: torch fills a fresh ones_like(loss) per call (one
+    # 4.7 us fill kernel per step on the measured stack); the same values, no launch
+    loss.backward(_unit_gradient(loss))
     bucket.all_reduce()
     if optimizer is not None:
         optimizer.step()
