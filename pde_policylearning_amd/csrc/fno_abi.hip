@@ -1556,7 +1556,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
     static const int lift_dft_lin = getenv("FNO_NO_LIFT_ROWDFT") ? 0 : 1;      // A/B switch
-    const size_t lds_lr = ((size_t)2 * g.Klast * (g.W + 1) + (size_t)LR_ROWS * d.Cin * (g.W + 1) + 2) * 4 + (size_t)LR_ROWS * g.Klast * (d.Cin + 1) * 8;
+    const size_t lds_lr = ((size_t)2 * g.Klast * (g.W + 4) + (size_t)LR_ROWS * d.Cin * (g.W + 4) + 2) * 4 + (size_t)LR_ROWS * g.Klast * (d.Cin + 1) * 8;
     if (lift_dft_lin && cs.u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
       // u_0 is never stored: only its row spectra are needed, and those are linear in the <= 4 input channels
       const int nrows = B * g.P;

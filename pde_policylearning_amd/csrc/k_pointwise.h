@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
                                                      float2* __restrict__ x1, int CL, int C, int PW, int W, int P, int K2,
                                                      int nrows, float* __restrict__ xmax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int WP = W + 1;                               // row pitch: threads of a wave read different rows at the same w
+  const int WP = W + 4;                               // row pitch: threads of a wave read different rows at the same w, four
+                                                      // floats per read (rows 4 banks apart: 8 lanes cover the 32 banks)
   float* ts = smem;                                   // [2 K2][WP]
   float* xs = ts + 2 * K2 * WP;                       // [LR_ROWS][CL][WP]
   float2* xh = reinterpret_cast<float2*>(xs + ((LR_ROWS * CL * WP + 1) & ~1));     // [LR_ROWS][K2][CL + 1]: spectra; entry CL = sum of the table row
@@ -503,10 +504,16 @@ __global__ void __launch_bounds__(256) k_lift_rowdft(const float* __restrict__ x
     if (k < CL) {
       const float* xr = xs + (r * CL + k) * WP;
       float sr2 = 0.f, si2 = 0.f;                       // two chains: the sums are latency-bound otherwise
-#pragma unroll 8
-      for (int w = 0; w < W; w += 2) {
-        sr = fmaf(xr[w], tr[w], sr); si = fmaf(xr[w], ti[w], si);
-        if (w + 1 < W) { sr2 = fmaf(xr[w + 1], tr[w + 1], sr2); si2 = fmaf(xr[w + 1], ti[w + 1], si2); }
+      // 16-byte LDS reads (round 5: the stage was bound by LDS issue - three 4-byte reads per product pair); W is a multiple
+      // of 32 on this path.  Same products in the same two chains (even / odd w) as before.
+#pragma unroll 4
+      for (int w = 0; w < W; w += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + w), tv = *reinterpret_cast<const float4*>(tr + w),
+                     uv = *reinterpret_cast<const float4*>(ti + w);
+        sr = fmaf(xv.x, tv.x, sr); si = fmaf(xv.x, uv.x, si);
+        sr2 = fmaf(xv.y, tv.y, sr2); si2 = fmaf(xv.y, uv.y, si2);
+        sr = fmaf(xv.z, tv.z, sr); si = fmaf(xv.z, uv.z, si);
+        sr2 = fmaf(xv.w, tv.w, sr2); si2 = fmaf(xv.w, uv.w, si2);
       }
       sr += sr2; si += si2;
     } else {
