@@ -176,6 +176,23 @@ FNO_DEV void gelu_pairs(f32x2 (&x)[NP], float six, float inf) {
     x[p][1] = __builtin_fmaf(-__builtin_fabsf(x[p][1]), r[p][1], __builtin_amdgcn_fmed3f(x[p][1], 0.0f, inf));
   }
 }
+// gelu_pairs' arithmetic on ONE value with scalar fp32 instructions (same operations in the same order: bit-identical).  Eleven
+// instructions per value where the packed form spends 7.5 - but scalar fp32 instructions run beside another wave's matrix
+// products and packed ones do not, so a kernel with many independent waves per SIMD (k_proj_fwd_w: six,
+// no barrier) hides its products behind this form.
+FNO_DEV float gelu_s(float x, float six, float inf) {
+  const float ax = __builtin_fabsf(x);
+  const float s = __builtin_amdgcn_fmed3f(ax, 0.0f, six);
+  float r = __builtin_fmaf(s, 6.119213594502071e-06f, -3.2478157663717866e-05f);
+  r = __builtin_fmaf(s, r, -0.0004947108100168407f);
+  r = __builtin_fmaf(s, r, 0.0075082844123244286f);
+  r = __builtin_fmaf(s, r, -0.052784692496061325f);
+  r = __builtin_fmaf(s, r, -0.4591203033924103f);
+  r = __builtin_fmaf(s, r, -1.1511149406433105f);
+  r = __builtin_fmaf(s, r, -0.9999998211860657f);
+  r = __builtin_amdgcn_exp2f(r);
+  return __builtin_fmaf(-ax, r, __builtin_amdgcn_fmed3f(x, 0.0f, inf));
+}
 FNO_DEV void gelu8(float (&v)[8], float six, float inf) {
   f32x2 x[4] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, f32x2{v[4], v[5]}, f32x2{v[6], v[7]}};
   gelu_pairs<4>(x, six, inf);

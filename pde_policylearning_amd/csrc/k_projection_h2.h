@@ -232,6 +232,15 @@ __device__ unsigned long long g_pfw_trace[64 * 16 * 4];
 // the old 8-wave tile kernel: 176 us); ONE 16-wave workgroup per CU with an LDS work queue is balanced but slower (159-174 us:
 // four waves per SIMD); eight global work queues (returning atomics on eight addresses) serialise: 465 us.  The chip holds
 // 1.9-2.0 GHz inside this kernel where the 8-wave kernels hold 2.3-2.4 (denser issue, MI355X_MICROARCH.md DVFS item 4).
+// Round 5: this is the one kernel of the engine whose waves are independent (six per SIMD, no barrier), so at any moment some
+// of a SIMD's waves are in their products and some in their vector phase - and on gfx950 SCALAR fp32 vector instructions run
+// beside another wave's products while packed ones serialise with them.  With the hidden activation
+// (gelu_s: 11 instructions per value against 7.5 packed) and the column's own activation + split in scalar form the launch takes
+// 0.1606 ms against 0.1742 (level 1, hidden activation only: 0.1679; six interleaved runs each on one box, +-0.0005) - more
+// instructions, hidden behind the matrix pipe.  Same operations in the same order: bit-identical results.
+#ifndef FNO_PFW_SCALAR_ACT
+#define FNO_PFW_SCALAR_ACT 2      // 0 = packed forms (A/B arm), 1 = scalar hidden activation, 2 = + scalar input activation and split
+#endif
 template <int C, int HID, int NWAVE>
 __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArgs a) {
   FNO_CLK_ENTRY();
@@ -299,7 +308,6 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
 
   const int cols_per_plane = a.PW / 32, ncols = a.ntiles * 4;
   const unsigned PWb = (unsigned)a.PW * 4u;
-  const float b2v = a.b2[0];
 #ifdef PFW_TRACE      // diagnostic build: where a wave's cycles go (stamps cost an s_waitcnt lgkmcnt(0) each)
   unsigned long long tr_load = 0, tr_mfma = 0, tr_valu = 0, tr_cols = 0, tr_t = __builtin_readcyclecounter(), tr_n;
   const unsigned long long tr_k2 = tr_t;
@@ -333,8 +341,21 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = buf_ld1(rx, voff, (unsigned)(16 * kb + j) * PWb);
+#if FNO_PFW_SCALAR_ACT >= 2      // the column's own activation and split with scalar instructions too
+      if (a.act_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_s(v[j], gk_six, gk_inf);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sv = v[j] * sx;
+        const _Float16 hh = (_Float16)sv;
+        bfrag[kb][0][j] = hh; bfrag[kb][1][j] = (_Float16)(sv - (float)hh);
+      }
+#else
       if (a.act_in) gelu8(v, gk_six, gk_inf);
       split2x8(v, sx, bfrag[kb][0], bfrag[kb][1]);
+#endif
     }
 #ifdef PFW_TRACE
     asm volatile("" :: "v"(bfrag[KB - 1][1]));
@@ -361,6 +382,22 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
       // D[row = hidden 32 ch + (r & 3) + 8 (r >> 2) + 4 half][col = pixel l31]
       const float* b1p = b1s + ch * 32 + 4 * half;
       const float* w2p = w2s + ch * 32 + 4 * half;
+#if FNO_PFW_SCALAR_ACT
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {            // four values at a time (the scalar form's temporaries: 80 registers per wave)
+        float hv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * q + k;
+          hv[k] = gelu_s(fmaf(acc[r] + lo[r], inv, b1p[(r & 3) + 8 * (r >> 2)]), gk_six, gk_inf);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * q + k;
+          ysum = fmaf(w2p[(r & 3) + 8 * (r >> 2)], hv[k], ysum);
+        }
+      }
+#else
 #pragma unroll
       for (int q = 0; q < 2; ++q) {            // eight values at a time: half the live temporaries of the packed GELU
         f32x2 hp[4];
@@ -378,13 +415,15 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
           ysum = fmaf(w2p[((r + 1) & 3) + 8 * ((r + 1) >> 2)], hp[k][1], ysum);
         }
       }
+#endif
 #ifdef PFW_TRACE
       asm volatile("" :: "v"(ysum));
 #endif
       PFW_STAMP(tr_valu);
     }
     ysum += __shfl_xor(ysum, 32, 64);
-    if (half == 0) a.y[(size_t)b * a.PW + px0 + l31] = ysum + b2v;
+    if (half == 0) a.y[(size_t)b * a.PW + px0 + l31] = ysum + a.b2[0];      // (a scalar load per column: held in a register across the
+                                                                              // column loop it was the kernel's one spill)
 #ifdef PFW_TRACE
     ++tr_cols;
 #endif
