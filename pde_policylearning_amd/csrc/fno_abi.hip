@@ -1200,7 +1200,9 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
   const PwFwdArgs& a = a_in;
   // profile label: block 0 with the lifting recomputed reads the <= 4-channel model input instead of u_0 (bench.py prices it so)
   const char* nm = a_in.lw ? "k_pw_fwd_block0" : "k_pw_fwd_block";
-  if (blk_fwd_t_ok<C>(p, a_in, &lds2)) {
+  // (64 channels only: blk_fwd_t_ok refuses 32, where k_pw_fwd_x3 measured faster - `if constexpr` so that the 33 instantiations
+  // nothing can launch are not compiled: tools/kernel_coverage.py, round 5)
+  if constexpr (C == 64) if (blk_fwd_t_ok<C>(p, a_in, &lds2)) {
     const dim3 g2(std::min(a.ntiles, (g_grid_bf2 > 0 ? g_grid_bf2 : (C == 64 ? 2 : 3)) * p->ncu)), blk((C / 32) * 2 * 64);
     const int epi = a.x1 ? (a.act_out ? 2 : 1) : 0;
     // two workgroups per CU: the one dispatched first gets the larger share of the CU's tiles (pair_share, fno_dev.h)

@@ -237,7 +237,10 @@ __device__ unsigned long long g_pfw_trace[64 * 16 * 4];
 // beside another wave's products while packed ones serialise with them.  With the hidden activation
 // (gelu_s: 11 instructions per value against 7.5 packed) and the column's own activation + split in scalar form the launch takes
 // 0.1606 ms against 0.1742 (level 1, hidden activation only: 0.1679; six interleaved runs each on one box, +-0.0005) - more
-// instructions, hidden behind the matrix pipe.  Same operations in the same order: bit-identical results.
+// instructions, hidden behind the matrix pipe.  Same operations in the same order: bit-identical results.  A MIX of the forms
+// (three or two of a chunk's four groups of hidden values scalar, the rest packed) is slower than all-scalar: 0.1678 / 0.1690
+// against 0.1646 ms on one box - every packed instruction holds the matrix pipe off.  Issue priorities (none, or raised
+// around the products instead of alternating per column): 0.1654 / 0.1674 against 0.1650.
 #ifndef FNO_PFW_SCALAR_ACT
 #define FNO_PFW_SCALAR_ACT 2      // 0 = packed forms (A/B arm), 1 = scalar hidden activation, 2 = + scalar input activation and split
 #endif
