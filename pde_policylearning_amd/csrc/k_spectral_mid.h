@@ -1274,6 +1274,10 @@ __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ 
 // wait for HBM (50 MB in ~9 us), the contraction for L2 (151 MB of weight rows in ~6 us = 25 TB/s); none of them for the
 // vector unit.  The scalar form stays.
 //   block (64, 8), grid (inner / 64, samples), LDS (8 + 2) * NK * 64 float2
+#ifndef FNO_MID_SMEM_TABLE
+#define FNO_MID_SMEM_TABLE 1      // 1 = DFT table rows through scalar loads (round 5; up to 12 kept modes: 16 need more scalar
+                                  // registers than a wave has); 0 = staged in LDS, broadcast reads (A/B arm)
+#endif
 #ifndef FNO_MID_SKIP
 #define FNO_MID_SKIP 0        // timing experiments: 1 = no contraction, 2 = no phase 1 loads, 4 = no phase 3
 #endif
@@ -1281,16 +1285,34 @@ __global__ void __launch_bounds__(256) k_channel_sums(const float* __restrict__ 
 #define MID_STAMP(slot) do { if (blockIdx.x == 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0) \
     g_trace[threadIdx.y * 256 + (slot)] = __builtin_readcyclecounter(); \
     if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0 && ((slot) == 0 || (slot) == 7)) \
-    g_trace[8 * 256 + blockIdx.y * 2 + ((slot) == 7)] = __builtin_readcyclecounter(); } while (0)
+    g_trace[8 * 256 + blockIdx.y * 2 + ((slot) == 7)] = __builtin_readcyclecounter(); \
+    if (blockIdx.x == 1 && threadIdx.x == 0 && threadIdx.y == 0 && blockIdx.y < 64) /* every sample's workgroup 1, wave 0: all stamps */ \
+    g_trace[10 * 256 + blockIdx.y * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MID_STAMP(slot) do { } while (0)
 #endif
+template <bool B> struct MidFlag { static constexpr bool value = B; };
+// acc += w * v as complex numbers, w UNIFORM (a table entry in a scalar register pair): two packed FMAs with the factor taken
+// from the pair's low / high word through op_sel on src0 (SGPR sources and src0 selections are outside the gfx950 hazard:
+// fno_dev.h).  vs = (-v.y, v.x).  Same products in the same order as four scalar FMAs: bit-identical.
+template <bool SREG>
+FNO_DEV void cfma_uniform(f32x2& acc, float2 w, f32x2 v, f32x2 vs) {
+  if constexpr (SREG) {
+    const f32x2 wp = {w.x, w.y};
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wp), "v"(v));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wp), "v"(vs));
+  } else {
+    acc[0] = fmaf(w.x, v[0], acc[0]); acc[0] = fmaf(w.y, vs[0], acc[0]);
+    acc[1] = fmaf(w.x, v[1], acc[1]); acc[1] = fmaf(w.y, vs[1], acc[1]);
+  }
+}
 template <int NK, int C>
 __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ x1, float2* __restrict__ hat,
                                                      const float2* __restrict__ wm, float2* __restrict__ z,
                                                      const float2* __restrict__ twT, const float2* __restrict__ twi, int n,
                                                      int inner, int K2, int conj_w, int Bm, size_t w_ms) {
   static_assert(C == 32 || C == 64, "whole bins per workgroup");
+  constexpr bool SREG = FNO_MID_SMEM_TABLE && NK <= 12;      // table rows in scalar registers
   constexpr int SEGS = 8, JW = C / SEGS, NTH = 64 * SEGS;
   constexpr int RB = 2, NG = NK / RB;               // RB modes' weight rows per load group, double-buffered
   static_assert(NK % RB == 0, "mode groups");
@@ -1307,9 +1329,12 @@ __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ 
   const int k2 = q / C, ch = q - k2 * C, lb = (ql / C) * C;     // lb: first lane of this lane's bin
   const float2* wb = wm + (size_t)(o / Bm) * w_ms + ((size_t)k2 * C + seg * JW) * C + ch;
   MID_STAMP(0);
-  // Table rows are the same for every lane.  Through the scalar cache a wave waits ~1000 cycles per row (measured with
-  // the stamps: 16 rows = 16 k cycles, the register budget leaves no room to run ahead); as broadcast LDS reads they pipeline.
-  for (int i = tid; i < n * NK; i += NTH) sh[i] = twT[i];
+  // Table rows are the same for every lane.  Round 2 staged them in LDS (through the scalar cache, one row at a time, a wave
+  // waited ~1000 cycles per row); round 5 found what that costs: a broadcast ds_read_b64 still occupies the LDS unit for four
+  // cycles, 192 of them per wave and phase = 12 k cycles per phase on the CUs that hold two workgroups - the phases were bound
+  // by LDS issue, which is why halving their vector instructions alone changed nothing.  Now a row's NK entries come through
+  // scalar loads one row AHEAD of their use (2 x NK scalar register pairs), and the multiply-adds are packed.
+  if constexpr (!SREG) for (int i = tid; i < n * NK; i += NTH) sh[i] = twT[i];
   // the first weight group does not depend on phase 1: in flight from here on
   float2 wv[2][RB][JW];
   auto load_w = [&](int g, int buf) {
@@ -1321,9 +1346,9 @@ __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ 
   if (!(FNO_MID_SKIP & 1)) load_w(0, 0);
   // ---- phase 1 ----
   {
-    float2 acc[NK];
+    f32x2 acc[NK];
 #pragma unroll
-    for (int r = 0; r < NK; ++r) acc[r] = make_float2(0.f, 0.f);
+    for (int r = 0; r < NK; ++r) acc[r] = f32x2{0.f, 0.f};
     const float2* src = x1 + (size_t)o * n * inner + q;
     // 16 rows per lane in flight (two batches of 8) before the first use: one HBM round trip for n <= 128
     constexpr int NBR = 16;
@@ -1335,26 +1360,50 @@ __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ 
         const int nn = nb + SEGS * j;
         v[j] = (nn < n && !(FNO_MID_SKIP & 2)) ? src[(size_t)nn * inner] : make_float2(0.f, 0.f);
       }
+      if constexpr (SREG) {
+      (void)first;
+      // (GUARD: whether rows beyond n exist in this batch.  Without the per-row branch the batch is ONE basic block and the
+      // scalar loads of row j + 1 stay in flight under row j's multiply-adds; with it every row's loads are waited for at the
+      // block boundary in front of them)
+      auto rows = [&](auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+        float2 tw[2][NK];                                 // row nb and the next one: uniform addresses, scalar loads
+#pragma unroll
+        for (int r = 0; r < NK; ++r) tw[0][r] = twT[(size_t)min(nb, n - 1) * NK + r];
+#pragma unroll
+        for (int j = 0; j < NBR; ++j) {
+          const int nn = nb + SEGS * j;
+          if (j + 1 < NBR) {
+#pragma unroll
+            for (int r = 0; r < NK; ++r) tw[(j + 1) & 1][r] = twT[(size_t)(GUARD ? min(nn + SEGS, n - 1) : nn + SEGS) * NK + r];
+          }
+          if (!GUARD || nn < n) {
+            const f32x2 vv = {v[j].x, v[j].y}, vs = natural_pair(-v[j].y, v[j].x);
+#pragma unroll
+            for (int r = 0; r < NK; ++r) cfma_uniform<true>(acc[r], tw[j & 1][r], vv, vs);
+          }
+        }
+      };
+      if (nb + SEGS * (NBR - 1) < n) rows(MidFlag<false>{}); else rows(MidFlag<true>{});
+      } else {
       if (first) { __syncthreads(); first = false; }      // the table is staged (n >= 1: every wave passes here once)
 #pragma unroll
       for (int j = 0; j < NBR; ++j) {
         const int nn = nb + SEGS * j;
         if (nn < n) {
           const float2* t = sh + nn * NK;
+          const f32x2 vv = {v[j].x, v[j].y}, vs = natural_pair(-v[j].y, v[j].x);
 #pragma unroll
-          for (int r = 0; r < NK; ++r) {
-            const float2 w = t[r];
-            acc[r].x = fmaf(w.x, v[j].x, acc[r].x); acc[r].x = fmaf(-w.y, v[j].y, acc[r].x);
-            acc[r].y = fmaf(w.x, v[j].y, acc[r].y); acc[r].y = fmaf(w.y, v[j].x, acc[r].y);
-          }
+          for (int r = 0; r < NK; ++r) cfma_uniform<false>(acc[r], t[r], vv, vs);
         }
       }
+      }
     }
-    if (first) __syncthreads();
+    if constexpr (!SREG) { if (first) __syncthreads(); }
     MID_STAMP(1);
-    __syncthreads();                                    // every wave is done reading the table
+    if constexpr (!SREG) __syncthreads();               // every wave is done reading the table
 #pragma unroll
-    for (int r = 0; r < NK; ++r) sh[(seg * NK + r) * 64 + ql] = acc[r];
+    for (int r = 0; r < NK; ++r) sh[(seg * NK + r) * 64 + ql] = make_float2(acc[r][0], acc[r][1]);
   }
   __syncthreads();
   MID_STAMP(2);
@@ -1399,27 +1448,58 @@ __global__ void __launch_bounds__(512, 4) k_spec_mid(const float2* __restrict__ 
     os[r * 64 + ql] = make_float2(sx, sy);
   }
   __syncthreads();
-  for (int i = tid; i < n * NK; i += NTH) sh[i] = twi[i];
-  __syncthreads();
+  if constexpr (!SREG) {
+    for (int i = tid; i < n * NK; i += NTH) sh[i] = twi[i];
+    __syncthreads();
+  }
   MID_STAMP(6);
   // ---- phase 3 ----
   if (!(FNO_MID_SKIP & 4))
   {
-    float2 v[NK];
+    f32x2 v[NK], vs[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) v[k] = os[k * 64 + ql];
+    for (int k = 0; k < NK; ++k) {
+      const float2 t = os[k * 64 + ql];
+      v[k] = f32x2{t.x, t.y};
+      vs[k] = natural_pair(-t.y, t.x);
+    }
     float2* dst = z + (size_t)o * n * inner + q;
+    if constexpr (SREG) {
+    // two rows of the table, ping-pong (static names: no indexed register array); PAIRS: this wave's row count is even, the
+    // loop body is one basic block and a row's scalar loads stay in flight under the row before it
+    auto rows3 = [&](auto pairs) {
+      constexpr bool PAIRS = decltype(pairs)::value;
+      float2 ta[NK], tb[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) ta[k] = twi[(size_t)min(seg, n - 1) * NK + k];
+      for (int r = seg; r < n; r += 2 * SEGS) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) tb[k] = twi[(size_t)(PAIRS ? r + SEGS : min(r + SEGS, n - 1)) * NK + k];
+        f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NK; ++k) cfma_uniform<true>(s2, ta[k], v[k], vs[k]);
+        dst[(size_t)r * inner] = make_float2(s2[0], s2[1]);
+        if (PAIRS || r + SEGS < n) {
+#pragma unroll
+          for (int k = 0; k < NK; ++k) ta[k] = twi[(size_t)min(r + 2 * SEGS, n - 1) * NK + k];
+          f32x2 s3 = {0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < NK; ++k) cfma_uniform<true>(s3, tb[k], v[k], vs[k]);
+          dst[(size_t)(r + SEGS) * inner] = make_float2(s3[0], s3[1]);
+        }
+      }
+    };
+    const int nrows3 = seg < n ? (n - seg + SEGS - 1) / SEGS : 0;
+    if ((nrows3 & 1) == 0) rows3(MidFlag<true>{}); else rows3(MidFlag<false>{});
+    } else {
 #pragma unroll 2
     for (int r = seg; r < n; r += SEGS) {
       const float2* t = sh + r * NK;
-      float sr = 0.f, si = 0.f;
+      f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const float2 w = t[k];
-        sr = fmaf(w.x, v[k].x, sr); sr = fmaf(-w.y, v[k].y, sr);
-        si = fmaf(w.x, v[k].y, si); si = fmaf(w.y, v[k].x, si);
-      }
-      dst[(size_t)r * inner] = make_float2(sr, si);
+      for (int k = 0; k < NK; ++k) cfma_uniform<false>(s2, t[k], v[k], vs[k]);
+      dst[(size_t)r * inner] = make_float2(s2[0], s2[1]);
+    }
     }
   }
   MID_STAMP(7);

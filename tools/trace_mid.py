@@ -25,3 +25,19 @@ for w in range(8):
 se = [(buf[8 * 256 + 2 * y], buf[8 * 256 + 2 * y + 1]) for y in range(64)]
 t0 = min(a for a, b in se)
 print("workgroup (0, y): start / end  " + " ".join(f"{a - t0}/{b - t0}" for a, b in se[::4]))
+
+d = sorted(b - a for a, b in se)
+print("durations of workgroup (0, y), cycles: min %d  median %d  max %d   (n = %d)" % (d[0], d[len(d) // 2], d[-1], len(d)))
+
+# every sample's workgroup (1, y), wave 0: cycles per phase, sorted by total (the workgroups that share a CU are the slow ones)
+rows = []
+for y in range(64):
+    st = [buf[10 * 256 + y * 8 + i] for i in range(8)]
+    if st[7] > st[0] > 0:
+        rows.append((st[7] - st[0], [st[i + 1] - st[i] for i in range(7)]))
+rows.sort()
+for name, sel in (("fastest quarter", rows[:len(rows) // 4]), ("slowest quarter", rows[-(len(rows) // 4):])):
+    if sel:
+        n = len(sel)
+        print(f"workgroups (1, y), {name} (n = {n}): total {sum(r[0] for r in sel) // n:6d}  phases " +
+              " ".join(f"{sum(r[1][i] for r in sel) // n:6d}" for i in range(7)))
