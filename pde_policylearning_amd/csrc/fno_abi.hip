@@ -1723,7 +1723,10 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   const bool chain = g_gemm_x3 && g_h2 && cs.h2_fwd && L <= 24;
   // (not after a forward that has just cleared all 64 slots: one 4.5 us fill less per step; a second backward on the same
   // `saved`, or an unknown buffer, clears)
-  if ((h2 || chain) && !(cs_found && cs.bwd_clean) && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess)
+#ifndef FNO_DEBUG_NO_BWD_FILL      // (debug builds of the detector test: 1 = never clear - tests/test_boundary_gpu.py must then fail)
+#define FNO_DEBUG_NO_BWD_FILL 0
+#endif
+  if (!FNO_DEBUG_NO_BWD_FILL && (h2 || chain) && !(cs_found && cs.bwd_clean) && hipMemsetAsync(amax + 32, 0, 32 * sizeof(float), st) != hipSuccess)
     return fail(FNO_EHIP, "memset of the magnitude bounds");
   if (h2) {
     // (one output channel: the same launch leaves 256 partial sums of dy = the bias gradient's partial slabs; k_channel_sums

@@ -260,6 +260,57 @@ def test_backward_survives_relocated_saved_buffer(dev):
         assert torch.isfinite(a).all() and float((a - b).norm() / b.norm()) < 5e-6, n
 
 
+def test_second_backward_on_one_forward_resets_the_bounds(dev):
+    """A forward pass clears the 64 magnitude-bound slots behind its `saved` buffer and the FIRST backward pass on that buffer
+    skips its own fill of slots [32, 64) (round 5: one launch less per step, csrc/fno_abi.hip CallState::bwd_clean).  A second
+    backward on the same forward (retain_graph) must clear them again: its dy is 1e-6 of the first one's here, and with the first
+    pass's bounds left in place the two-term fp16 operands of the whole gradient chain would be scaled a million times too small
+    (second terms in the fp16 subnormals).  The step is linear in dy: every gradient of the second pass against 1e-6 times the
+    first pass's, at config 2's shape (two-term GEMMs on, lifting fused)."""
+    from oracle.detfill import fill_named
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    torch.manual_seed(0)
+    model = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev)
+    x = torch.from_numpy(fill_named("twice.x", (8, 3, 128, 128), 1.0)).to(dev)
+    dy = torch.from_numpy(fill_named("twice.dy", (8, 1, 128, 128), 1.0)).to(dev)
+    y = model(x)
+    y.backward(dy, retain_graph=True)
+    g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    y.backward(1e-6 * dy)
+    for n, p in model.named_parameters():
+        a, b = p.grad.double(), 1e-6 * g1[n].double()
+        assert torch.isfinite(a).all() and float((a - b).norm() / b.norm()) < 1e-5, (n, float((a - b).norm() / b.norm()))
+
+
+def test_projection_weight_at_an_unaligned_address(dev):
+    """Parameters may be views into a flat bucket (trainer.FusedAdam): W1 of the projection then starts at an address that is
+    not a multiple of 16 bytes.  The backward's prologue (k_absmax3_pack_w1: the scan of dy / W1 / w2 and the two-term split of
+    W1 in one launch, round 5) reads W1 with 16-byte loads when it can and element-wise when it cannot - same bound, same
+    fragments: every gradient bitwise equal to the aligned case."""
+    from oracle.detfill import fill_named
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    torch.manual_seed(0)
+    model = FNO2d(12, 12, 64, in_channels=3, out_channels=1).to(dev)
+    x = torch.from_numpy(fill_named("unal.x", (8, 3, 128, 128), 1.0)).to(dev)
+    tgt = torch.from_numpy(fill_named("unal.t", (8, 1, 128, 128), 1.0)).to(dev)
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        O.lp_loss_rel_sum(model(x), tgt).backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    g0 = grads()
+    w = model.projection.fc1.weight
+    assert w.data_ptr() % 16 == 0
+    flat = torch.empty(w.numel() + 1, dtype=w.dtype, device=dev)
+    flat[1:].copy_(w.detach().reshape(-1))
+    w.data = flat[1:].view_as(w)                 # 4 bytes past a 16-byte boundary
+    assert w.data_ptr() % 16 == 4
+    g1 = grads()
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
 def test_opt_in_projection_backward_arm_matches_default():
     """k_proj_bwd_q (csrc/k_projection3.h: 16 waves, four per SIMD; FNO_PBWD_Q=1) is an A/B arm that the default never runs: every
     gradient of a config-2-shaped step from a process with the switch against one without (tools/pbq_check.py; the switch is read
