@@ -281,37 +281,44 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
           mfma_split_s<NT3>(af, wf[kb], hi, lo);
           __builtin_amdgcn_sched_barrier(0);      // keep at most one k block of operand fragments live
         }
+        // (pairs: with the SLP vectorizer off - build.py - element-wise source is element-wise code; the accumulator registers
+        // are consecutive, so the pairs are natural ones.  Round 5: the vector phase's bookkeeping around the GELU by hand on pairs)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = NT3 == 2 ? (hi[r] + lo[r]) * inv_aw : hi[r] + lo[r];
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 sm = f32x2{hi[r], hi[r + 1]} + f32x2{lo[r], lo[r + 1]};
+          if (NT3 == 2) sm = sm * f32x2{inv_aw, inv_aw};
+          acc[r] = sm[0]; acc[r + 1] = sm[1];
+        }
       }
       load_wb3(ch);            // the dx product's fragments arrive while the GELU phase runs
       if (ch == 1) FNO_STAMP(tslot + 4);
       // ---- E: lane <-> hidden row; registers <-> pixels n0 + (r&3) + 8 (r>>2) + 4 half ------------------------------------
       {
-        float sdb = 0.f, sdw = 0.f;
+        f32x2 sdb = {0.f, 0.f}, sdw = {0.f, 0.f};      // even / odd pixels; added at the end of the chunk
         const int hrow = hm * 32 + l31;
+        const f32x2 b1p = {b1v, b1v}, w2p = {w2v, w2v};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 dy4 = ld4(douts + n0 + 8 * i + 4 * half);
-          const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
-          float dp[4];
-          float4 glv = make_float4(acc[4 * i] + b1v, acc[4 * i + 1] + b1v, acc[4 * i + 2] + b1v, acc[4 * i + 3] + b1v), dgv;
-          if constexpr (RELU) {
-            dgv = make_float4(glv.x > 0.f ? 1.f : 0.f, glv.y > 0.f ? 1.f : 0.f, glv.z > 0.f ? 1.f : 0.f, glv.w > 0.f ? 1.f : 0.f);
-            glv = make_float4(fmaxf(glv.x, 0.f), fmaxf(glv.y, 0.f), fmaxf(glv.z, 0.f), fmaxf(glv.w, 0.f));
-          } else gelu_both4(glv, dgv);          // value and derivative on pairs (fno_dev.h)
-          const float gl4[4] = {glv.x, glv.y, glv.z, glv.w}, dg4[4] = {dgv.x, dgv.y, dgv.z, dgv.w};
+          const f32x2 dyp[2] = {f32x2{dy4.x, dy4.y}, f32x2{dy4.z, dy4.w}};
+          f32x2 dpp[2];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            dp[j] = dg4[j] * (w2v * dyv[j]);
-            sdw = fmaf(gl4[j], dyv[j], sdw);
-            sdb += dp[j];
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 pv = f32x2{acc[4 * i + 2 * h2], acc[4 * i + 2 * h2 + 1]} + b1p;
+            f32x2 gv, dv;
+            if constexpr (RELU) {
+              dv = f32x2{pv[0] > 0.f ? 1.f : 0.f, pv[1] > 0.f ? 1.f : 0.f};
+              gv = f32x2{fmaxf(pv[0], 0.f), fmaxf(pv[1], 0.f)};
+            } else gelu_both2(pv, gv, dv);          // value and derivative on pairs (fno_dev.h)
+            dpp[h2] = dv * (w2p * dyp[h2]);
+            sdw = __builtin_elementwise_fma(gv, dyp[h2], sdw);
+            sdb = sdb + dpp[h2];
           }
-          put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dp[0], dp[1], dp[2], dp[3]), sd);
+          put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dpp[0][0], dpp[0][1], dpp[1][0], dpp[1][1]), sd);
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
-          if (k == ch) { sdb1[k] += sdb; sdw2[k] += sdw; }
+          if (k == ch) { sdb1[k] += sdb[0] + sdb[1]; sdw2[k] += sdw[0] + sdw[1]; }
       }
       if (ch == 1) FNO_STAMP(tslot + 5);
       __syncthreads();         // dr[ch & 1] is complete; every reader of dr[(ch + 1) & 1] (chunk ch - 1) is done
