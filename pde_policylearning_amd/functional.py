@@ -111,6 +111,19 @@ def _weights_ready(ws):
     return [t.contiguous() for t in ws], False
 
 
+def _check_corner_weights(spec_ws, cin, cout, modes, planes, what):
+    """The C ABI takes raw pointers: a corner weight of the wrong extent is an out-of-bounds read on the device, not an
+    error.  Contiguous corner weights (real view) must be (cin, cout, *modes, 2) - what the reference's einsum would
+    have refused otherwise; plane-major ones carry their own (checked) extents."""
+    if planes:
+        return
+    want = (int(cin), int(cout)) + tuple(int(m) for m in modes) + (2,)
+    for i, t in enumerate(spec_ws):
+        if tuple(t.shape) != want:
+            raise RuntimeError(f"fnoengine {what}: spectral weight {i} has shape {tuple(t.shape)}, the plan's kept modes "
+                               f"{tuple(modes)} need {want} (real view of a ({cin}, {cout}, {', '.join(str(int(m)) for m in modes)}) complex corner)")
+
+
 def _same_layout(g, w):
     return g is not None and g.shape == w.shape and g.stride() == w.stride() and (g.is_contiguous() or plane_major(g))
 
@@ -299,6 +312,14 @@ class _FNOModelFn(torch.autograd.Function):
         sb = spec_bias.contiguous() if spec_bias is not None else None
         B, cin = x.shape[0], x.shape[1]
         c, cout, hid = lift_w.shape[0], w2.shape[0], w1.shape[0]
+        _check_corner_weights(spec_ws, c, c, modes, False, "fno_model")
+        for t, want, nm in ((lift_w, c * cin, "lifting weight"), (lift_b, c, "lifting bias"), (w1, hid * c, "projection W1"), (b1, hid, "projection b1"),
+                            (w2, cout * hid, "projection W2"), (b2, cout, "projection b2")):
+            if t.numel() != want:
+                raise RuntimeError(f"fnoengine fno_model: {nm} has {t.numel()} elements, the model's widths need {want}")
+        for l, t in enumerate(skip_ws):
+            if t.numel() != c * c:
+                raise RuntimeError(f"fnoengine fno_model: skip weight {l} has {t.numel()} elements, need {c * c}")
         L = _lib.lib()
         plan = model_plan(ndim, cin, c, cout, hid, n_layers, dims, modes, norm, gelu_mask, x.device)
         prm = _lib.FnoModelParams()
@@ -555,6 +576,7 @@ class _FNOBlocksFn(torch.autograd.Function):
             _require_cuda(t, "parameter")
         sb = bias.contiguous() if bias is not None else None
         B, c = x.shape[0], x.shape[1]
+        _check_corner_weights(spec_ws, c, c, modes, planes, "fno_blocks")
         L = _lib.lib()
         plan = model_plan(ndim, 0, c, 0, 0, n_layers, dims, modes, norm, gelu_mask, x.device, weight_planes=planes)
         prm = _lib.FnoModelParams()
@@ -721,6 +743,7 @@ class _FourierFanoutFn(torch.autograd.Function):
         for t in skip_ws + biases + spec_ws:
             _require_cuda(t, "parameter")
         B, c = x.shape[0], x.shape[1]
+        _check_corner_weights(spec_ws, c, c, modes, planes, "fourier_fanout")
         L = _lib.lib()
         plan = model_plan(ndim, 0, c, 0, 0, FANOUT_MAX, dims, modes, norm, 0, x.device, weight_planes=planes)
         prm = _lib.FnoModelParams()

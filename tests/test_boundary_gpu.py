@@ -311,6 +311,22 @@ def test_projection_weight_at_an_unaligned_address(dev):
         assert torch.equal(g0[n], g1[n]), n
 
 
+def test_corner_weight_of_the_wrong_extent_is_an_error_not_a_fault(dev):
+    """The C ABI takes raw pointers, so a corner weight smaller than the plan's kept modes would be read out of bounds on the
+    device (round 5: a tool did exactly that and took a GPU memory fault).  The operator layer refuses it, as the reference's
+    einsum does (neuralop/models/spectral_convolution.py:15-36)."""
+    from pde_policylearning_amd import functional as F
+    C, modes = 32, (8, 8)
+    x = torch.randn(2, C, 64, 64, device=dev)
+    skip = [0.1 * torch.randn(C, C, 1, device=dev)]
+    bias = 0.1 * torch.randn(1, C, device=dev)
+    good = [0.05 * torch.randn((C, C) + modes + (2,), device=dev) for _ in range(2)]
+    small = [w[:, :, :4, :4].contiguous() for w in good]
+    assert torch.isfinite(F.fno_blocks(x, skip, good, bias, modes, "ortho")).all()
+    with pytest.raises(RuntimeError, match="spectral weight"):
+        F.fno_blocks(x, skip, small, bias, modes, "ortho")
+
+
 def test_opt_in_projection_backward_arm_matches_default():
     """k_proj_bwd_q (csrc/k_projection3.h: 16 waves, four per SIMD; FNO_PBWD_Q=1) is an A/B arm that the default never runs: every
     gradient of a config-2-shaped step from a process with the switch against one without (tools/pbq_check.py; the switch is read
