@@ -179,6 +179,17 @@ class _SpectralConvFn(torch.autograd.Function):
         dims = tuple(x.shape[2:])
         ndim = len(dims)
         cout = ws_list[0].shape[1]
+        # (raw pointers from here on: extents the plan will assume are checked against the tensors first)
+        if len(ws_list) != 2 ** (ndim - 1) or len(modes) != ndim:
+            raise RuntimeError(f"fnoengine spectral_conv: {len(ws_list)} corner weights / {len(modes)} mode counts for {ndim}-d data")
+        wl = int(weight_last_extent) if weight_last_extent else int(modes[-1])
+        want = (int(cin), int(cout)) + tuple(int(m) for m in modes[:-1]) + (wl, 2)
+        for i, w in enumerate(ws_list):
+            if tuple(w.shape) != want:
+                raise RuntimeError(f"fnoengine spectral_conv: corner weight {i} has shape {tuple(w.shape)}, kept modes {tuple(modes)} "
+                                   f"(last extent {wl}) need {want}")
+        if bias is not None and bias.numel() != cout:
+            raise RuntimeError(f"fnoengine spectral_conv: bias has {bias.numel()} elements, {cout} output channels")
         L = _lib.lib()
         plan = spec_plan(ndim, cin, cout, dims, modes, weight_last_extent, norm, x.device, weight_planes=planes)
         ctx.planes = planes
@@ -1340,6 +1351,8 @@ class _ProjectionHeadFn(torch.autograd.Function):
         hid, co = w1.shape[0], w2.shape[0]
         w1c, b1c = w1.reshape(hid, Cc).contiguous(), b1.contiguous()
         w2c, b2c = w2.reshape(co, hid).contiguous(), b2.contiguous()
+        if b1c.numel() != hid or b2c.numel() != co:
+            raise RuntimeError(f"fnoengine projection_head: biases of {b1c.numel()} / {b2c.numel()} elements for {hid} hidden and {co} output channels")
         y = torch.empty((B, co) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().fno_projection_forward_act(B, Cc, hid, co, pw, _ptr(x), _ptr(w1c), _ptr(b1c), _ptr(w2c),
