@@ -1004,6 +1004,8 @@ class _RnoResetGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a3, a4, b2, h):
+        if not (a3.shape == a4.shape == h.shape):
+            raise RuntimeError(f"fnoengine rno_reset_gate: operands of shapes {tuple(a3.shape)}, {tuple(a4.shape)}, {tuple(h.shape)}")
         a3, a4, h = a3.contiguous(), a4.contiguous(), h.contiguous()
         r, rh = torch.empty_like(h), torch.empty_like(h)
         _lib.check(_lib.lib().fno_rno_reset_gate_forward(h.numel(), _ptr(a3), _ptr(a4), _ptr(b2), _ptr(h), _ptr(r), _ptr(rh),
@@ -1028,6 +1030,8 @@ class _RnoOutputGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a1, a2, b1, a7, a8, b4, a5, a6, b3, h):
+        if any(t.shape != h.shape for t in (a1, a2, a7, a8, a5, a6)):
+            raise RuntimeError(f"fnoengine rno_output_gate: operands must all have the state's shape {tuple(h.shape)}")
         a1, a2, a7, a8, a5, a6, h = [t.contiguous() for t in (a1, a2, a7, a8, a5, a6, h)]
         z, z2, s3, hn = (torch.empty_like(h) for _ in range(4))
         _lib.check(_lib.lib().fno_rno_output_gate_forward(h.numel(), _ptr(a1), _ptr(a2), _ptr(b1), _ptr(a7), _ptr(a8), _ptr(b4),
@@ -1078,6 +1082,10 @@ class _PointwiseAddFn(torch.autograd.Function):
         B, Cc = x.shape[0], x.shape[1]
         pw = x.numel() // (B * Cc)
         w2 = w.reshape(Cc, Cc).contiguous()
+        if addend is not None and addend.shape != x.shape:
+            raise RuntimeError(f"fnoengine pointwise_conv_add: addend of shape {tuple(addend.shape)} for x of shape {tuple(x.shape)}")
+        if bias is not None and bias.numel() != Cc:
+            raise RuntimeError(f"fnoengine pointwise_conv_add: bias of {bias.numel()} elements for {Cc} channels")
         add_c = addend.contiguous() if addend is not None else None
         b_c = bias.contiguous() if bias is not None else None
         y = torch.empty_like(x)
