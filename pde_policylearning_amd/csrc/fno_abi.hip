@@ -19,6 +19,7 @@
 #include "k_chanflow.h"
 #include "k_pointwise.h"
 #include "k_block_fwd2.h"
+#include "k_block_fwd3.h"
 #include "k_projection.h"
 #include "k_projection2.h"
 #include "k_projection_h2.h"
@@ -1194,6 +1195,18 @@ static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds)
   *lds = blk_fwd_t_lds_bytes(C, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr);
   return *lds + 2048 <= 160 * 1024;
 }
+// third-generation block forward (k_block_fwd3.h): independent strip waves fed by LDS-DMA.  64 channels, rows of 128 pixels,
+// <= 8 kept last-dim modes either side, two-term fp16 mode, no lifting / ReLU / addend; everything else keeps k_blk_fwd_t.
+// u is bit-identical to k_blk_fwd_t's (same products in the same order), x1 agrees to ~2e-7 (fp16-split row DFT instead of
+// fp32 MFMAs).  FNO_BFWD_V2=1 keeps the second generation (A/B arm).
+static const int g_bfwd_v2 = getenv("FNO_BFWD_V2") ? 1 : 0;
+static bool blk_fwd_s_ok(const FnoModelPlan* p, const PwFwdArgs& a) {
+  if (g_bfwd_v2 || p->NPX != 128 || p->loose || !a.x || !a.u || !a.z || !a.xmax) return false;
+  if (a.W != 128 || a.K2in > 8 || a.lw || a.relu_out || a.add) return false;
+  if (a.x1 && (a.NJ != 1 || a.K2out > 8)) return false;
+  if ((size_t)a.PW * 4 * 64 >= (size_t)1 << 31) return false;          // 32-bit offsets within one sample
+  return true;
+}
 template <int C>
 static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, const PwFwdArgs& a_in) {
   size_t lds2 = 0;
@@ -1212,6 +1225,17 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
     // (template flags: LIFT, RELU, ACT_IN, EPI, ADD - k_block_fwd2.h; other combinations keep k_pw_fwd_x3)
     const int kz = a.z ? (2 * a.K2in + 15) / 16 : 0;
     const bool h2k = g_h2 && g_h2_blocks && g_h2_fwd_blocks && a.xmax && kz > 0 && !a.add && !a.relu_out;      // two-term fp16 variants: the model path's combinations
+    if (h2k && blk_fwd_s_ok(p, a)) {
+      const size_t lds3 = blk_fwd_s_lds_bytes(a.K2out, a.x1 != nullptr);
+      const dim3 g3(std::min(a.ntiles, 2 * p->ncu));
+      a.share32 = ((int)g3.x == 2 * p->ncu) ? share_bf : 0;
+#define BF3(AIN_, EPI_) return GT(2), launch(nm, k_blk_fwd_s<AIN_, EPI_>, g3, dim3(256), lds3, st, a)
+      if (a.act_in) { if (epi == 2) BF3(true, 2); if (epi == 1) BF3(true, 1); BF3(true, 0); }
+      if (epi == 2) BF3(false, 2);
+      if (epi == 1) BF3(false, 1);
+      BF3(false, 0);
+#undef BF3
+    }
 #define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
     if (h2k && !(RELU_) && !(ADD_)) \
       return GT(2), launch(nm, k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \

@@ -55,6 +55,8 @@ struct PwFwdArgs {
                       // two-term fp16 GEMMs of the consumer scale their operand by it: fno_dev.h, "h2")
   int share32 = 0;    // k_blk_fwd_t with two workgroups per CU: 32nds of a CU's tiles that go to the workgroup dispatched FIRST
                       // (0 = even split; pair_share() in fno_dev.h)
+  int rev = 0;        // k_blk_fwd_s: walk the tiles from the last to the first (the input's most recently written part - what the
+                      // Infinity Cache still holds of the producer's output - is read first)
 };
 
 // dynamic LDS bytes needed by k_pw_fwd<CIN, COUT, NPX>
