@@ -1200,9 +1200,10 @@ static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds)
 // u is bit-identical to k_blk_fwd_t's (same products in the same order), x1 agrees to ~2e-7 (fp16-split row DFT instead of
 // fp32 MFMAs).  FNO_BFWD_V2=1 keeps the second generation (A/B arm).
 static const int g_bfwd_v2 = getenv("FNO_BFWD_V2") ? 1 : 0;
+static const int g_zigzag = getenv("FNO_NO_ZIGZAG") ? 0 : 1;      // A/B switch: alternating tile order along the kernel chain
 static bool blk_fwd_s_ok(const FnoModelPlan* p, const PwFwdArgs& a) {
   if (g_bfwd_v2 || p->NPX != 128 || p->loose || !a.x || !a.u || !a.z || !a.xmax) return false;
-  if (a.W != 128 || a.K2in > 8 || a.lw || a.relu_out || a.add) return false;
+  if (a.W != 128 || a.K2in > 8 || a.relu_out || a.add || (a.lw && a.CL > 4)) return false;
   if (a.x1 && (a.NJ != 1 || a.K2out > 8)) return false;
   if ((size_t)a.PW * 4 * 64 >= (size_t)1 << 31) return false;          // 32-bit offsets within one sample
   return true;
@@ -1230,6 +1231,11 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
       const dim3 g3(std::min(a.ntiles, 2 * p->ncu));
       a.share32 = ((int)g3.x == 2 * p->ncu) ? share_bf : 0;
 #define BF3(AIN_, EPI_) return GT(2), launch(nm, k_blk_fwd_s<AIN_, EPI_>, g3, dim3(256), lds3, st, a)
+      if (a.lw) {
+        if (epi == 2) return GT(2), launch(nm, k_blk_fwd_s<false, 2, true>, g3, dim3(256), lds3, st, a);
+        if (epi == 1) return GT(2), launch(nm, k_blk_fwd_s<false, 1, true>, g3, dim3(256), lds3, st, a);
+        return GT(2), launch(nm, k_blk_fwd_s<false, 0, true>, g3, dim3(256), lds3, st, a);
+      }
       if (a.act_in) { if (epi == 2) BF3(true, 2); if (epi == 1) BF3(true, 1); BF3(true, 0); }
       if (epi == 2) BF3(false, 2);
       if (epi == 1) BF3(false, 1);
@@ -1300,7 +1306,8 @@ static size_t bbwd_g2_lds(const BlkBwdArgs& a, int nterm = 3) {
   const size_t kext = !a.zg ? 0 : a.kx16 ? (size_t)2 * 3 * (128 / a.W) * 64 * 32 + (size_t)3 * a.W * 32
                                          : ((size_t)2 * (128 / a.W) * a.K2in * 64 * 2 + (size_t)2 * a.K2in * a.W) * 4;
   return (size_t)4 * nterm * 64 * 128 + kext +
-         ((size_t)2 * 64 * 68 + (a.xin ? 2 * 2 * 8 * 68 : 0) + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0) + 4) * 4;
+         ((size_t)2 * 64 * 68 + (a.xin ? 2 * 2 * 8 * 68 : 0) + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0) + 4) * 4 +
+         (a.lines ? 16 + 8 * 2048 : 0);      // whole-line u: 2 KB of staging per wave behind the barrier counters
 }
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a_in, bool* published = nullptr) {
@@ -1343,7 +1350,10 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   }
   // C = 64, rows of 32 / 64 / 128 pixels: two independent 4-wave groups per workgroup (k_block_bwd_g2)
   static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
+  static const int no_lines = getenv("FNO_BBWD_NO_LINES") ? 1 : 0;      // A/B switch: u loaded / gout stored 16 bytes per channel row
   if constexpr (C == 64) {
+    a.lines = (no_lines || !h2) ? 0 : 1;      // (the two-term variants carry it)
+    if (a.lines && bbwd_g2_lds(a, g2_terms) > 160 * 1024) a.lines = 0;
     if (g_gemm_x3 && FNO_BBWD_X3 && !v1 && !no_g2 && p->NPX == 128 && (a.W == 32 || a.W == 64 || a.W == 128) &&
         (!a.x1g || a.NJ <= 2) && a.ntiles >= 2 && bbwd_g2_lds(a, g2_terms) <= 160 * 1024) {
       const int g2 = grid;      // the host sums `grid` partial slabs per output: groups without a tile write zeros
@@ -1351,12 +1361,14 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       const bool two = a.x1g && a.W == 128 && a.NJ == 2;
       if (a.lw && !a.x1g && !a.gadd) {
         if (published) *published = a.gmax_out != nullptr;
+        if (h2 && a.lines) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
         if (h2) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
         return GT(3), launch(nm, k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
       // (gradient addends and two 16-output blocks per wave do not fit the register budget yet: k_block_bwd_t takes those)
       if (!a.lw && !a.xin && !a.gadd && !two) {
         if (published) *published = a.gmax_out != nullptr;
+        if (h2 && a.lines) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
         if (h2) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
         return GT(3), launch(nm, k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
@@ -1627,6 +1639,9 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
       if (l == 0) { a.xmax = (a.lw && lift_xmax) ? amax + 7 : nullptr; a.ubound = amax + 8; }   // (an unfused u_0 has no published bound)
       else a.xmax = amax + 8 + l;
     }
+    // zigzag: every block walks its tiles in the opposite direction of its producer, so that it starts on the part of its
+    // input the producer wrote last - what the 256 MB Infinity Cache still holds of it (kernels without the option walk forward)
+    a.rev = g_zigzag ? (l & 1) : 0;
     LAUNCHCHK(launch_block(p, st, std::min(s.ntiles, (g_gemm_x3 ? FNO_GRID_PWX : FNO_GRID_PW) * p->ncu), a));
   }
 
@@ -1783,6 +1798,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   pb.PW = g.PW; pb.W = g.W; pb.P = g.P; pb.K2out = g.Klast; pb.NJ = g.NJ; pb.CO = d.Cout;
   pb.act_in = (d.gelu_mask >> (L - 1)) & 1u;
   pb.tiles_per_plane = s.tiles_per_plane; pb.ntiles = s.ntiles;
+  pb.rev = g_zigzag;      // the forward pass's projection read u_L front to back: start at the back (k_proj_bwd_t; the others ignore it)
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
   jobs.add(w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C);
@@ -1856,6 +1872,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
       if (gvalid && (l > 0 || (a.lw && cs.h2_u0))) { a.gmax_in = amax_b + 32 + l + 1; a.umax = amax_b + 8 + l; }
       if (l > 0) a.gmax_out = amax_b + 32 + l;      // (cleared with the whole range at the start of the pass)
     }
+    a.rev = g_zigzag ? ((L - 1 - l) & 1) : 0;      // zigzag along the chain: the projection backward ended at the front
     bool published = false;
     LAUNCHCHK(launch_bbwd(p, st, s.grid_bb, a, &published));
     gvalid = published;

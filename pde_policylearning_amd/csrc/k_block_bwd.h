@@ -54,6 +54,10 @@ struct BlkBwdArgs {
   float* gmax_out;
   int kx16;           // k_block_bwd_g2: the spectral K-extension as ONE 16-deep bf16x3 block on the matrix pipe (<= 8 kept last-dim
                       // modes; table / spectral-row images in LDS) instead of 2-deep fp32 MFMAs on the VALU lanes
+  int rev = 0;        // k_block_bwd_g2: walk the tiles from the last to the first (the most recently written part of g - what the
+                      // Infinity Cache still holds of the producer's output - is read first)
+  int lines = 0;      // k_block_bwd_g2: u is loaded and gout stored in whole 128 / 256-byte lines (the host adds 16 KB of staging
+                      // to the LDS size; round 6)
 };
 
 template <int C, int NPX>

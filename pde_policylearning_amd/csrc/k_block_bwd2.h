@@ -421,7 +421,8 @@ FNO_DEV void group_barrier(unsigned* cnt, unsigned& epoch, int lane) {
 
 // LIFT: block 0 of a model with a lifting layer (u_0 recomputed from the model input, lifting gradients instead of a row DFT);
 // GADD: a gradient addend is added to dx (fan-out chains); NJP: 16-output blocks of the row DFT per wave when a row spans both halves
-template <bool LIFT = false, bool GADD = false, int NJP = 1, int NT3 = 3>
+// LINES: u is loaded and gout stored in whole lines (a.lines; the host adds the staging to the LDS size)
+template <bool LIFT = false, bool GADD = false, int NJP = 1, int NT3 = 3, bool LINES = false>
 __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   FNO_CLK_ENTRY();
   constexpr int C = 64, GPX = 64, KB = C / 16, PITCH = GPX + 4, XPITCH = GPX + 4;
@@ -461,6 +462,10 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   float* tfwd_s = after;
   after += a.x1g ? 16 * a.NJ * (a.W + 4) : 0;
   unsigned* bar = reinterpret_cast<unsigned*>(after) + grp;
+  // a.lines: 2 KB per wave behind the counters (16-byte aligned): gelu'(u), computed where u arrives in whole lines (lane <-> row
+  // 8 i + lane / 8, 16-byte chunk lane % 8), takes a turn through it into the accumulators' layout (lane <-> row, registers <->
+  // 4-pixel runs) for the epilogue: 16 rows x 128 bytes at a time, chunks XOR-swizzled by the row, private to the wave
+  unsigned char* dgst = reinterpret_cast<unsigned char*>(after + 4) + wave * 2048;
 
   // Every global value the prologue needs is REQUESTED first (weights, bounds, both tables), then the images are cleared and
   // the values used: the prologue was a chain of dependent L2 round trips behind barriers (9.2 us of a 170-200 us launch,
@@ -486,7 +491,8 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   float xa[NKL];
   float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
   const int zc4 = a.zg ? R2 * a.K2in * C / 2 : 0;     // float4s of spectral rows per 128-pixel tile
-  auto issue = [&](int tile, int h) {
+  auto issue = [&](int tile_, int h) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * 128 + 64 * h;
 #pragma unroll
@@ -499,15 +505,18 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
         xa[s] = k < a.CL ? a.xin[((size_t)b * a.CL + k) * a.PW + px0 + n0 + l31] : (k == a.CL ? 1.f : 0.f);
       }
     } else {
-#ifdef FNO_EXP_UCOAL      // timing experiment only (wrong results): u in whole lines like g
+      // (as loaded by rounds 2-5 - lane <-> channel row, 16 bytes - one instruction touches 32 lines for 32 bytes each; in
+      // whole lines like g the block backward takes 0.181 instead of 0.205 ms per launch at config 2 and, unlike every
+      // schedule change of rounds 3-5, the step gets ALL of it: fewer requests are less energy, not just less waiting)
+      if constexpr (LINES) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        uq[i] = ld4(a.uin + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
-#else
-      const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
+        for (int i = 0; i < 4; ++i)
+          uq[i] = ld4(a.uin + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+      } else {
+        const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) uq[i] = ld4(a.uin + ro + 8 * i);
-#endif
+        for (int i = 0; i < 4; ++i) uq[i] = ld4(a.uin + ro + 8 * i);
+      }
     }
     if (h == 0 && gtid < zc4) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * zrow_f + 4 * gtid);
   };
@@ -598,7 +607,8 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
   FNO_TRACE_IF(FNO_TRACE_WHICH == 2 && a.x1g != nullptr);
   int tslot = 0;
   FNO_CLK_BEGIN();
-  for (int tile = tile0; tile < a.ntiles; tile += tstep) {
+  for (int tile_ = tile0; tile_ < a.ntiles; tile_ += tstep) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int pxt = (tile % a.tiles_per_plane) * 128;
 #pragma unroll 1
@@ -617,6 +627,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
           for (int s = 0; s < NKL; ++s)
             if (2 * s <= a.CL) u0 = mfma32(xa[s], wl[s], u0);
         }
+        constexpr bool ULINES = !LIFT && LINES;      // u in g's layout (whole lines)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 gv = gq[i];
@@ -625,10 +636,27 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
           float4 uv;
           if constexpr (LIFT) uv = make_float4(u0[4 * i], u0[4 * i + 1], u0[4 * i + 2], u0[4 * i + 3]);
           else uv = uq[i];
-          if (a.act_in) {
-            gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
+          if constexpr (ULINES) {
+            // the derivative takes a turn through the wave's staging rows into the accumulator layout: rows 16 p .. 16 p + 15
+            // of the wave's 32 (i = 2 p, 2 p + 1) per pass, read back by the half of the lanes that own those rows
+            float4 dw_ = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (a.act_in) gelu_both4(uv, dw_);
+            put_split4_n<NT3>(aimg, TERM, swz64_off(grow0 + 8 * i, (n0 >> 3) + ((lane & 7) >> 1)) + 8 * (lane & 1), uv, sa);
+            if (a.act_in) {
+              const int r = 8 * (i & 1) + (lane >> 3);
+              st4(reinterpret_cast<float*>(dgst + r * 128 + (((lane & 7) ^ (r & 7)) * 16)), dw_);
+              if ((i & 1) && (l31 >> 4) == (i >> 1)) {
+                const int rr = l31 & 15;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dg[k] = ld4(reinterpret_cast<const float*>(dgst + rr * 128 + (((2 * k + half) ^ (rr & 7)) * 16)));
+              }
+            }
+          } else {
+            if (a.act_in) {
+              gelu_both4(uv, dg[i]);          // value and derivative on pairs (fno_dev.h)
+            }
+            put_split4_n<NT3>(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv, sa);
           }
-          put_split4_n<NT3>(aimg, TERM, swz64_off(crow, (n0 >> 3) + i) + 8 * half, uv, sa);
         }
       }
       if (h == 0) {
@@ -747,7 +775,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
       // the next half's operands: issued behind the GEMMs (32 registers that must not be live beside the weight fragments and
       // the accumulators); their latency is covered by the epilogue, the row DFT and the other group's work on this SIMD
       {
-        const int nh = h ^ 1, ntile = h ? tile + tstep : tile;
+        const int nh = h ^ 1, ntile = h ? tile_ + tstep : tile_;
         if (ntile < a.ntiles) issue(ntile, nh);
       }
       // ---- epilogue -------------------------------------------------------------------------------------------------------
@@ -764,11 +792,8 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
           float4 v = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
           if constexpr (GADD) { v.x += ad[i].x; v.y += ad[i].y; v.z += ad[i].z; v.w += ad[i].w; }
           if (a.act_in) { v.x *= dg[i].x; v.y *= dg[i].y; v.z *= dg[i].z; v.w *= dg[i].w; }
-#ifdef FNO_EXP_STCOAL     // timing experiment only (wrong results): gout in whole lines
-          if (a.gout) st4(a.gout + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7), v);
-#elif !defined(FNO_EXP_NOSTORE)
-          if (a.gout) st4(a.gout + ro + 8 * i, v);
-#endif
+          // (a.lines with a gout tile in LDS: the tile leaves in whole lines behind the barrier, below)
+          if (a.gout && !(LINES && (LIFT || a.x1g))) st4(a.gout + ro + 8 * i, v);
           if (a.gmax_out) vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
           if (LIFT || a.x1g) st4(r3p + 8 * i, v);
         }
@@ -776,6 +801,14 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
       FNO_STAMP(tslot + 5);
       group_barrier(bar, epoch, lane);
       FNO_STAMP(tslot + 6);
+      if (LINES && a.gout && (LIFT || a.x1g)) {
+        // gout from the fp32 tile in whole 256-byte lines: wave wg stores rows 16 wg .. 16 wg + 15, four rows per instruction
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 16 * wg + 4 * i + (lane >> 4);
+          st4(a.gout + ((size_t)b * C + row) * a.PW + px0 + 4 * (lane & 15), ld4(r3 + row * PITCH + 4 * (lane & 15)));
+        }
+      }
       // ---- row DFT of gout (truncated, fp32 MFMA 16x16x4) -----------------------------------------------------------------
       if (!LIFT && a.x1g) {
         if (a.W == 128) {

@@ -60,8 +60,11 @@ static inline size_t blk_fwd_s_lds_bytes(int K2out, bool has_x1) {
 #define FNO_BFS_EXP 0           // timing experiments of tools/bf3_test.hip (results are wrong): 1 = no u stores, 2 = no strip loads
 #endif
 
-template <bool ACT_IN, int EPI>
+// LIFT: block 0 of a model with a lifting layer: the strip is u_0 = W_l x + b_l of the <= 4-channel model input (tfno.py:11-20),
+// computed where the other variants read their slot (no DMA: four dword loads per lane and strip, one strip ahead)
+template <bool ACT_IN, int EPI, bool LIFT = false>
 __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
+  static_assert(!(LIFT && ACT_IN), "variants");
   constexpr int C = 64, NW = 4, NT = 256, KB = 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
@@ -87,25 +90,36 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
     const int b = tile / a.tiles_per_plane, px0 = (tile % a.tiles_per_plane) * 128 + w0;
     return uniform_ptr(a.x + (size_t)b * C * a.PW + px0);
   };
+  float xin[4];                                               // LIFT: the model input at this lane's pixel, next strip
   auto issue_dma = [&](int tile) {
-    const float* src = strip_src(tile);
+    if constexpr (LIFT) {
+      const int t2 = a.rev ? a.ntiles - 1 - tile : tile;
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x + (size_t)(t2 / a.tiles_per_plane) * a.CL * a.PW + (t2 % a.tiles_per_plane) * 128 + w0,
+                                                  (unsigned)(a.CL - 1) * PWb + 32 * 4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (!(FNO_BFS_EXP & 2)) glds16(src + (size_t)i * 8 * a.PW, dma_voff, slot_a + i * 1024);
+      for (int k = 0; k < 4; ++k) xin[k] = buf_ld1(rx, l31 * 4, k * PWb);      // (channels past CL: out of range = 0)
+    } else {
+      const float* src = strip_src(tile);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (!(FNO_BFS_EXP & 2)) glds16(src + (size_t)i * 8 * a.PW, dma_voff, slot_a + i * 1024);
+    }
   };
   // spectral coefficients of the strip's row for channel o = mt * 32 + l31: k = 8 half + j <-> mode 4 half + (j >> 1), re / im
   float zraw[2][8];
+  // (buffer loads: descriptor and row in SGPRs, ONE per-lane offset register, the (mode, half) part in the instruction's offset
+  // field, modes past K2in out of the descriptor's range = 0 - per-lane 64-bit addresses of eight loads, hoisted out of the strip
+  // loop, were 16 registers and, in the LIFT variant, scratch)
+  const int z_voff = ((4 * half * C + l31) * 2) * 4;
   auto load_z = [&](int tile_) {
     const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane, prow = ((tile % a.tiles_per_plane) * 128) / W;
-    const float* zrow = a.z + ((size_t)b * a.P + prow) * a.K2in * C * 2;
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.z + ((size_t)b * a.P + prow) * a.K2in * C * 2, (unsigned)a.K2in * C * 2 * 4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const int s = 4 * half + jj;
-        float2 v = make_float2(0.f, 0.f);
-        if (s < a.K2in) v = *reinterpret_cast<const float2*>(zrow + ((size_t)s * C + mt * 32 + l31) * 2);
-        zraw[mt][2 * jj] = v.x; zraw[mt][2 * jj + 1] = v.y;
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rz, z_voff + ((jj * C + mt * 32) * 2) * 4, 0, 0));
+        zraw[mt][2 * jj] = v[0]; zraw[mt][2 * jj + 1] = v[1];
       }
   };
   if (ts.first < ts.end) { issue_dma(ts.first); load_z(ts.first); }      // the first strip travels while the images are built
@@ -123,7 +137,9 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
     for (int k = 0; k < NW; ++k) r = fmaxf(r, red[k]);
     return r;
   };
-  const float bx = *a.xmax;                                   // |x| <= bx; |gelu(x)| <= |x|
+  float bx = *a.xmax;                                         // |x| <= bx; |gelu(x)| <= |x| (LIFT: of the model input)
+  float* lws = reinterpret_cast<float*>(lds);                 // LIFT: [C][4] lifting weights (columns >= CL zero) + [C] biases, in the unused slots
+  if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);
   float wraw[2][8];                                           // items tid, tid + 256 of [mt][kb][lane]
   float mw = 0.f;
 #pragma unroll
@@ -136,6 +152,15 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
     }
   }
   const float sw = h2_scale(wg_max(mw));
+  if constexpr (LIFT) {                                       // |u_0[c]| <= sum_k |lw[c][k]| bx + |lb[c]|  (as k_blk_fwd_t: the same bound, bit for bit)
+    float m = 0.f;
+    for (int c = tid; c < C; c += NT) {
+      const float4 wv = ld4(lws + 4 * c);                     // (staged above; wg_max's barriers made it visible)
+      m = fmaxf(m, (fabsf(wv.x) + fabsf(wv.y) + fabsf(wv.z) + fabsf(wv.w)) * bx + fabsf(lws[4 * C + c]));
+    }
+    bx = wg_max(m);
+    if (a.ubound && blockIdx.x == 0 && tid == 0) *a.ubound = bx;      // (the same value in every workgroup) for the backward pass
+  }
   const float sx = h2_scale(bx);
   const float inv_xw = 1.f / (sx * sw);
 #pragma unroll
@@ -201,14 +226,19 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
     const int b = tile / a.tiles_per_plane, px0 = (tile % a.tiles_per_plane) * 128;
     const bool more = tile_ + ts.step < ts.end;
     // ---- the strip has landed: behind its DMA this wave issued only the previous strip's stores (and nothing the first time) ------
-    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((FNO_BFS_EXP & 1) ? 0 : (TR ? FNO_BFS_NST : 32)) : "memory");
+    if constexpr (!LIFT) {
+      if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((FNO_BFS_EXP & 1) ? 0 : (TR ? FNO_BFS_NST : 32)) : "memory");
+    }
     first = false;
     float raw[KB][8];
+    const float x0 = xin[0], x1_ = xin[1], x2 = xin[2], x3 = xin[3];      // LIFT: this strip's input (xin is refilled below)
+    if constexpr (!LIFT) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[kb][j] = *reinterpret_cast<const float*>(slot + (16 * kb + 8 * half + j) * 128 + l31 * 4);
+        for (int j = 0; j < 8; ++j) raw[kb][j] = *reinterpret_cast<const float*>(slot + (16 * kb + 8 * half + j) * 128 + l31 * 4);
+    }
     bf16x8 zb[2][3];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) split3x8(zraw[mt], zb[mt][0], zb[mt][1], zb[mt][2]);
@@ -222,8 +252,24 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
 
     // ---- A fragments: (GELU,) two-term split of the wave's 32 pixels x 64 channels ------------------------------------------------
     bf16x8 fa[KB][2];
+    // LIFT: a compiler-level memory barrier per strip (this variant has no DMA statement in its loop, and without one every
+    // loop-invariant LDS read - the lifting parameters, all sixteen W fragments - is hoisted into registers and from there
+    // into scratch) and the parameter pointers opaque per strip (one base register each, the channel in the offset field)
+    const float* lwp = lws + 32 * half;
+    const float* lbp = lws + 4 * C + 8 * half;
+    if constexpr (LIFT) {
+      asm volatile("" ::: "memory");
+      asm volatile("" : "+v"(lwp), "+v"(lbp));
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
+      if constexpr (LIFT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 wv = ld4(lwp + 4 * (16 * kb + j));
+          raw[kb][j] = fmaf(wv.w, x3, fmaf(wv.z, x2, fmaf(wv.y, x1_, fmaf(wv.x, x0, lbp[16 * kb + j]))));
+        }
+      }
       if constexpr (ACT_IN) gelu8(raw[kb], six, inf);
       split_n_x8<2>(raw[kb], sx, fa[kb]);
     }

@@ -127,6 +127,8 @@ struct ProjBwdArgs {
   const float* amax;  // k_proj_bwd_t<.., 2>: {-, max |dy|, max |W1|, max |w2|} (device scalars)
   const float* xmax;  // ... and the bound of |x| the forward pass published
   float* gmax_out;    // k_proj_bwd_t: max |gout| is published here (bound for the next kernel's fp16 operand scale)
+  int rev = 0;        // k_proj_bwd_t: walk the tiles from the last to the first (u_L's most recently read part - what the
+                      // Infinity Cache still holds of it behind the forward pass - is read first)
 };
 
 template <int C, int HID, int NPX>

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   // the tile's rows of u_L: thread (c = tid / 32 + 16 i, q = tid % 32) loads 16 bytes; per-sample descriptor
   float4 xq[XI];
   const int xvoff = ((tid >> 5) * a.PW + 4 * (tid & 31)) * 4;
-  auto issue_x = [&](int tile) {
+  auto issue_x = [&](int tile_) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
@@ -239,7 +240,8 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   int tslot = 0;
   FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
   FNO_CLK_BEGIN();
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (int tile_ = blockIdx.x; tile_ < a.ntiles; tile_ += gridDim.x) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       if (ch == 1) FNO_STAMP(tslot + 6);
       // the next tile's rows: issued in the last chunk, so that their 16 registers are not live through the whole tile
       if (ch == NCH - 1) {
-        const int nt2 = tile + gridDim.x;
+        const int nt2 = tile_ + gridDim.x;
         if (nt2 < a.ntiles) issue_x(nt2);
       }
       // ---- A3: dx^T[px][c] += sum_hid dP1[hid][px] W1[hid][c]: A = transposed reads of the dP1 image ----------------------
@@ -396,8 +398,12 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
           { float4 uu = uq[i], dd; gelu_both4(uu, dd); v[i].x *= dd.x; v[i].y *= dd.y; v[i].z *= dd.z; v[i].w *= dd.w; }
         }
       }
+      // (with a gout tile in LDS for the row DFT the tile leaves in whole lines behind the barrier, below: stored from the
+      // accumulator layout - lane <-> channel row, 16 bytes - one instruction touches 32 lines for 32 bytes each)
+      if (!a.x1g) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st4(a.gout + ro + 8 * i, v[i]);
+        for (int i = 0; i < 4; ++i) st4(a.gout + ro + 8 * i, v[i]);
+      }
       if (a.gmax_out) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) gvmax = fmaxf(fmaxf(gvmax, fabsf(v[i].x)), fmaxf(fmaxf(fabsf(v[i].y), fabsf(v[i].z)), fabsf(v[i].w)));
@@ -463,6 +469,13 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     }
     if (a.x1g) {
       __syncthreads();
+      if constexpr (MT == 2) {      // gout: row tid / 32 + 16 i of the tile, 16-byte piece tid % 32 - whole 512-byte rows
+#pragma unroll
+        for (int i = 0; i < C / 16; ++i) {
+          const int row = (tid >> 5) + 16 * i;
+          st4(a.gout + ((size_t)b * C + row) * a.PW + px0 + 4 * (tid & 31), ld4(r3 + row * PITCH + 4 * (tid & 31)));
+        }
+      }
       row_dft_epilogue<C, NPX, 8>(MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + R3B_OFF), tfwd_s, a.W + 4, a.x1g, b, px0, a.P,
                                   a.W, a.K2out, a.NJ, wave, lane);
       FNO_STAMP(tslot + 11);

@@ -45,7 +45,7 @@ static void run(int B, int W, int K2, int reps) {
   const int ncu = prop.multiProcessorCount;
   const size_t lds_old = blk_fwd_t_lds_bytes(C, W, K2, NJ, true, EPI != 0), lds_new = blk_fwd_s_lds_bytes(K2, EPI != 0);
   auto kold = k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 1, 2>;
-  auto knew = k_blk_fwd_s<AIN, EPI>;
+  auto knew = k_blk_fwd_s<AIN, EPI, LIFT>;
   CK(hipFuncSetAttribute((const void*)kold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
   CK(hipFuncSetAttribute((const void*)knew, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
   const int nthr = (C / 32) * 2 * 64;
@@ -143,5 +143,6 @@ int main(int argc, char** argv) {
   if (which < 0 || which == 2) run<64, false, false, 0>(B, W, K2, reps);
   if (which < 0 || which == 3) run<64, false, true, 0>(B, W, K2, reps);
   if (which < 0 || which == 4) run<64, false, false, 2>(B, W, K2, reps);
+  if (which < 0 || which == 5) run<64, true, false, 2>(B, W, K2, reps);
   return 0;
 }
