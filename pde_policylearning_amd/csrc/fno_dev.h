@@ -348,6 +348,28 @@ FNO_DEV float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
 FNO_DEV float buf_ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// STREAMING loads (round 6): activations a kernel reads exactly once are loaded non-temporally - no allocation in L2 / the
+// Infinity Cache - so that what stays resident is what the kernel WRITES, which the next kernel of the chain (walking its
+// tiles in the opposite direction: "zigzag", fno_abi.hip) reads first.  Measured on the strip kernel alone: 110 -> 101 us per
+// launch (issue -> landed is shorter for nt loads, MI355X_MICROARCH.md, nt-weights).  -DFNO_NT_LOADS=0: default policy (A/B arm).
+#ifndef FNO_NT_LOADS
+#define FNO_NT_LOADS 1
+#endif
+FNO_DEV float buf_ld1s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, FNO_NT_LOADS ? 2 : 0));
+}
+FNO_DEV float4 buf_ld4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, FNO_NT_LOADS ? 2 : 0));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+FNO_DEV float4 ld4s(const float* p) {
+#if FNO_NT_LOADS
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
 FNO_DEV bf16x8 buf_ld8h(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }

@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
     const int px0 = (tile % a.tiles_per_plane) * 128 + 64 * h;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      gq[i] = ld4(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+      gq[i] = ld4s(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
     if constexpr (LIFT) {
 #pragma unroll
       for (int s = 0; s < NKL; ++s) {
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(512, 2) k_block_bwd_g2(BlkBwdArgs a) {
       if constexpr (LINES) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          uq[i] = ld4(a.uin + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+          uq[i] = ld4s(a.uin + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
       } else {
         const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
 #pragma unroll

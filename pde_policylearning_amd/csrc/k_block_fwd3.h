@@ -28,10 +28,18 @@
 // source = sbase (wave-uniform) + voff (per lane, bytes).  M0 carries the LDS base and is compiler-reserved: saved and
 // restored inside the statement (cdna_hip_programming.md, inline-asm rules).  Not counted by the compiler's s_waitcnt
 // bookkeeping: the caller waits with a counted s_waitcnt vmcnt.
+#ifndef FNO_BFS_NT
+#define FNO_BFS_NT FNO_NT_LOADS // the strip loads are non-temporal (fno_dev.h: streaming loads)
+#endif
 FNO_DEV void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;
+#if FNO_BFS_NT
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#else
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
 }
 FNO_DEV unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;

@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     for (int i = 0; i < XI; ++i) xq[i] = ld4(a.x + ((size_t)b * C + (tid >> 5) + 16 * i) * a.PW + px0 + 4 * (tid & 31));
 #else
 #pragma unroll
-    for (int i = 0; i < XI; ++i) xq[i] = buf_ld4(rs, xvoff, (16 * i * a.PW + px0) * 4);
+    for (int i = 0; i < XI; ++i) xq[i] = buf_ld4s(rs, xvoff, (16 * i * a.PW + px0) * 4);
 #endif
   };
   if ((int)blockIdx.x < a.ntiles) issue_x(blockIdx.x);

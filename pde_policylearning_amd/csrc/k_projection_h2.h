@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(NWAVE * 64, NWAVE / 2) k_proj_fwd_w(ProjFwdArg
     for (int kb = 0; kb < KB; ++kb) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = buf_ld1(rx, voff, (unsigned)(16 * kb + j) * PWb);
+      for (int j = 0; j < 8; ++j) v[j] = buf_ld1(rx, voff, (unsigned)(16 * kb + j) * PWb);      // (default policy: the projection backward re-reads u_L, last part first)
 #if FNO_PFW_SCALAR_ACT >= 2      // the column's own activation and split with scalar instructions too
       if (a.act_in) {
 #pragma unroll
