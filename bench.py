@@ -95,6 +95,20 @@ PMC_TRAFFIC_JSON = "r05_pmc_traffic.json"
 PMC_SQ_CSV = "r05_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
+# profile label -> the instantiation rocprofv3 --kernel-trace lists for it (headline workload, default GEMM mode)
+INSTANTIATION = {
+    "fno2d_128x128_w64_m12_b64": {
+        "k_block_bwd": "k_block_bwd_g2<false, false, 1, 2, true>",
+        "k_block_bwd0": "k_block_bwd_g2<true, false, 1, 2, true>",
+        "k_proj_bwd": "k_proj_bwd_t<64, 256, false, 2>",
+        "k_proj_fwd": "k_proj_fwd_w<64, 256, 12>",
+        "k_pw_fwd_block": "k_blk_fwd_s<true, 2, false> / <true, 1, false> / <false, 0, false> (blocks 1, 2, 3)",
+        "k_pw_fwd_block0": "k_blk_fwd_s<false, 2, true>",
+        "k_spec_mid": "k_spec_mid<12, 64>",
+    },
+}
+
+
 def source_hash():
     """sha1 over the engine's device + ABI sources: ties a committed counter file to the kernels it was collected on
     (the git sha cannot: committing the profile changes it)."""
@@ -435,6 +449,7 @@ def main():
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bk.close()      # (an overlapped bucket takes itself off the fused module: the other arm must not inherit it - ADVICE r05)
             return float(t.item()) / 3 * 1e3
         state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
         t_ov = probe(lambda: FlatGradBucket.for_fno(model, split_layer=1))
@@ -640,9 +655,13 @@ def main():
             ev_scale = min(1.0, (1e3 * dt / args.steps) / (tot / args.profile_steps))
         for name, ms, n, terms in sorted(prof, key=lambda r: -r[1]):
             avg_ev = ms / n
-            avg = avg_ev * ev_scale
+            # (the RAW event time is `avg_ms` and the basis of every rate below; the value scaled to the timed step
+            # is reported beside it - the event pairs' overhead is a per-launch constant, not proportional to the duration)
+            avg = avg_ev
             rec = dict(name=name, launches_per_step=n / args.profile_steps, avg_ms=round(avg, 4), avg_ms_events=round(avg_ev, 4),
-                       share=round(ms / tot, 3))
+                       avg_ms_scaled=round(avg_ev * ev_scale, 4), share=round(ms / tot, 3))
+            if name in INSTANTIATION.get(args.config, {}):
+                rec["instantiation"] = INSTANTIATION[args.config][name]
             if name in km:
                 pipe_name, pipe_peak = PIPE[terms if terms in PIPE else mode_terms]
                 rec["GBps"] = round(km[name]["bytes"] / avg / 1e6, 1)
@@ -698,8 +717,18 @@ def main():
                 pass
             roofline["avg_launch_ms"] = dom["avg_ms"]
             roofline["event_scale"] = round(ev_scale, 4)
-            roofline["measured"] = (f"HIP events on the launch stream, {args.profile_steps} profiled steps after the timed region; "
-                                    "event durations scaled by event_scale so that the engine kernels sum to the timed step")
+            if "instantiation" in dom:
+                roofline["instantiation"] = dom["instantiation"]      # the name rocprofv3 --kernel-trace shows for it
+            roofline["measured"] = (f"HIP events on the launch stream, {args.profile_steps} profiled steps after the timed region, "
+                                    "RAW event durations (event_scale = timed step / sum of event times, for reference only)")
+            # the kernel FURTHEST below its roof among those with >= 5 % of the step: `roofline` above is
+            # the one with the largest share
+            big = [k for k in kernels if k["name"] in km and k["share"] >= 0.05]
+            if big:
+                worst = min(big, key=lambda k: max(k["hbm_frac"], k["pipe_frac"]))
+                roofline["furthest_below_roof"] = dict(kernel=worst["name"], instantiation=worst.get("instantiation"),
+                                                        frac=max(worst["hbm_frac"], worst["pipe_frac"]), hbm_frac=worst["hbm_frac"],
+                                                        pipe_frac=worst["pipe_frac"], avg_launch_ms=worst["avg_ms"], share=worst["share"])
 
     # ---- CPU baseline: the oracle (validated restatement of the reference) on the host cores ----
     # Each measurement is its own process, pinned to physical cores of NUMA node 0 before torch creates its thread pool

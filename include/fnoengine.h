@@ -32,10 +32,17 @@ enum { FNO_NORM_BACKWARD = 0, FNO_NORM_FORWARD = 1, FNO_NORM_ORTHO = 2 };
 
 int fno_version(void);
 const char* fno_last_error(void);
-/* GEMM arithmetic of the fused model kernels: 1 (default) = every fp32 operand split into three
- * bf16 terms, six bf16 MFMA products, fp32 accumulation (error <= fp32 MFMA);
- * 0 = fp32 MFMA.  Environment FNO_GEMM_F32=1 selects 0 at load time. */
-void fno_set_gemm_mode(int split_bf16x3);
+/* GEMM arithmetic of the fused model kernels.
+ * 1 (default) = split precision, fp32 in / fp32 accumulate / fp32 out: every operand of a channel GEMM is scaled by a power of
+ *     two taken from a published bound of its magnitude and split into TWO fp16 terms x = h + l (22 significand bits); the
+ *     products h h', h l', l h' run on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16: THREE products per 16-deep k block),
+ *     hh and the cross terms in separate fp32 accumulators.  Where no bound is known before the operand is split (the
+ *     spectral K-extension's table and spectral rows, small-K extensions, kernels of models with fewer than 1024 tiles) the
+ *     operand is split into THREE bf16 terms instead and six products are kept (v_mfma_f32_32x32x16_bf16).  Error of either
+ *     form against float64 = the fp32 MFMA's own (1.5e-7 relative at K = 64; DESIGN.md sections 4, 4d).
+ * 0 = every GEMM on the exact fp32 matrix instruction (v_mfma_f32_32x32x2_f32).
+ * Environment FNO_GEMM_F32=1 selects 0 at load time. */
+void fno_set_gemm_mode(int split_precision);
 int fno_get_gemm_mode(void);
 /* The mode contraction 'bixy,ioxy->boxy' (spectral_convolution.py:15-36, rno.py:51-58, basics.py:14-24) and its two
  * adjoints: 1 (default) = one real GEMM per kept mode on the fp32 matrix cores (32 / 64 channels; other channel counts

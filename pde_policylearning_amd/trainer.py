@@ -7,6 +7,8 @@ matching collective is ONE all-reduce(SUM) of a flat gradient bucket with no ave
 `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI on MI355X nodes); "gloo" is used
 by the CPU tests.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -194,6 +196,13 @@ class FlatGradBucket(object):
         if direct_module is not None:
             for m in direct_module.modules():
                 if hasattr(m, "fused_supported"):
+                    # a new bucket for the model supersedes an overlapped one (for_fno) that was built on it before: the fused
+                    # module must not keep handing the old bucket to the engine (an extra async all-reduce of its late
+                    # segment per step, never waited for: ADVICE r05).  for_fno() installs itself again behind this constructor.
+                    old = getattr(m, "_grad_overlap", None)
+                    if old is not None:
+                        old._drop_inflight()
+                        m._grad_overlap = None
                     m._direct_grads = True
                     direct_ids.update(id(p) for p in m.parameters())
                 elif hasattr(m, "direct_grad_params"):
@@ -376,10 +385,22 @@ class FlatGradBucket(object):
         F.DIRECT_WRITE_HOOKS.append(self._direct_ref)
         return self
 
+    def _drop_inflight(self):
+        """wait for an asynchronous all-reduce of the late segment that nobody collected (for_fno)"""
+        work, self._inflight = getattr(self, "_inflight", None), None
+        if work is not None:
+            work.wait()
+
     def close(self):
-        """Detach from the parameters' gradient hooks and from functional.DIRECT_WRITE_HOOKS (a bucket that is dropped
-        without close() is released as well: both registrations hold weak references only)."""
+        """Detach from the parameters' gradient hooks, from functional.DIRECT_WRITE_HOOKS and - an overlapped bucket
+        (for_fno) - from the fused module it installed itself on (a bucket that is dropped without close() is released
+        as well: the registrations hold weak references only)."""
         from . import functional as F
+        self._drop_inflight()
+        fno = getattr(self, "_fno_ref", None)
+        fno = fno() if fno is not None else None
+        if fno is not None and getattr(fno, "_grad_overlap", None) is self:
+            fno._grad_overlap = None
         for h in getattr(self, "_hook_handles", []):
             h.remove()
         self._hook_handles = []
@@ -471,6 +492,7 @@ class FlatGradBucket(object):
         bucket._late_count = sum(1 for p in late if p.requires_grad)
         bucket._inflight = None
         bucket.split_layer = split_layer
+        bucket._fno_ref = weakref.ref(fno)
         fno._grad_overlap = bucket
         return bucket
 

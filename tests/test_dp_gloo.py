@@ -191,6 +191,32 @@ def test_overlapped_bucket_reduces_every_element_once(world):
     assert all(r[2] for r in res)
 
 
+def test_overlapped_bucket_does_not_outlive_its_replacement():
+    """FlatGradBucket.for_fno installs itself on the fused module (`_grad_overlap`), which hands it to the engine on
+    every forward.  A plain bucket built on the same model afterwards, or close() of the overlapped one, must take it off -
+    otherwise the 'single all-reduce' arm of bench.py's start-up probe keeps running the two-part backward and an extra,
+    never-awaited all-reduce of the stale bucket's late segment."""
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    from pde_policylearning_amd.trainer import FlatGradBucket
+    torch.manual_seed(0)
+    model = FNO2d(8, 8, 32)
+    fno = next(m for m in model.modules() if hasattr(m, "fused_supported"))
+    ov = FlatGradBucket.for_fno(model, split_layer=1)
+    assert fno._grad_overlap is ov
+    plain = FlatGradBucket(model.parameters(), direct_module=model)
+    assert fno._grad_overlap is None and ov._inflight is None
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(plain.params, plain.views(plain.flat)))
+    ov2 = FlatGradBucket.for_fno(model, split_layer=1)
+    assert fno._grad_overlap is ov2
+    ov2.close()
+    assert fno._grad_overlap is None
+    ov3 = FlatGradBucket.for_fno(model, split_layer=1)      # an overlapped bucket replaced by another one
+    ov4 = FlatGradBucket.for_fno(model, split_layer=2)
+    assert fno._grad_overlap is ov4
+    ov3.close()                                              # closing the superseded one leaves the live one installed
+    assert fno._grad_overlap is ov4
+
+
 class OraclePinoFF(nn.Module):
     """nn.Module facade over oracle.observers_oracle.pinobserver_fullfield_forward (reference parameter names of
     libs/models/pino_models/pinobserver.py: PINObserverFullField with plane_num 2, width 6, modes 3 x 3 x 4).  With the T = 1

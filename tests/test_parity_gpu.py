@@ -142,14 +142,15 @@ def _run_fused(p, x, n_modes, dev, n_layers=4):
     return y, pg
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["split", "f32"])
 def gemm_mode(request):
-    """Both arithmetic modes of the fused kernels' channel GEMMs: the 3-way bf16 split on the bf16 matrix pipe (default)
+    """Both arithmetic modes of the fused kernels' channel GEMMs: split precision on the 16-bit matrix pipe (default: two
+    fp16 terms and three products per k block where a magnitude bound is known, three bf16 terms and six products otherwise)
     and the exact fp32 MFMA (fno_set_gemm_mode(0) / FNO_GEMM_F32=1)."""
     from pde_policylearning_amd import _lib
     L = _lib.lib()
     prev = L.fno_get_gemm_mode()
-    L.fno_set_gemm_mode(1 if request.param == "bf16x3" else 0)
+    L.fno_set_gemm_mode(1 if request.param == "split" else 0)
     yield request.param
     L.fno_set_gemm_mode(prev)
 
