@@ -23,7 +23,6 @@
 #include "k_projection.h"
 #include "k_projection2.h"
 #include "k_projection_h2.h"
-#include "k_projection3.h"
 #include "k_spectral_mid.h"
 #include "k_pino_loss.h"
 #include "k_pino_loss2.h"
@@ -54,21 +53,17 @@ extern "C" int fno_version(void) { return FNO_VERSION; }
 // GEMM arithmetic of the fused model path: 1 = 3-term bf16 split on the matrix cores (fp32-grade,
 // default), 0 = fp32 MFMA.  FNO_GEMM_F32=1 in the environment selects 0 at load time.
 static int g_gemm_x3 = []() { const char* e = getenv("FNO_GEMM_F32"); return (e && e[0] == '1') ? 0 : 1; }();
-// Two-term fp16 channel GEMMs (fno_dev.h "h2": half the matrix-pipe work of the three-term bf16 split) where a kernel has
-// the variant and its operands' magnitude bounds are known: FNO_NO_H2=1 keeps bf16x3 everywhere (A/B arm)
-static int g_h2 = getenv("FNO_NO_H2") ? 0 : 1;
-static int g_h2_blocks = getenv("FNO_NO_H2_BLOCKS") ? 0 : 1;      // ... in the block kernels (the projection keeps it)
-// ... in the block FORWARD kernel (on since round 4: the sporadic wrong patches that kept it off in round 3 were the packed-fp32
-// op_sel hazard of fno_dev.h / tools/pk_opsel_hazard.hip, which natural_pair() now keeps out of the code); FNO_NO_H2_FWD_BLOCKS=1
-// restores the three-term bf16 forward (A/B arm)
-static int g_h2_fwd_blocks = getenv("FNO_NO_H2_FWD_BLOCKS") ? 0 : 1;
+// Two-term fp16 channel GEMMs (fno_dev.h "h2": half the matrix-pipe work of the three-term bf16 split) wherever a kernel has
+// the variant and its operands' magnitude bounds are known (the A/B switches of rounds 3-5 - FNO_NO_H2, FNO_NO_H2_BLOCKS,
+// FNO_NO_H2_FWD_BLOCKS - are retired: the three-term kernels remain as what runs when no bound is known)
+static constexpr int g_h2 = 1, g_h2_blocks = 1, g_h2_fwd_blocks = 1;
 extern "C" void fno_set_gemm_mode(int x3) { g_gemm_x3 = x3 ? 1 : 0; }
 extern "C" int fno_get_gemm_mode(void) { return g_gemm_x3; }
 extern "C" const char* fno_last_error(void) { return g_err.c_str(); }
 // mode contraction on the fp32 matrix cores (default) or the VALU kernels (FNO_MODE_GEMM_VALU=1 / fno_set_mode_gemm(0)):
 // an A/B switch for profiling and for the parity tests, which run both
 static int g_mode_mfma = []() { const char* e = getenv("FNO_MODE_GEMM_VALU"); return (e && e[0] == '1') ? 0 : 1; }();
-static const int g_mode_gemv = getenv("FNO_NO_MODE_GEMV") ? 0 : 1;      // A/B switch: weight-streaming kernels for tiny batches
+static constexpr int g_mode_gemv = 1;      // weight-streaming kernels for tiny batches (config 5 as named: 59.5 -> 52.3 ms, round 1)
 extern "C" void fno_set_mode_gemm(int mfma) { g_mode_mfma = mfma ? 1 : 0; }
 extern "C" int fno_get_mode_gemm(void) { return g_mode_mfma; }
 
@@ -232,7 +227,6 @@ static int upload(Tables& t, const void* host, size_t bytes, void** dev) {
   return FNO_OK;
 }
 
-static int g_pack_flat_early();
 static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int wl_stride, int norm, int w_planes = 0) {
   if (ndim != 2 && ndim != 3) return fail(FNO_EUNSUPPORTED, "ndim=%d (2 or 3 supported)", ndim);
   g.ndim = ndim;
@@ -260,7 +254,6 @@ static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int w
   g.wl_stride = wl_stride > 0 ? wl_stride : g.Klast;
   if (g.wl_stride < g.Klast) return fail(FNO_EINVAL, "weight_last_extent < modes[last]");
   g.w_planes = w_planes ? 1 : 0;
-  if (g.w_planes && g_pack_flat_early()) return fail(FNO_EUNSUPPORTED, "FNO_PACK_FLAT has no plane-major layout kernels");
   const double n = (double)g.PW;
   if (norm == FNO_NORM_FORWARD) { g.s_f = 1.0 / n; g.s_i = 1.0; }
   else if (norm == FNO_NORM_ORTHO) { g.s_f = 1.0 / std::sqrt(n); g.s_i = g.s_f; }
@@ -351,29 +344,31 @@ static ModeMap make_modemap(const Geom& g, int Cin, int Cout) {
 }
 
 
-static int g_pack_flat_early() { static const int v = getenv("FNO_PACK_FLAT") ? 1 : 0; return v; }
 // many -> few (twT transposed (n_in, n_out)) or few -> many (tw (n_out, n_in)); the small (kept) extent
 // is a template parameter of the fast kernels (2*m for the usual m = 2..20), anything else is generic.
+#define FNO_AXIS_GENERIC 1      // axis_pass_t: "take the generic kernel" (not an error code: those are negative)
 template <int NS>
 static int axis_pass_t(hipStream_t st, bool truncating, const float2* in, float2* out, const float2* tw, int outer,
                        int n_in, int n_out, int inner) {
   constexpr int SEGS = NS > 24 ? 4 : 8;      // partial sums [SEGS][NS][64] complex: 80 KB at NS = 40
+  // (>= 24 kept modes read their twiddle table from LDS instead of the scalar cache: k_axis_fwd<40> 0.47 -> 0.30 ms, round 1;
+  // `if constexpr`: the LDS-table variants of the smaller mode counts are not compiled)
   if (truncating) {
-    static const int tlds = getenv("FNO_AXIS_TABLE_SMEM") ? 0 : 1;       // A/B switch: table rows through the scalar cache
-    static const int tmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
     const size_t red = (size_t)SEGS * NS * 64 * 8, tab = (size_t)n_in * NS * 8;
-    if (tlds && NS >= tmin && (NS >= 32 || n_in >= 64) && std::max(red, tab) <= 96 * 1024)      // short sweeps: the copy does not pay
+    if constexpr (NS >= 24) {
+      if (std::max(red, tab) > 96 * 1024) return FNO_AXIS_GENERIC;      // (sweeps of > 300 rows: the generic kernel)
       return launch("k_axis_fwd_tlds", k_axis_fwd<NS, SEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), std::max(red, tab), st,
                     in, out, tw, n_in, inner);
+    } else
     return launch("k_axis_fwd", k_axis_fwd<NS, SEGS>, dim3((inner + 63) / 64, outer), dim3(64, SEGS), red, st, in, out, tw, n_in,
                   inner);
   }
   constexpr int ISEGS = NS > 24 ? 8 : 16;
-  static const int itlds = getenv("FNO_AXIS_TABLE_SMEM") ? 0 : 1;
-  static const int itmin = getenv("FNO_AXIS_TLDS_MIN") ? atoi(getenv("FNO_AXIS_TLDS_MIN")) : 24;
-  if (itlds && NS >= itmin && (NS >= 32 || n_out >= 64) && (size_t)n_out * NS * 8 <= 96 * 1024)
+  if constexpr (NS >= 24) {
+    if ((size_t)n_out * NS * 8 > 96 * 1024) return FNO_AXIS_GENERIC;
     return launch("k_axis_inv_tlds", k_axis_inv<NS, ISEGS, true>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), (size_t)n_out * NS * 8,
                   st, in, out, tw, n_out, inner);
+  } else
   return launch("k_axis_inv", k_axis_inv<NS, ISEGS>, dim3((inner + 63) / 64, outer), dim3(64, ISEGS), 0, st, in, out, tw,
                 n_out, inner);
 }
@@ -383,19 +378,20 @@ static int axis_pass(hipStream_t st, bool truncating, const float* in_, float* o
   const float2* in = (const float2*)in_;
   float2* out = (float2*)out_;
   const int small = truncating ? n_out : n_in;
-  switch (small) {
-    case 4: return axis_pass_t<4>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 6: return axis_pass_t<6>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 8: return axis_pass_t<8>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 10: return axis_pass_t<10>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 12: return axis_pass_t<12>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 16: return axis_pass_t<16>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 20: return axis_pass_t<20>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 24: return axis_pass_t<24>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 32: return axis_pass_t<32>(st, truncating, in, out, tw, outer, n_in, n_out, inner);
-    case 40: return axis_pass_t<40>(st, truncating, in, out, tw, outer, n_in, n_out, inner);   // modes 20: BASELINE config 5
+  int rc = FNO_AXIS_GENERIC;
+  switch (small) {      // the kept extent is a template parameter of the fast kernels (2 m for m = 2, 3, 4, 5, 6, 8, 12, 16, 20)
+    case 4: rc = axis_pass_t<4>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 6: rc = axis_pass_t<6>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 8: rc = axis_pass_t<8>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 10: rc = axis_pass_t<10>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 12: rc = axis_pass_t<12>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 16: rc = axis_pass_t<16>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 24: rc = axis_pass_t<24>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 32: rc = axis_pass_t<32>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;
+    case 40: rc = axis_pass_t<40>(st, truncating, in, out, tw, outer, n_in, n_out, inner); break;   // modes 20: BASELINE config 5
     default: break;
   }
+  if (rc != FNO_AXIS_GENERIC) return rc;
   if (n_out > 65535) return fail(FNO_EUNSUPPORTED, "axis pass grid too large (%d)", n_out);
   return launch("k_axis_generic", k_axis_generic, dim3((inner + 255) / 256, n_out, outer), dim3(256), 0, st, in, out,
                 tw, n_in, n_out, inner, truncating ? 1 : 0);
@@ -423,7 +419,7 @@ static int g_fused_mid = getenv("FNO_NO_FUSED_MID") ? 0 : 1;
 extern "C" void fno_set_fused_mid(int on) { g_fused_mid = on ? 1 : 0; }
 extern "C" int fno_get_fused_mid(void) { return g_fused_mid; }
 static bool fused_mid_shape_ok(const Geom& g, int C) {      // decides what the forward packs (the switch may flip before the backward)
-  if (g_pack_flat_early() || g.nlead != 1 || (C != 32 && C != 64) || (g.Klast * C) % 64 != 0) return false;
+  if (g.nlead != 1 || (C != 32 && C != 64) || (g.Klast * C) % 64 != 0) return false;
   if (g.dims[0] > 512) return false;             // the (n, Klead) tables are staged in the partial-sum region
   const int nk = g.Klead[0];
   // 24 kept modes: one workgroup per CU (123 KB of LDS), measured no faster than the three launches (RNO2d 128^2: 6.30 vs 6.26 ms)
@@ -461,7 +457,7 @@ static int spectral_mid_fused(hipStream_t st, const Geom& g, const Tables& t, bo
 // nm > 1: nm independent contractions in one launch (fan-out members); *_ms = member strides in floats (0 = shared operand).
 // Only the matrix-core kernels take members; callers check mode_gemm_members_ok() first.
 static bool mode_gemm_members_ok(int Cin, int Cout) {
-  return g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64);
+  return g_mode_mfma && Cin == Cout && (Cin == 32 || Cin == 64);      // (square blocks: what every model of the reference has)
 }
 static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out, int B, int Ktot, int Cin, int Cout,
                      int conj_w, int nm = 1, size_t x_ms = 0, size_t w_ms = 0, size_t o_ms = 0, int trans_w = 0) {
@@ -492,7 +488,7 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
     }
   }
   if (nm > 1 && !mode_gemm_members_ok(Cin, Cout)) return fail(FNO_EUNSUPPORTED, "batched mode contraction needs the matrix-core kernels");
-  if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {     // one real GEMM per mode on the matrix cores
+  if (mode_gemm_members_ok(Cin, Cout)) {     // one real GEMM per mode on the matrix cores
     // batch rows per workgroup (k_spectral_mid.h): 32 where the batch has no more AND the workgroup stays four waves
     // (64 output channels; at 32 channels the two-wave workgroup stages its weights too slowly: 10.7 vs 8.6 us at FNO3d)
     const int br = (B > 32 || Cout < 64) ? 64 : 32;
@@ -500,14 +496,10 @@ static int mode_gemm(hipStream_t st, const float* x, const float* w, float* out,
     const size_t lds = (size_t)br * (2 * Cin + 1) * 4 + (size_t)std::max(Cin * (Cout + 1), Cout * (Cin + 1)) * 8;      // spectra + the complex weight block
     const float2 *xx = (const float2*)x, *ww = (const float2*)w;
     float2* oo = (float2*)out;
-#define MGK(CI_, CO_) do { \
-      if (br == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<CI_, CO_, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w); \
-      return launch("k_mode_gemm", k_mode_gemm_mfma<CI_, CO_, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w); } while (0)
-    if (Cin == 32 && Cout == 32) MGK(32, 32);
-    if (Cin == 32 && Cout == 64) MGK(32, 64);
-    if (Cin == 64 && Cout == 32) MGK(64, 32);
-    MGK(64, 64);
-#undef MGK
+    if (Cin == 32)      // (br = 64 always at 32 channels, above)
+      return launch("k_mode_gemm", k_mode_gemm_mfma<32, 32, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+    if (br == 64) return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64, 64>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
+    return launch("k_mode_gemm", k_mode_gemm_mfma<64, 64, 32>, grid, blk, lds, st, xx, ww, oo, B, Ktot, conj_w, x_ms / 2, w_ms / 2, o_ms / 2, trans_w);
   }
   if (512 % Cout == 0 && Cout >= 32) {
     const int bt = 2 * (512 / Cout);                   // 2 batch rows per thread
@@ -536,7 +528,7 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
       default: return launch("k_mode_outer_dw", k_mode_outer_dw<4>, grid, blk, 0, st, xx, gg, dd, Ktot, Cin, Cout);
     }
   }
-  if (g_mode_mfma && (Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64)) {
+  if (mode_gemm_members_ok(Cin, Cout)) {
     const dim3 grid(Ktot, nm), blk((Cin / 32) * (2 * Cout / 32) * 64);
     const int bc = B > 32 ? 32 : 16;      // samples staged per chunk (k_spectral_mid.h)
     const size_t lds = ((size_t)bc * 2 * Cin + (size_t)2 * bc * (2 * Cout + 32)) * 4;
@@ -545,9 +537,7 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
 #define DWK(CI_, CO_) do { \
       if (bc == 32) return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<CI_, CO_, 32>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2); \
       return launch("k_mode_gemm_dw", k_mode_gemm_dw_mfma<CI_, CO_, 16>, grid, blk, lds, st, xx, gg, dd, B, Ktot, x_ms / 2, g_ms / 2, d_ms / 2); } while (0)
-    if (Cin == 32 && Cout == 32) DWK(32, 32);
-    if (Cin == 32 && Cout == 64) DWK(32, 64);
-    if (Cin == 64 && Cout == 32) DWK(64, 32);
+    if (Cin == 32) DWK(32, 32);
     DWK(64, 64);
 #undef DWK
   }
@@ -561,7 +551,6 @@ static int mode_gemm_dw(hipStream_t st, const float* x, const float* g, float* d
   return launch("k_mode_gemm_dw", k_mode_gemm_dw, grid, dim3(256), 0, st, (const float2*)x, (const float2*)g,
                 (float2*)dw, B, Ktot, Cin, Cout);
 }
-static const int g_pack_flat = getenv("FNO_PACK_FLAT") ? 1 : 0;      // A/B switch: thread-per-element layout kernels
 // all layers of a stack in one launch each way (blockIdx.y = layer); wp / wpt nullable; `stride` = floats between layers
 static int nrest_of(const Geom& g) { return g.nlead == 2 ? g.modes[0] * g.modes[1] : g.modes[0]; }
 static int plane_rc(int nrest) { int rc = 64; while (rc > 8 && rc / 2 >= nrest) rc >>= 1; return rc; }      // rest positions per tile
@@ -605,37 +594,16 @@ static int unpack_dw_layers(hipStream_t st, const Geom& g, int Cin, int Cout, co
                 (const float2*)dwp, cp, mm, stride / 2, nrest);
 }
 static int pack_w(hipStream_t st, const Geom& g, int Cin, int Cout, const float* const* corners, float* wp, float* wpt) {
-  if (!g_pack_flat) {
-    CornerPtrsL cpl;
-    memset(&cpl, 0, sizeof(cpl));
-    for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (const float2*)corners[c];
-    return pack_w_layers(st, g, Cin, Cout, cpl, 1, wp, wpt, 0);
-  }
-  CornerPtrs cp;
-  for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (const float2*)corners[c] : nullptr;
-  const ModeMap mm = make_modemap(g, Cin, Cout);
-  const size_t n = (size_t)g.Ktot * Cin * Cout;
-  return launch("k_pack_w", k_pack_w, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cp, (float2*)wp,
-                (float2*)wpt, mm);
+  CornerPtrsL cpl;
+  memset(&cpl, 0, sizeof(cpl));
+  for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (const float2*)corners[c];
+  return pack_w_layers(st, g, Cin, Cout, cpl, 1, wp, wpt, 0);
 }
 static int unpack_dw(hipStream_t st, const Geom& g, int Cin, int Cout, const float* dwp, float* const* dcorners) {
-  if (!g_pack_flat) {
-    CornerPtrsMutL cpl;
-    memset(&cpl, 0, sizeof(cpl));
-    for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (float2*)dcorners[c];
-    return unpack_dw_layers(st, g, Cin, Cout, dwp, cpl, 1, 0);
-  }
-  CornerPtrsMut cp;
-  for (int c = 0; c < 4; ++c) cp.p[c] = (c < (1 << g.nlead)) ? (float2*)dcorners[c] : nullptr;
-  const ModeMap mm = make_modemap(g, Cin, Cout);
-  size_t per = (size_t)g.modes[0] * g.wl_stride;
-  if (g.nlead == 2) per *= g.modes[1];
-  if (per > 0x7fffffffull / 2) return fail(FNO_EUNSUPPORTED, "corner weight of %zu entries per channel pair", per);
-  int bx = 256;
-  while (bx > 16 && (size_t)bx / 2 >= per) bx >>= 1;
-  const int by = 256 / bx, rows = (1 << g.nlead) * Cin * Cout;
-  return launch("k_unpack_dw", k_unpack_dw, dim3((unsigned)((rows + by - 1) / by), (unsigned)((per + bx - 1) / bx)), dim3(bx, by),
-                0, st, (const float2*)dwp, cp, mm, (int)per);
+  CornerPtrsMutL cpl;
+  memset(&cpl, 0, sizeof(cpl));
+  for (int c = 0; c < (1 << g.nlead); ++c) cpl.p[0][c] = (float2*)dcorners[c];
+  return unpack_dw_layers(st, g, Cin, Cout, dwp, cpl, 1, 0);
 }
 static int reduce_slabs(hipStream_t st, const float* part, float* out, int nslab, int rows, int ncols, int ld_in,
                         int ld_out) {
@@ -767,12 +735,10 @@ static int row_forward(hipStream_t st, const Geom& g, const float* tfwd, const f
     if (C == 32) return launch("k_rowdft_tile", k_rowdft_tile<32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowdft_tile", k_rowdft_tile<64, 128>, dim3(grid), dim3(256), lds, st, a);
   }
-  static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
-  static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 320;
-  if ((chan || act_in) && K2P) {
+  constexpr int chan_rb = 320;
+  if (K2P) {
     // long 16-byte-aligned runs when the rows allow it: 8 channels x rb rows, rb * W % 4 == 0, P % rb == 0
-    static const int run4 = getenv("FNO_ROW_RUN4") ? atoi(getenv("FNO_ROW_RUN4")) : 1;
-    if (run4 && C % 8 == 0) {
+    if (C % 8 == 0) {
       const int q = (g.W % 4 == 0) ? 1 : (g.W % 2 == 0 ? 2 : 4);            // rows per 16-byte period
       const int tabf = 2 * K2P * rowdft4_pitch((g.W + 3) & ~3) + 4;         // table + slack floats in the same LDS
       int rb = std::min(2560 / g.W, (int)(((80 * 1024 / 4 - tabf) / 8 - 36) / g.W)) / q * q;
@@ -830,21 +796,18 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, const f
     if (C == 32) return launch("k_rowidft_tile", k_pw_fwd<2, 32, 128>, dim3(grid), dim3(256), lds, st, a);
     return launch("k_rowidft_tile", k_pw_fwd<2, 64, 128>, dim3(grid), dim3(512), lds, st, a);
   }
-  static const int chan = getenv("FNO_ROW_CHAN") ? atoi(getenv("FNO_ROW_CHAN")) : 1;
-  static const int chan_rb = getenv("FNO_ROW_RB") ? atoi(getenv("FNO_ROW_RB")) : 4;
-  if (chan && K2P) {
+  constexpr int chan_rb = 4;
+  if (K2P) {
     // rows per workgroup: runs of <= 320 floats per channel, tile <= 78 KB (two workgroups per CU), >= 4 tiles per CU
     int rb = std::max(1, std::min(chan_rb, 320 / g.W));
     while (rb > 1 && ((size_t)C * (rb * g.W + 1) * 4 > 78 * 1024 || (long)B * ((g.P + rb - 1) / rb) < 4L * dev_ncu())) rb >>= 1;
     const size_t lds2 = (size_t)C * (rb * g.W + 1) * 4;
-    static const int chan_mfma = getenv("FNO_ROW_INV_VALU") ? 0 : 1;
-    if (chan_mfma && C % 32 == 0 && g.W >= 32 && g.W <= 128) {   // truncated inverse DFT on the fp32 matrix cores (short rows would waste the 32-column tiles)
+    if (C % 32 == 0 && g.W >= 32 && g.W <= 128) {   // truncated inverse DFT on the fp32 matrix cores (short rows would waste the 32-column tiles)
       const size_t tabb = (size_t)2 * g.Klast * (((g.W + 31) / 32) * 32 + 4) * 4;
-      static const int flat = getenv("FNO_ROW_INV_ROWTILES") ? 0 : 1;
       const size_t ldsf = (size_t)C * (ROWFLAT_CH + 4) * 4 + tabb;
-      if (flat && g.PW % 4 == 0 && g.W < ROWFLAT_CH && ldsf <= 160 * 1024 && B <= 65535) {     // whole-line tiles of the flattened planes
+      if (g.PW % 4 == 0 && g.W < ROWFLAT_CH && ldsf <= 160 * 1024 && B <= 65535) {     // whole-line tiles of the flattened planes
         const dim3 gridf((g.PW + ROWFLAT_CH - 1) / ROWFLAT_CH, B);
-        static const int flat_threads = getenv("FNO_ROWFLAT_THREADS") ? atoi(getenv("FNO_ROWFLAT_THREADS")) : 512;
+        constexpr int flat_threads = 512;
         if (K2P == 8) return launch("k_rowidft_chan", k_rowidft_flat_mfma<8>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
         if (K2P == 16) return launch("k_rowidft_chan", k_rowidft_flat_mfma<16>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
         return launch("k_rowidft_chan", k_rowidft_flat_mfma<32>, gridf, dim3(flat_threads), ldsf, st, (const float2*)z, y, tinv, bias, C, g.P, g.W, g.Klast);
@@ -1024,10 +987,9 @@ extern "C" int fno_model_plan_create(const FnoModelDesc* d, FnoModelPlan** out) 
   if (rc == FNO_OK) {
     const int W = p->g.W;
     p->loose = false;
-    static const int no_loose = getenv("FNO_NO_LOOSE") ? 1 : 0;      // A/B switch: loose-row stacks fall back to the chained layers
     const int npx_tiled = W > 128 ? 256 : 128;
     const bool tiles = W % 32 == 0 && W <= 256 && npx_tiled % W == 0 && p->g.PW % npx_tiled == 0;
-    if (!no_loose && !tiles && W >= 32 && W <= 320 && p->g.PW % 128 == 0 && p->g.Klast <= 32) {
+    if (!tiles && W >= 32 && W <= 320 && p->g.PW % 128 == 0 && p->g.Klast <= 32) {
       // "loose rows" (the PINO observers' padded time axis, 73; FNO grids such as 96 x 96 or 160 x 160): 128-pixel tiles of
       // the flattened plane; the block kernels take the spectral rows that overlap their tile (kext_loose_rows) and the
       // last-dim forward transforms
@@ -1177,16 +1139,13 @@ static int launch_lift(const FnoModelPlan* p, hipStream_t st, int grid, const Pw
 }
 // block 0 of a model with a lifting layer computes u_0 = W_l x + b_l itself (forward on load, backward from the input rows it
 // stages anyway) when both of its kernels are the split-precision 128-pixel ones: u_0 then never travels through HBM
-static const int g_no_lift_fuse = getenv("FNO_NO_LIFT_FUSE") ? 1 : 0;      // A/B switch
 static bool lift_fused(const FnoModelPlan* p) {
-  return !g_no_lift_fuse && p->d.Cin > 0 && g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !p->loose;
+  return p->d.Cin > 0 && g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !p->loose;
 }
-// second-generation block forward (k_block_fwd2.h): whole rows in 128-pixel tiles; FNO_BFWD_V1=1 keeps k_pw_fwd_x3 (A/B arm)
-static const int g_bfwd_v1 = getenv("FNO_BFWD_V1") ? 1 : 0;
-static const int g_grid_bf2 = getenv("FNO_GRID_BF2") ? atoi(getenv("FNO_GRID_BF2")) : 0;   // 0: 2 per CU at 64 channels, 3 at 32
+// second-generation block forward (k_block_fwd2.h): whole rows in 128-pixel tiles, two workgroups per CU
 template <int C>
 static bool blk_fwd_t_ok(const FnoModelPlan* p, const PwFwdArgs& a, size_t* lds) {
-  if (g_bfwd_v1 || p->NPX != 128 || p->loose || !a.x) return false;
+  if (p->NPX != 128 || p->loose || !a.x) return false;
   if ((size_t)a.PW * 4 * C >= (size_t)1 << 31) return false;          // 32-bit buffer offsets within one sample
   if (a.z && a.K2in > 8) return false;      // more than 8 kept last-dim modes (two extension k blocks, e.g. RNO2d at 12): k_pw_fwd_x3
                                             // is as fast or faster (RNO2d 128^2: 0.085 vs 0.108 ms per launch)
@@ -1217,10 +1176,10 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
   // (64 channels only: blk_fwd_t_ok refuses 32, where k_pw_fwd_x3 measured faster - `if constexpr` so that the 33 instantiations
   // nothing can launch are not compiled: tools/kernel_coverage.py, round 5)
   if constexpr (C == 64) if (blk_fwd_t_ok<C>(p, a_in, &lds2)) {
-    const dim3 g2(std::min(a.ntiles, (g_grid_bf2 > 0 ? g_grid_bf2 : (C == 64 ? 2 : 3)) * p->ncu)), blk((C / 32) * 2 * 64);
+    const dim3 g2(std::min(a.ntiles, 2 * p->ncu)), blk((C / 32) * 2 * 64);
     const int epi = a.x1 ? (a.act_out ? 2 : 1) : 0;
     // two workgroups per CU: the one dispatched first gets the larger share of the CU's tiles (pair_share, fno_dev.h)
-    static const int share_bf = getenv("FNO_BF_SHARE") ? std::min(32, std::max(0, atoi(getenv("FNO_BF_SHARE")))) : 18;      // of 32; 0 / 16 = even
+    constexpr int share_bf = 20;      // of 32 (16 = even): 2.111 / 2.114 / 2.103 / 2.110 ms per step at 18 / 16 / 20 / 22 (round 6, one box)
     PwFwdArgs a = a_in;
     a.share32 = ((int)g2.x == 2 * p->ncu) ? share_bf : 0;
     // (template flags: LIFT, RELU, ACT_IN, EPI, ADD - k_block_fwd2.h; other combinations keep k_pw_fwd_x3)
@@ -1242,24 +1201,21 @@ static int launch_block_x3(const FnoModelPlan* p, hipStream_t st, int grid, cons
       BF3(false, 0);
 #undef BF3
     }
-#define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_) do { \
-    if (h2k && !(RELU_) && !(ADD_)) \
-      return GT(2), launch(nm, k_blk_fwd_t<C, LIFT_, false, AIN_, EPI_, false, 1, 2>, g2, blk, lds2, st, a); \
-    if (kz == 0) return GT(3), launch(nm, k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 0>, g2, blk, lds2, st, a); \
-    return GT(3), launch(nm, k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, 1>, g2, blk, lds2, st, a); } while (0)
-    if (a.lw && !a.relu_out && !a.add) {
-      if (epi == 2) BF2(true, false, false, 2, false);
-      if (epi == 1) BF2(true, false, false, 1, false);
-      BF2(true, false, false, 0, false);
+    // k_blk_fwd_t (three-term variants: its two-term ones were replaced by the strip kernel above) for the flag combinations the
+    // models and layer stacks of the reference produce - every instantiation below is launched by the GPU test suite
+    // (tools/kernel_coverage.py); anything else takes k_pw_fwd_x3, which has every option as a run-time argument.
+    // (template flags: LIFT, RELU, ACT_IN, EPI, ADD, KZ)
+#define BF2(LIFT_, RELU_, AIN_, EPI_, ADD_, KZ_) return GT(3), launch(nm, k_blk_fwd_t<C, LIFT_, RELU_, AIN_, EPI_, ADD_, KZ_>, g2, blk, lds2, st, a)
+    const bool plain = !a.lw && !a.relu_out && !a.add;
+    if (kz == 1) {
+      if (a.lw && !a.relu_out && !a.add && epi == 2) BF2(true, false, false, 2, false, 1);
+      if (plain && a.act_in) { if (epi == 2) BF2(false, false, true, 2, false, 1); if (epi == 1) BF2(false, false, true, 1, false, 1); BF2(false, false, true, 0, false, 1); }
+      if (plain) { if (epi == 2) BF2(false, false, false, 2, false, 1); if (epi == 1) BF2(false, false, false, 1, false, 1); BF2(false, false, false, 0, false, 1); }
+      if (!a.lw && a.relu_out && !a.add && epi == 0 && !a.act_in) BF2(false, true, false, 0, false, 1);
+    } else if (kz == 0 && epi == 0 && !a.lw && !a.relu_out) {      // pointwise layers (no spectral branch), with or without an addend
+      if (a.add) { if (a.act_in) BF2(false, false, true, 0, true, 0); BF2(false, false, false, 0, true, 0); }
+      if (!a.act_in) BF2(false, false, false, 0, false, 0);
     }
-    if (!a.lw && !a.relu_out && !a.add) {
-      if (a.act_in) { if (epi == 2) BF2(false, false, true, 2, false); if (epi == 1) BF2(false, false, true, 1, false); BF2(false, false, true, 0, false); }
-      if (epi == 2) BF2(false, false, false, 2, false);
-      if (epi == 1) BF2(false, false, false, 1, false);
-      BF2(false, false, false, 0, false);
-    }
-    if (!a.lw && !a.relu_out && a.add && epi == 0) { if (a.act_in) BF2(false, false, true, 0, true); BF2(false, false, false, 0, true); }
-    if (!a.lw && a.relu_out && !a.add && epi == 0 && !a.act_in) BF2(false, true, false, 0, false);
 #undef BF2
   }
   const size_t lds = pw_fwd_x3_lds_bytes(C, p->NPX, a.W, a.K2in, a.NJ, a.z != nullptr, a.x1 != nullptr) +
@@ -1286,12 +1242,6 @@ static int launch_block(const FnoModelPlan* p, hipStream_t st, int grid, const P
   if (p->d.C == 32) return launch_pw<32, 32>(p, st, grid, a, "k_pw_fwd_block");
   return launch_pw<64, 64>(p, st, grid, a, "k_pw_fwd_block");
 }
-static size_t bbwd_x3_lds(int C, int npx, const BlkBwdArgs& a) {
-  return (size_t)6 * C * (npx + 8) * 2 +
-         ((size_t)C * (npx + 4) + (a.xin ? 8 * (npx + 4) : 0) +
-          (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(npx / a.W) * a.K2in * C * 2 : 0) +
-          (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
-}
 // k_block_bwd_t (k_block_bwd2.h): two swizzled [3][C][128] bf16 images, the fp32 gout tile, two lifting-input buffers, tables
 static size_t bbwd_t_lds(int C, const BlkBwdArgs& a) {
   return (size_t)6 * C * 256 +
@@ -1311,7 +1261,6 @@ static size_t bbwd_g2_lds(const BlkBwdArgs& a, int nterm = 3) {
 }
 template <int C>
 static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const BlkBwdArgs& a_in, bool* published = nullptr) {
-  static const int kx_f32 = getenv("FNO_BBWD_KEXT_F32") ? 1 : 0;      // A/B switch: the K-extension of k_block_bwd_g2 as fp32 MFMAs
   BlkBwdArgs a = a_in;
   // profile labels: block 0 behind a lifting layer reads g and the model input and writes no gradient tile unless dx is asked for
   const char* nm = (a_in.xin && !a_in.gout) ? "k_block_bwd0" : "k_block_bwd";
@@ -1319,9 +1268,8 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
   const size_t pitch = p->NPX + 4;
   const bool h2 = g_h2 && g_h2_blocks && a.gmax_in && a.umax;      // two-term fp16 variants (operand bounds known)
   const int g2_terms = h2 ? 2 : 3;
-  a.kx16 = (!kx_f32 && C == 64 && a.zg && a.K2in <= 8) ? 1 : 0;
+  a.kx16 = (C == 64 && a.zg && a.K2in <= 8) ? 1 : 0;
   if (a.kx16 && bbwd_g2_lds(a, g2_terms) > 160 * 1024) a.kx16 = 0;
-  static const int v1 = getenv("FNO_BBWD_V1") ? 1 : 0;        // A/B switch: the first-generation split-precision kernel
   if (a.drop_seed) {      // dropout of the spectral branch (one-layer stacks with a tail, fno_model_*_tail)
     if (p->loose || a.lw || a.xin || !g_gemm_x3 || p->NPX != 128 || bbwd_t_lds(C, a) > 160 * 1024)
       return fail(FNO_EUNSUPPORTED, "spectral-branch dropout: split-precision GEMM mode, 128-pixel tiles of whole rows, no lifting");
@@ -1334,7 +1282,7 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
     const int rows = 128 / a.W + 2;
     BlkBwdArgs nz = a;
     nz.zg = nullptr;
-    const size_t base = v1 ? bbwd_x3_lds(C, 128, nz) : bbwd_t_lds(C, nz);   // everything but the spectral rows and their table
+    const size_t base = bbwd_t_lds(C, nz);   // everything but the spectral rows and their table
     const size_t per_mode = ((size_t)2 * a.W + (size_t)rows * C * 2) * 4;
     size_t ldsl = base;
     if (a.zg) {
@@ -1344,55 +1292,43 @@ static int launch_bbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const 
       al.kch = kch < a.K2in ? kch : 0;
       ldsl = base + kch * per_mode;
     }
-    if (v1)
-      return GT(3), launch(al.kch ? nm_kch : nm, k_block_bwd_x3<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
     return GT(3), launch(al.kch ? nm_kch : nm, k_block_bwd_t<C, 128, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), ldsl, st, al);
   }
   // C = 64, rows of 32 / 64 / 128 pixels: two independent 4-wave groups per workgroup (k_block_bwd_g2)
-  static const int no_g2 = getenv("FNO_BBWD_NO_G2") ? 1 : 0;
-  static const int no_lines = getenv("FNO_BBWD_NO_LINES") ? 1 : 0;      // A/B switch: u loaded / gout stored 16 bytes per channel row
   if constexpr (C == 64) {
-    a.lines = (no_lines || !h2) ? 0 : 1;      // (the two-term variants carry it)
-    if (a.lines && bbwd_g2_lds(a, g2_terms) > 160 * 1024) a.lines = 0;
-    if (g_gemm_x3 && FNO_BBWD_X3 && !v1 && !no_g2 && p->NPX == 128 && (a.W == 32 || a.W == 64 || a.W == 128) &&
+    a.lines = h2 ? 1 : 0;      // whole-line u loads / gout stores (round 6): the two-term variants carry them
+    if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && (a.W == 32 || a.W == 64 || a.W == 128) &&
         (!a.x1g || a.NJ <= 2) && a.ntiles >= 2 && bbwd_g2_lds(a, g2_terms) <= 160 * 1024) {
       const int g2 = grid;      // the host sums `grid` partial slabs per output: groups without a tile write zeros
       const size_t lds2 = bbwd_g2_lds(a, g2_terms);
       const bool two = a.x1g && a.W == 128 && a.NJ == 2;
       if (a.lw && !a.x1g && !a.gadd) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2 && a.lines) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
-        if (h2) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch(nm, k_block_bwd_g2<true, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
         return GT(3), launch(nm, k_block_bwd_g2<true, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
       // (gradient addends and two 16-output blocks per wave do not fit the register budget yet: k_block_bwd_t takes those)
       if (!a.lw && !a.xin && !a.gadd && !two) {
         if (published) *published = a.gmax_out != nullptr;
-        if (h2 && a.lines) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
-        if (h2) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2>, dim3(g2), dim3(512), lds2, st, a);
+        if (h2) return GT(2), launch(nm, k_block_bwd_g2<false, false, 1, 2, true>, dim3(g2), dim3(512), lds2, st, a);
         return GT(3), launch(nm, k_block_bwd_g2<false, false, 1>, dim3(g2), dim3(512), lds2, st, a);
       }
     }
   }
   if (a.lw) {
-    if (!(g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024))
+    if (!(g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_t_lds(C, a) <= 160 * 1024))
       return fail(FNO_EUNSUPPORTED, "block 0 cannot recompute the lifting in this GEMM mode (the forward pass skipped u_0)");
-    if (!v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
-      if (published) *published = a.gmax_out != nullptr;
-      if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-      return GT(3), launch(nm, k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
-    }
-    return GT(3), launch(nm, k_block_bwd_x3<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
-                  bbwd_x3_lds(C, 128, a), st, a);
-  }
-  if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && !v1 && bbwd_t_lds(C, a) <= 160 * 1024) {
     if (published) *published = a.gmax_out != nullptr;
-    if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    if constexpr (C == 32)      // (64 channels: k_block_bwd_g2 above carries the two-term variants)
+      if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, true, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+    return GT(3), launch(nm, k_block_bwd_t<C, 128, false, true>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
+  }
+  if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_t_lds(C, a) <= 160 * 1024) {
+    if (published) *published = a.gmax_out != nullptr;
+    if constexpr (C == 32)
+      if (h2) return GT(2), launch(nm, k_block_bwd_t<C, 128, false, false, false, 2>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
     return GT(3), launch(nm, k_block_bwd_t<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64), bbwd_t_lds(C, a), st, a);
   }
-  if (g_gemm_x3 && FNO_BBWD_X3 && p->NPX == 128 && bbwd_x3_lds(C, 128, a) <= 160 * 1024)
-    return GT(3), launch(nm, k_block_bwd_x3<C, 128>, dim3(grid), dim3(BlkBwdCfg<C, 128>::NW * 64),
-                  bbwd_x3_lds(C, 128, a), st, a);
   const size_t lds = ((size_t)2 * C * pitch + (a.xin ? 8 * pitch : 0) +
                       (a.zg ? (size_t)2 * a.K2in * a.W + (size_t)(p->NPX / a.W) * a.K2in * C * 2 : 0) +
                       (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) : 0)) * 4;
@@ -1412,21 +1348,15 @@ static int bbwd_ksplit(const FnoModelPlan* p) {
 template <int C, int NCO>
 static int launch_pfwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const ProjFwdArgs& a) {
   // no row structure in the projection: always 128-pixel tiles
-  static const int no_pfw = getenv("FNO_NO_PFWD_W") ? 1 : 0;       // A/B switch: the 8-wave tile kernel (k_proj_fwd_h2) instead
-  if (g_gemm_x3 && g_h2 && a.xmax && NCO == 1 && !no_pfw && a.PW % 32 == 0) {
+  if (g_gemm_x3 && g_h2 && a.xmax && NCO == 1 && a.PW % 32 == 0) {
     // independent waves, four per SIMD (k_projection_h2.h): two workgroups per CU
     constexpr int NWV = 12;
     const int ncols = a.ntiles * 4;
-    static const int share_pf = getenv("FNO_PFW_SHARE") ? std::min(32, std::max(0, atoi(getenv("FNO_PFW_SHARE")))) : 18;      // of 32; 0 / 16 = even (pair_share)
+    constexpr int share_pf = 18;      // of 32; 16 = even (pair_share)
     const int g = std::min((ncols + NWV - 1) / NWV, 2 * p->ncu);
     ProjFwdArgs aw = a;
     aw.share32 = g == 2 * p->ncu ? share_pf : 0;
     return GT(2), launch("k_proj_fwd", k_proj_fwd_w<C, kHID, NWV>, dim3(g), dim3(NWV * 64), proj_fwd_w_lds(C, kHID), st, aw);
-  }
-  if (g_gemm_x3 && g_h2 && a.xmax) {
-    const size_t lds = (size_t)2 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 2 * 64 * 16 +
-                       (size_t)(kHID + NCO * kHID + NCO * 128) * 4;
-    return GT(2), launch("k_proj_fwd", k_proj_fwd_h2<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   }
   if (g_gemm_x3) {
     const size_t lds = (size_t)3 * 128 * (C + 8) * 2 + (size_t)(kHID / 32) * (C / 16) * 3 * 64 * 16 +
@@ -1454,54 +1384,29 @@ static int launch_pbwd_cn(const FnoModelPlan* p, hipStream_t st, int grid, const
     return GT(1), launch("k_proj_bwd", k_proj_bwd<C, kHID, 128, NCO>, dim3(grid), dim3(512), lds, st, a);
   return GT(1), launch("k_proj_bwd", k_proj_bwd<C, kHID, 256, NCO>, dim3(grid), dim3(1024), lds, st, a);
 }
-static size_t pbwd_x3_lds(int C, int npx, int nco) {
-  return ((size_t)3 * npx * (C + 8) + (size_t)3 * C * (npx + 8) + (size_t)3 * 64 * (npx + 8)) * 2 +
-         ((size_t)nco * npx + kHID + (size_t)nco * kHID) * 4;
-}
 // second-generation projection backward (k_projection2.h): C = 64, one output channel, 128-pixel tiles, split-precision mode
 static size_t pbwd_t_lds(int C, const ProjBwdArgs& a) {
   const size_t nt = a.amax ? 2 : 3;       // term planes per image
   return nt * C * 256 + 2 * nt * 64 * 256 + 128 * 4 + (a.x1g ? (size_t)16 * a.NJ * (a.W + 4) * 4 : 0);
 }
 static bool use_pbwd_t(int C, int CO, int npx) {
-  static const int v1 = getenv("FNO_PBWD_V1") ? 1 : 0;        // A/B switch: the first-generation kernel
-  return !v1 && g_gemm_x3 && (C == 64 || C == 32) && CO == 1 && npx == 128;
+  return g_gemm_x3 && (C == 64 || C == 32) && CO == 1 && npx == 128;
 }
 // W1 -> bf16x3 fragments in the order the selected projection-backward kernel reads them
 static int pack_w1_x3(hipStream_t st, const float* w1, unsigned short* wa1, unsigned short* wa3, int HID, int C, bool t_order,
                       const float* wmax = nullptr) {
   const int nitems = (HID / 32) * (C / 16) * 64 + (HID / 32) * 2 * (C / 32) * 64;
-  if (t_order && wmax)      // two fp16 terms (k_proj_bwd_t<.., 2>): scaled by the weights' magnitude bound
-    return launch("k_pack_w1_x3", k_pack_w1_t<2>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
-  if (t_order) return launch("k_pack_w1_x3", k_pack_w1_t<3>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
-  return launch("k_pack_w1_x3", k_pack_w1_x3, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C);
-}
-// third-generation projection backward (k_projection3.h: one 16-wave workgroup per CU, four waves per SIMD): 64 channels, one
-// output channel, two fp16 terms (every operand bound published), rows of 32 / 64 / 128 floats or no row-DFT epilogue.
-// Measured SLOWER than k_proj_bwd_t (0.67 vs 0.50 ms at BASELINE config 2; DESIGN.md section 4f says why: the packed-fp32
-// vector work and the matrix products of different waves do not overlap on a SIMD, so four waves per SIMD buy nothing, and
-// the 64-pixel half tiles cost 37 % more vector instructions): an A/B arm, selected with FNO_PBWD_Q=1
-static bool use_pbwd_q(const FnoModelPlan* p, int C, const ProjBwdArgs& a) {
-  static const int use_q = getenv("FNO_PBWD_Q") ? 1 : 0;
-  if (!use_q || C != 64 || !a.wa1 || !a.amax || !a.xmax || !use_pbwd_t(C, a.CO, p->NPX)) return false;
-  if (a.x1g && !(a.W == 32 || a.W == 64 || a.W == 128)) return false;
-  if (a.x1g && 4 * (64 / std::min(a.W, 64)) * a.NJ > 8) return false;      // row-DFT jobs of a half tile: one per spare wave
-  return proj_bwd_q_lds(kHID, a.W, a.NJ, a.x1g != nullptr) <= 160 * 1024;
+  // (the two-term fragments of k_proj_bwd_t<.., 2> are made by k_absmax3_pack_w1, in the launch that scans the bounds)
+  if (wmax) return fail(FNO_EUNSUPPORTED, "projection weight fragments: two-term split without the bound scan");
+  if (!t_order) return fail(FNO_EUNSUPPORTED, "projection weight fragments: k_proj_bwd_t's order only");
+  return launch("k_pack_w1_x3", k_pack_w1_t<3>, dim3((nitems + 255) / 256), dim3(256), 0, st, w1, wa1, wa3, HID, C, wmax);
 }
 template <int C>
 static int launch_pbwd_c(const FnoModelPlan* p, hipStream_t st, int grid, const ProjBwdArgs& a) {
-  if constexpr (C == 64) {
-    if (use_pbwd_q(p, C, a))
-      return GT(2), launch("k_proj_bwd", k_proj_bwd_q<kHID, false>, dim3(grid), dim3(1024),
-                           proj_bwd_q_lds(kHID, a.W, a.NJ, a.x1g != nullptr), st, a);
-  }
   if (a.wa1 && a.amax && use_pbwd_t(C, a.CO, p->NPX))      // two fp16 terms: same LDS carve with two planes per image
     return GT(2), launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false, 2>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
   if (a.wa1 && use_pbwd_t(C, a.CO, p->NPX))
     return GT(3), launch("k_proj_bwd", k_proj_bwd_t<C, kHID, false>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
-  // all-bf16x3 kernel: single output channel, 128-pixel tiles, three bf16 images must fit in LDS
-  if (a.wa1 && a.CO == 1 && p->NPX == 128 && pbwd_x3_lds(C, 128, 1) <= 160 * 1024)
-    return GT(3), launch("k_proj_bwd", k_proj_bwd_x3<C, kHID, 128, 1>, dim3(grid), dim3(512), pbwd_x3_lds(C, 128, 1), st, a);
   return a.CO == 1 ? launch_pbwd_cn<C, 1>(p, st, grid, a) : launch_pbwd_cn<C, PROJ_MAXCO>(p, st, grid, a);
 }
 
@@ -1562,22 +1467,15 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   // save (BASELINE config 1, 128 tiles: 0.27 -> 0.22 ms per step without it)
   const bool h2 = g_gemm_x3 && g_h2 && d.Cout > 0 && L <= FNO_MAX_LAYERS && (size_t)B * g.PW >= ((size_t)1 << 17);
   static_assert(kNAmax == 64, "k_pack_w_tiled clears 64 slots");
-  // cleared by the weight pack's first workgroup (the first launch of the pass), by a fill when that kernel is not the one that runs
-  if (h2 && g_pack_flat && hipMemsetAsync(amax, 0, kNAmax * sizeof(float), st) != hipSuccess) return fail(FNO_EHIP, "memset of the magnitude bounds");
+  // (the bound slots are cleared by the weight pack's first workgroup - the first launch of the pass - or, plane-major weights, by a fill)
   {
     CornerPtrsL cp;
     memset(&cp, 0, sizeof(cp));
     for (int l = 0; l < L; ++l)
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l][c] = (const float2*)prm->spec_w[l][c];
-    const ModeMap mm = make_modemap(g, C, C);
-    const size_t n = (size_t)g.Ktot * C * C;
     // the matrix-core adjoint reads wps; the fused middle's adjoint streams the transposed copy
-    if (!g_pack_flat)
-      LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) && !fused_mid_shape_ok(g, C) ? nullptr : wpts, s.n_wp,
-                              h2 ? amax : nullptr));
-    else
-    LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, st, cp,
-                     (float2*)wps, (float2*)wpts, mm, n));
+    LAUNCHCHK(pack_w_layers(st, g, C, C, cp, L, wps, mode_gemm_members_ok(C, C) && !fused_mid_shape_ok(g, C) ? nullptr : wpts, s.n_wp,
+                            h2 ? amax : nullptr));
   }
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
@@ -1593,9 +1491,8 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
     a.PW = g.PW; a.W = g.W; a.P = g.P; a.K2in = 0; a.K2out = g.Klast; a.NJ = g.NJ;
     a.act_in = 0; a.act_out = 0;
     a.tiles_per_plane = s.tiles_per_plane; a.ntiles = s.ntiles;
-    static const int lift_dft_lin = getenv("FNO_NO_LIFT_ROWDFT") ? 0 : 1;      // A/B switch
     const size_t lds_lr = ((size_t)2 * g.Klast * (g.W + 4) + (size_t)LR_ROWS * d.Cin * (g.W + 4) + 2) * 4 + (size_t)LR_ROWS * g.Klast * (d.Cin + 1) * 8;
-    if (lift_dft_lin && cs.u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
+    if (cs.u0_skipped && !p->loose && lds_lr <= 48 * 1024) {
       // u_0 is never stored: only its row spectra are needed, and those are linear in the <= 4 input channels
       const int nrows = B * g.P;
       LAUNCHCHK(launch("k_lift_rowdft", k_lift_rowdft, dim3((nrows + LR_ROWS - 1) / LR_ROWS), dim3(256), lds_lr, st, x,
@@ -1712,8 +1609,8 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   const float* wps = hats + (size_t)L * s.n_hat;                          // [k][i][o] packed weights from forward
   float* wpts = const_cast<float*>(wps) + (size_t)L * s.n_wp;            // [k][o][i]: only the VALU adjoint needs them
   const bool fused_mid = fused_mid_ok(g, C);           // the forward packed the transposed copy as well
-  const bool adj_mfma = mode_gemm_members_ok(C, C) && !g_pack_flat;
-  if (!adj_mfma && !g_pack_flat && !fused_mid_shape_ok(g, C)) {       // VALU contraction (A/B switch): the forward may have skipped the transposed copy
+  const bool adj_mfma = mode_gemm_members_ok(C, C);
+  if (!adj_mfma && !fused_mid_shape_ok(g, C)) {       // VALU contraction (A/B switch): the forward may have skipped the transposed copy
     CornerPtrsL cpw;
     memset(&cpw, 0, sizeof(cpw));
     for (int l = l_lo; l <= l_hi; ++l)
@@ -1771,25 +1668,22 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     // (one output channel: the same launch leaves 256 partial sums of dy = the bias gradient's partial slabs; k_channel_sums
     // below is then not launched)
     db2_done = d.Cout == 1;
-    // the scan and the split of W1 into its two fp16 terms share a launch (FNO_SPLIT_PROLOGUE=1: the two launches of round 4)
-    static const int split_prologue = getenv("FNO_SPLIT_PROLOGUE") ? 1 : 0;
-    if (!split_prologue) {
+    // the scan and the split of W1 into its two fp16 terms share a launch
+    {
       const int nitems = (kHID / 32) * (C / 16) * 64 + (kHID / 32) * 2 * (C / 32) * 64;
       LAUNCHCHK(launch("k_absmax", k_absmax3_pack_w1, dim3(256 + 8 + 1 + (nitems + 255) / 256), dim3(256), 0, st, dy,
                        (size_t)B * d.Cout * g.PW, 256, prm->proj_w1, 8, prm->proj_w2, (size_t)d.Cout * kHID, 1, bwd_b + 1,
                        db2_done ? w.db2_part : nullptr, w.wa1, w.wa3, kHID, C));
       w1_packed = true;
-    } else
-    LAUNCHCHK(launch("k_absmax", k_absmax3, dim3(256 + 8 + 1), dim3(256), 0, st, dy, (size_t)B * d.Cout * g.PW, 256, prm->proj_w1,
-                     (size_t)kHID * C, 8, prm->proj_w2, (size_t)d.Cout * kHID, bwd_b + 1, db2_done ? w.db2_part : nullptr));
+    }
     pb.amax = bwd_b; pb.xmax = amax + 8 + L;
   }
   if (g_gemm_x3 && g_h2 && cs.h2_fwd && use_pbwd_t(C, d.Cout, p->NPX)) {      // the chain of gradient bounds starts here
     pb.gmax_out = amax + 32 + L;
     gvalid = true;
   }
-  if (g_gemm_x3) {
-    if (!w1_packed) LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, use_pbwd_t(C, d.Cout, p->NPX), h2 ? bwd_b + 2 : nullptr));
+  if (use_pbwd_t(C, d.Cout, p->NPX)) {      // (g_gemm_x3, one output channel: the fragments of k_proj_bwd_t)
+    if (!w1_packed) LAUNCHCHK(pack_w1_x3(st, prm->proj_w1, w.wa1, w.wa3, kHID, C, true, h2 ? bwd_b + 2 : nullptr));
     pb.wa1 = w.wa1; pb.wa3 = w.wa3;
   }
   pb.x = u + (size_t)L * s.n_act; pb.dy = dy; pb.w1 = prm->proj_w1; pb.b1 = prm->proj_b1;
@@ -1802,7 +1696,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
   if (C == 32) LAUNCHCHK(launch_pbwd_c<32>(p, st, s.grid, pb));
   else LAUNCHCHK(launch_pbwd_c<64>(p, st, s.grid, pb));
   jobs.add(w.dw1_part, gr->proj_w1, s.grid, kHID, C, C, C);
-  const int pslabs = use_pbwd_q(p, C, pb) ? 1 : p->NPX / 32;      // db1 / dW2 partial slabs per workgroup
+  const int pslabs = p->NPX / 32;      // db1 / dW2 partial slabs per workgroup
   jobs.add(w.db1_part, gr->proj_b1, s.grid * pslabs, 1, kHID, kHID, kHID);
   jobs.add(w.dw2_part, gr->proj_w2, s.grid * pslabs, d.Cout, kHID, kHID, kHID);
   if (!db2_done) LAUNCHCHK(launch("k_channel_sums", k_channel_sums, dim3(64, d.Cout), dim3(256), 0, st, dy, w.db2_part, B, d.Cout, g.PW));
@@ -1823,16 +1717,9 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     memset(&cp, 0, sizeof(cp));
     for (int l = l_lo; l <= l_hi; ++l)
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[l - l_lo][c] = (float2*)gr->spec_w[l][c];
-    const ModeMap mm = make_modemap(g, C, C);
-    size_t per = (size_t)g.modes[0] * g.wl_stride;
-    if (g.nlead == 2) per *= g.modes[1];
-    const size_t n = (size_t)(1 << g.nlead) * C * C * per;
-    if (!g_pack_flat) return unpack_dw_layers(su, g, C, C, w.dwp + (size_t)l_lo * s.n_wp, cp, l_hi - l_lo + 1, s.n_wp);
-    return launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), l_hi - l_lo + 1), dim3(256),
-                  0, su, (const float2*)(w.dwp + (size_t)l_lo * s.n_wp), cp, mm, (size_t)g.Ktot * C * C);
+    return unpack_dw_layers(su, g, C, C, w.dwp + (size_t)l_lo * s.n_wp, cp, l_hi - l_lo + 1, s.n_wp);
   };
-  static const int no_batch_dw = getenv("FNO_NO_BATCH_DW") ? 1 : 0;       // A/B switch: one weight-gradient contraction per layer
-  const bool batch_dw = !no_batch_dw && l_hi > l_lo && mode_gemm_members_ok(C, C) && g_mode_mfma &&
+  const bool batch_dw = l_hi > l_lo && mode_gemm_members_ok(C, C) && g_mode_mfma &&
                         !(g_mode_gemv && B <= 4 && (long)g.Ktot * C * C >= (1L << 21));
   for (int l = l_hi; l >= l_lo; --l) {
     // spectral backward middle: G = lead_forward(x1) ; dW = conj(Xhat) G ; GX = G conj(W) ; zg = lead_inverse(GX)
@@ -1964,12 +1851,7 @@ extern "C" int fno_fanout_forward(const FnoModelPlan* p, int B, int n_out, const
     memset(&cp, 0, sizeof(cp));
     for (int j = 0; j < n_out; ++j)
       for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (const float2*)prm->spec_w[j][c];
-    const ModeMap mm = make_modemap(g, C, C);
-    const size_t n = (size_t)g.Ktot * C * C;
-    if (!g_pack_flat) LAUNCHCHK(pack_w_layers(st, g, C, C, cp, n_out, wps, mode_gemm_members_ok(C, C) ? nullptr : wpts, s.n_wp));
-    else
-    LAUNCHCHK(launch("k_pack_w_layers", k_pack_w_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st, cp,
-                     (float2*)wps, (float2*)wpts, mm, n));
+    LAUNCHCHK(pack_w_layers(st, g, C, C, cp, n_out, wps, mode_gemm_members_ok(C, C) ? nullptr : wpts, s.n_wp));
   }
   LAUNCHCHK(row_forward(st, g, p->t.tfwd_f, p->t.tT[0], p->t.K2P, B, C, x, w.x1));
   LAUNCHCHK(lead_forward(st, g, p->t, false, B, C, w.x1, w.tmp, hat));        // the shared truncated spectrum of x
@@ -2012,8 +1894,8 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   const float* hat = (const float*)saved;
   const float* wps = hat + s.n_hat;
   float* wpts = const_cast<float*>(wps) + (size_t)n_out * s.n_wp;
-  const bool adj_mfma = mode_gemm_members_ok(C, C) && !g_pack_flat;
-  if (!adj_mfma && !g_pack_flat) {
+  const bool adj_mfma = mode_gemm_members_ok(C, C);
+  if (!adj_mfma) {
     CornerPtrsL cpw;
     memset(&cpw, 0, sizeof(cpw));
     for (int j = 0; j < n_out; ++j)
@@ -2065,13 +1947,7 @@ extern "C" int fno_fanout_backward(const FnoModelPlan* p, int B, int n_out, cons
   memset(&cp, 0, sizeof(cp));
   for (int j = 0; j < n_out; ++j)
     for (int c = 0; c < (1 << g.nlead); ++c) cp.p[j][c] = (float2*)gr->spec_w[j][c];
-  const ModeMap mm = make_modemap(g, C, C);
-  size_t per = (size_t)g.modes[0] * g.wl_stride;
-  if (g.nlead == 2) per *= g.modes[1];
-  const size_t n = (size_t)(1 << g.nlead) * C * C * per;
-  if (!g_pack_flat) return unpack_dw_layers(st, g, C, C, w.dwp, cp, n_out, s.n_wp);
-  return launch("k_unpack_dw_layers", k_unpack_dw_layers, dim3((unsigned)((n + 255) / 256), n_out), dim3(256), 0, st,
-                (const float2*)w.dwp, cp, mm, (size_t)g.Ktot * C * C);
+  return unpack_dw_layers(st, g, C, C, w.dwp, cp, n_out, s.n_wp);
 }
 
 // ===========================================================================
@@ -2343,8 +2219,6 @@ static int chanflow_geo(const FnoChanflowGrid* g, int B, const double* metrics, 
 }
 // slabs are split along y so that the launch carries ~8 waves per SIMD (one slab per workgroup leaves 4)
 static int chanflow_ysplit(int B, int Nx) {
-  static const int forced = getenv("FNO_CF_SPLIT") ? atoi(getenv("FNO_CF_SPLIT")) : 0;
-  if (forced > 0) return forced;
   const long wgs = (long)B * Nx, want = (long)dev_ncu() * 8;
   long s = (want + wgs - 1) / wgs;
   return (int)std::max(1L, std::min(s, 16L));
@@ -2587,10 +2461,8 @@ static int proj_fwd_launch(hipStream_t st, int grid, const ProjFwdArgs& a) {
 }
 template <int C, int HID, bool RELU>
 static int proj_bwd_launch(hipStream_t st, int grid, const ProjBwdArgs& a) {
-  if (use_pbwd_t(C, 1, 128))
-    return GT(3), launch("k_proj_bwd", k_proj_bwd_t<C, HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
-  const size_t lds = ((size_t)3 * 128 * (C + 8) + (size_t)3 * C * 136 + (size_t)3 * 64 * 136) * 2 + ((size_t)128 + HID + HID) * 4;
-  return GT(3), launch("k_proj_bwd", k_proj_bwd_x3<C, HID, 128, 1, RELU>, dim3(grid), dim3(512), lds, st, a);
+  // (the standalone head is split-precision in both GEMM modes: its exact-fp32 form is k_proj_bwd of the model path)
+  return GT(3), launch("k_proj_bwd", k_proj_bwd_t<C, HID, RELU>, dim3(grid), dim3(512), pbwd_t_lds(C, a), st, a);
 }
 // 2..PROJ_MAXCO output channels (PlanePredHead, pinobserver.py:257-273: fc2 -> out_dim * plane_num): the forward kernel with
 // PROJ_MAXCO output rows, the backward on the exact-fp32 first-generation kernel (the split-precision ones are built for one)
@@ -2651,7 +2523,7 @@ extern "C" int fno_projection_backward_act(int B, int C, int hidden, int Cout, s
   ProjWs w = carve_proj(C, hidden, ws, ws_bytes);
   if (!w.ok) return fail(FNO_ENOMEM, "workspace too small: need %zu, have %zu", w.total, ws_bytes);
   hipStream_t st = (hipStream_t)stream;
-  if (Cout == 1) LAUNCHCHK(pack_w1_x3(st, w1, w.wa1, w.wa3, hidden, C, use_pbwd_t(C, 1, 128)));
+  if (Cout == 1) LAUNCHCHK(pack_w1_x3(st, w1, w.wa1, w.wa3, hidden, C, true));
   ProjBwdArgs pb;
   memset(&pb, 0, sizeof(pb));
   pb.x = x; pb.dy = dy; pb.w1 = w1; pb.b1 = b1; pb.w2 = w2; pb.gout = dx;

@@ -278,327 +278,6 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_bloc
 }
 
 // ---------------------------------------------------------------------------
-// Split-precision variant: both GEMMs of the block backward run as bf16x3 MFMAs on the matrix
-// cores (fno_dev.h); the fp32 lanes keep the GELU derivative, the splits and the row DFT.
-// LDS (C = 64, NPX = 128: 152 KB with all tables):
-//   R12  gr[3][C][NPX+8] | ar[3][C][NPX+8]   row-major bf16x3 of g and a_l = act(u_l): dW operands
-//        ... after the dW GEMM the same bytes hold  gb[3][NPX][C+8] (pixel-major g, the dx GEMM's
-//        B operand) | dg tile fp32 C x PITCH (gelu'(u_l) in the accumulator's layout)
-//   R3   fp32 C x PITCH: g as loaded (for dbias and the pixel-major split pass), later the gout tile
-// Per tile:  commit (GELU, row-major splits) | dW GEMM + dbias | split pass + dg | dx GEMM, x gelu',
-// gout store | row DFT / lifting gradients - five barriers, as in the fp32 kernel.
-template <int C, int NPX, bool LOOSE = false, bool LIFT = false>
-__global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, FNO_OCC_BB) k_block_bwd_x3(BlkBwdArgs a) {
-  using Cfg = BlkBwdCfg<C, NPX>;
-  constexpr int NTN = Cfg::NTN, MT = Cfg::MT, NW = Cfg::NW, TILES = Cfg::TILES, KSPLIT = Cfg::KSPLIT;
-  constexpr int NT = NW * 64;
-  constexpr int KB = C / 16;
-  constexpr int PITCH = NPX + 4;
-  constexpr int RP = NPX + 8;                          // halfs per row of the row-major images
-  constexpr int RTERM = C * RP;
-  constexpr int PBH = C + 8, PTERM = NPX * PBH;        // pixel-major image
-  constexpr int DBPX = NPX / (NT / C);
-  static_assert(NT % C == 0 && DBPX % 4 == 0, "dbias thread mapping");
-  constexpr int PXK = NPX / KSPLIT;
-  static_assert(PXK % 16 == 0, "dW k blocks");
-  constexpr int LJ = (C / 16 + NW - 1) / NW;
-  static_assert((size_t)3 * PTERM * 2 + (size_t)C * PITCH * 4 <= (size_t)6 * RTERM * 2, "gb + dg alias the row-major images");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short* gr = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* ar = gr + 3 * RTERM;
-  unsigned short* gb = gr;                                            // after the dW GEMM
-  float* dgs = reinterpret_cast<float*>(gr + 3 * PTERM);             // after the dW GEMM
-  float* r3 = reinterpret_cast<float*>(gr + 6 * RTERM);              // C x PITCH fp32
-  float* xls = r3 + C * PITCH;
-  float* tinv_s = xls + (a.xin ? 8 * PITCH : 0);
-  const int R = LOOSE ? NPX / a.W + 2 : NPX / a.W;
-  const int KC = (LOOSE && a.kch > 0 && a.kch < a.K2in) ? a.kch : a.K2in;     // modes resident in LDS at a time
-  const bool chunked = KC < a.K2in;
-  float* zs = tinv_s + (a.zg ? 2 * KC * a.W : 0);
-  float* tfwd_s = zs + (a.zg ? R * KC * C * 2 : 0);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int l15 = lane & 15, quad = lane >> 4;
-  const int mt = wave / NTN, nt = wave % NTN;
-  const int n0 = nt * 32;
-  const int dtl = wave % TILES, dkp = wave / TILES;     // dW job
-  const int dmt = dtl / MT, dnt = dtl % MT;
-
-  if (a.zg && !chunked)
-    for (int i = tid; i < 2 * a.K2in * a.W; i += NT) tinv_s[i] = a.tinv[i];
-  if (a.x1g)
-    for (int i = tid; i < 16 * a.NJ * a.W; i += NT) tfwd_s[(i / a.W) * (a.W + 4) + i % a.W] = a.tfwd[i];
-  auto zc4 = [&](int px0) {
-    const int nrows = LOOSE ? (px0 + NPX - 1) / a.W - px0 / a.W + 1 : R;
-    return (a.zg && !chunked) ? nrows * a.K2in * C / 2 : 0;
-  };
-
-  // A fragments of W^T: A[i][k = o] = W[o][i], split into (h, m, l)
-  bf16x8 afrag[KB][3];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.w[(kb * 16 + 8 * half + j) * C + mt * 32 + l31];
-    split3x8(v, afrag[kb][0], afrag[kb][1], afrag[kb][2]);
-  }
-
-  f32x16 dwacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) dwacc[r] = 0.0f;
-  float dbsum = 0.0f;
-  f32x4 dl[LJ];
-#pragma unroll
-  for (int j = 0; j < LJ; ++j) dl[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  using PF = TilePrefetch<NPX, NT, C, C>;
-  PF pfg, pfu;
-  float4 xl[4];                  // LIFT: the lifting input under this thread's pixel group
-  __shared__ __attribute__((aligned(16))) float lws[LIFT ? 5 * C : 4];
-  if constexpr (LIFT) { stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT); __syncthreads(); }
-  static_assert(!LIFT || NT % (NPX / 4) == 0, "LIFT: one pixel group per thread");
-  float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto issue = [&](int tile) {
-    const int b = tile / a.tiles_per_plane;
-    const int px0 = (tile % a.tiles_per_plane) * NPX;
-    int t = tid;
-    asm volatile("" : "+v"(t));      // (see k_pw_fwd_x3: no hoisted per-lane 64-bit prefetch addresses)
-    pfg.issue(a.g + (size_t)b * C * a.PW + px0, a.PW, t);
-    if constexpr (LIFT) {     // this thread's 4 pixels of the <= 4 input rows (q = tid % (NPX / 4) for all its items)
-      const float* xb = a.xin + (size_t)b * a.CL * a.PW + px0 + 4 * (t % (NPX / 4));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xl[k] = k < a.CL ? ld4(xb + (size_t)k * a.PW) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      pfu.issue(a.uin + (size_t)b * C * a.PW + px0, a.PW, t);
-    }
-    if (t < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * t);
-  };
-  if ((int)blockIdx.x < a.ntiles) issue(blockIdx.x);
-  auto put_row4 = [&](unsigned short* img, int c, int q, const float4& t) {   // 4 pixels of row c -> 3 terms
-    const float tv[4] = {t.x, t.y, t.z, t.w};
-    unsigned short hh[4], mm[4], ll[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split3(tv[j], hh[j], mm[j], ll[j]);
-    unsigned short* dst = img + c * RP + 4 * q;
-    *reinterpret_cast<uint2*>(dst) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-    *reinterpret_cast<uint2*>(dst + RTERM) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-    *reinterpret_cast<uint2*>(dst + 2 * RTERM) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
-  };
-
-  int tslot = 0;
-  FNO_TRACE_IF(false);
-  FNO_SIMD_PARTNER_PRIO(wave, (C / 32) * (NPX / 32));
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int b = tile / a.tiles_per_plane;
-    const int px0 = (tile % a.tiles_per_plane) * NPX;
-    FNO_STAMP(tslot + 0);
-    // ---- commit: g -> fp32 tile + row-major image; a_l = act(u_l) -> row-major image; gelu' stays in registers
-    float4 dgv[PF::ITER];
-#pragma unroll
-    for (int i = 0; i < PF::ITER; ++i) {
-      const int idx = tid + i * NT;
-      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
-      const float4 gv = pfg.v[i];
-      st4(r3 + c * PITCH + 4 * q, gv);
-      put_row4(gr, c, q, gv);
-      float4 uv;
-      if constexpr (LIFT) {      // u_0 = W_l x + b_l, never stored by the forward pass
-        const float bc = lws[4 * C + c];
-        const float4 wv = ld4(lws + 4 * c);
-        const float wk[4] = {wv.x, wv.y, wv.z, wv.w};
-        uv = make_float4(bc, bc, bc, bc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          uv.x = fmaf(wk[k], xl[k].x, uv.x); uv.y = fmaf(wk[k], xl[k].y, uv.y);
-          uv.z = fmaf(wk[k], xl[k].z, uv.z); uv.w = fmaf(wk[k], xl[k].w, uv.w);
-        }
-      } else {
-        uv = pfu.v[i];
-      }
-      if (a.act_in) {
-        gelu_both(uv.x, uv.x, dgv[i].x);
-        gelu_both(uv.y, uv.y, dgv[i].y);
-        gelu_both(uv.z, uv.z, dgv[i].z);
-        gelu_both(uv.w, uv.w, dgv[i].w);
-      }
-      put_row4(ar, c, q, uv);
-    }
-    const int zcount4 = zc4(px0);
-    if (tid < zcount4) st4(zs + 4 * tid, zv);
-    for (int i = tid + NT; i < zcount4; i += NT)      // more spectral rows than threads (short rows, many modes)
-      st4(zs + 4 * i, ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * i));
-    if (a.xin) stage_rows<NPX, NT>(xls, a.xin + (size_t)b * a.CL * a.PW + px0, a.PW, a.CL, a.CL, false, tid);
-    FNO_STAMP(tslot + 1);
-    __syncthreads();
-    FNO_STAMP(tslot + 2);
-    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
-
-    {  // dbias[c] partial
-      const float* gq = r3 + (tid % C) * PITCH + (tid / C) * DBPX;
-#pragma unroll
-      for (int j = 0; j < DBPX / 4; ++j) {
-        const float4 gv = ld4(gq + 4 * j);
-        dbsum += (gv.x + gv.y) + (gv.z + gv.w);
-      }
-    }
-    FNO_STAMP(tslot + 3);
-    // ---- dW[o][i] += sum_px g[o][px] a[i][px]: both operands row-major, 8 consecutive pixels per lane
-    {
-      const unsigned short* ga = gr + (dmt * 32 + l31) * RP + dkp * PXK + 8 * half;
-      const unsigned short* ab = ar + (dnt * 32 + l31) * RP + dkp * PXK + 8 * half;
-#pragma unroll
-      for (int kq = 0; kq < PXK / 16; ++kq) {
-        bf16x8 af[3], bf[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          af[t] = ld8h(ga + t * RTERM + kq * 16);
-          bf[t] = ld8h(ab + t * RTERM + kq * 16);
-        }
-        dwacc = mfma_x3(af, bf, dwacc);
-      }
-    }
-    FNO_STAMP(tslot + 4);
-    __syncthreads();          // row-major images are dead: their bytes become gb + dg
-    FNO_STAMP(tslot + 5);
-    // ---- pixel-major image of g (B operand of the dx GEMM) from the fp32 tile; gelu' to its tile
-    for (int it = tid; it < NPX * (C / 8); it += NT) {
-      const int px = it % NPX, cg = it / NPX;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = r3[(cg * 8 + j) * PITCH + px];
-      bf16x8 h, m, l;
-      split3x8(v, h, m, l);
-      unsigned short* dst = gb + px * PBH + cg * 8;
-      st8h(dst, h);
-      st8h(dst + PTERM, m);
-      st8h(dst + 2 * PTERM, l);
-    }
-    if (a.act_in) {
-#pragma unroll
-      for (int i = 0; i < PF::ITER; ++i) {
-        const int idx = tid + i * NT;
-        st4(dgs + (idx / (NPX / 4)) * PITCH + 4 * (idx % (NPX / 4)), dgv[i]);
-      }
-    }
-    FNO_STAMP(tslot + 6);
-    __syncthreads();
-    FNO_STAMP(tslot + 7);
-    // ---- dx GEMM (+ row inverse DFT of the spectral gradient) -------------
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    {
-      const unsigned short* gp = gb + (n0 + l31) * PBH + 8 * half;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        bf16x8 bf[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) bf[t] = ld8h(gp + t * PTERM + kb * 16);
-        acc = mfma_x3(afrag[kb], bf, acc);
-      }
-    }
-    if constexpr (LOOSE) {
-      if (a.zg && !chunked) acc = kext_loose_rows<C>(acc, zs, tinv_s, a.K2in, a.W, px0 + n0, px0 / a.W, mt, l31, half);
-      else if (a.zg) {
-        const int r_lo = px0 / a.W, nrows = (px0 + NPX - 1) / a.W - r_lo + 1;
-        for (int k0 = 0; k0 < a.K2in; k0 += KC) {
-          const int kc = min(KC, a.K2in - k0);
-          __syncthreads();                        // every wave is done with the previous chunk (or the previous tile's last)
-          for (int i = tid; i < 2 * kc * a.W; i += NT) tinv_s[i] = a.tinv[2 * k0 * a.W + i];
-          const int per_row4 = kc * C / 2;        // float4s of one row's chunk: modes k0 .. k0 + kc are contiguous in a row
-          for (int i = tid; i < nrows * per_row4; i += NT) {
-            const int r = i / per_row4, rem = i - r * per_row4;
-            st4(zs + 4 * i, ld4(a.zg + (((size_t)b * a.P + r_lo + r) * a.K2in + k0) * C * 2 + 4 * rem));
-          }
-          __syncthreads();
-          acc = kext_loose_rows<C>(acc, zs, tinv_s, kc, a.W, px0 + n0, r_lo, mt, l31, half);
-        }
-      }
-    } else if (a.zg) {
-      const float* zr = zs + (((n0 / a.W) * a.K2in) * C + mt * 32 + l31) * 2 + half;
-      const float* tv = tinv_s + half * a.W + n0 % a.W + l31;
-#pragma unroll 2
-      for (int s = 0; s < a.K2in; ++s) acc = mfma32(zr[s * C * 2], tv[2 * s * a.W], acc);
-    }
-    if (a.gadd) {
-      const float* ap = a.gadd + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += ap[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW];
-    }
-    FNO_STAMP(tslot + 8);
-    {
-      const float* dq = dgs + (mt * 32 + 4 * half) * PITCH + n0 + l31;
-      float* gq = r3 + (mt * 32 + 4 * half) * PITCH + n0 + l31;      // the fp32 g tile is dead since the split pass
-      float* gp = a.gout ? a.gout + ((size_t)b * C + mt * 32 + 4 * half) * a.PW + px0 + n0 + l31 : nullptr;
-      if (a.act_in) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= dq[((r & 3) + 8 * (r >> 2)) * PITCH];
-      }
-      if (gp) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gp[(size_t)((r & 3) + 8 * (r >> 2)) * a.PW] = acc[r];
-      }
-      if (a.x1g || a.xin) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gq[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[r];
-      }
-    }
-    FNO_STAMP(tslot + 9);
-    if (a.x1g || a.xin) {
-      __syncthreads();
-      FNO_STAMP(tslot + 10);
-      if (a.x1g) row_dft_epilogue<C, NPX, NW>(r3, tfwd_s, a.W + 4, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
-      if (a.xin) {
-        // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]
-#pragma unroll
-        for (int j = 0; j < LJ; ++j) {
-          const int jm = wave + j * NW;
-          if (jm < C / 16) {
-            const float* arow = r3 + (jm * 16 + l15) * PITCH + quad;
-            const float* br = xls + (l15 < a.CL ? l15 : 0) * PITCH + quad;
-            const float cst = l15 == a.CL ? 1.0f : 0.0f;
-            for (int s = 0; s < NPX / 4; ++s) {
-              const float bf = (l15 < a.CL) ? br[4 * s] : cst;
-              dl[j] = mfma16(arow[4 * s], bf, dl[j]);
-            }
-          }
-        }
-      }
-    }
-    FNO_STAMP(tslot + 11);
-    __syncthreads();
-    tslot += 12;
-  }
-
-  // ---- write partial slabs ---------------------------------------------------
-  {
-    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPLIT + dkp) * C * C;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dwacc[r];
-  }
-  __syncthreads();
-  smem[tid] = dbsum;                         // [part][c]
-  __syncthreads();
-  if (tid < C) {
-    float v = 0.f;
-    for (int k = 0; k < NT / C; ++k) v += smem[k * C + tid];
-    a.db_part[(size_t)blockIdx.x * C + tid] = v;
-  }
-  if (a.xin) {
-#pragma unroll
-    for (int j = 0; j < LJ; ++j) {
-      const int jm = wave + j * NW;
-      if (jm < C / 16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          a.dwl_part[((size_t)blockIdx.x * C + jm * 16 + quad * 4 + r) * 16 + l15] = dl[j][r];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Gradients of a lifting layer on its own (y = W x + b, x (B, CL <= 4, PW) -> y (B, C, PW); tfno.py:11-20,
 // and the composed `fc0` + Re-conditioning front of the PINO observers, pinobserver.py:205-207):
 //   dW[c][i] = sum_{b,px} dy[c][px] x[i][px],  db[c] = sum dy[c][px]      (no input gradient: x is data)

@@ -380,328 +380,6 @@ __global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd(ProjBwdArgs a)
   }
 }
 
-// Split-precision variant of k_proj_bwd: ALL THREE GEMMs run as bf16x3 MFMAs on the matrix cores
-// (fno_dev.h) with W1 fragments pre-split by k_pack_w1_x3 (L2-resident); the fp32 lanes only do the
-// GELU / reductions / splits.  Wave (hm, nt) as in k_proj_fwd.  LDS holds three bf16x3 images:
-//   xb [3][NPX][C+8]    a, pixel-major   -> B operand of the P1 recompute (contraction over channels)
-//   xr [3][C][NPX+8]    a, row-major     -> B operand of dW1           (contraction over pixels)
-//   dr [3][64][NPX+8]   dP1 chunk, row-major -> A operand of dW1
-// Per 64-row hidden chunk:
-//   A1  recompute P1                                            (24 bf16 MFMAs per wave)
-//   E   gl = gelu(P1), dP1 = gelu'(P1) * (W2^T dy); DPP reductions for dW2 / db1; dP1 is split
-//       once: the three terms go to `dr` AND stay in registers as the B fragments of A3
-//   A3  dx += W1^T dP1 straight from those registers            (24 bf16 MFMAs)
-//   --- barrier ---
-//   B   dW1[chunk] += dP1 . a^T by the wave group that owns the chunk   (48 bf16 MFMAs)
-//   --- barrier --- (dr is single-buffered)
-template <int C, int HID, int NPX, int NCO, bool RELU = false>
-__global__ void __launch_bounds__(NPX * 4, FNO_OCC_PB) k_proj_bwd_x3(ProjBwdArgs a) {
-  using Cfg = ProjBwdCfg<C, HID, NPX>;
-  constexpr int NTN = Cfg::NTN, NW = Cfg::NW, MT = Cfg::MT, NCH = Cfg::NCH, TILES = Cfg::TILES, G = Cfg::G,
-                CPW = Cfg::CPW;
-  constexpr int NT = NW * 64;
-  constexpr int PITCH = NPX + 4;
-  constexpr int KB = C / 16;
-  using SP = SplitTilePrefetch<NPX, NT, C>;      // layout constants of the pixel-major image
-  constexpr int RP = NPX + 8;                    // halfs per row of the row-major images
-  constexpr int XR_TERM = C * RP, DR_TERM = 64 * RP;
-  static_assert((size_t)C * PITCH * 4 <= (size_t)3 * DR_TERM * 2 && (size_t)C * PITCH * 4 <= (size_t)3 * XR_TERM * 2,
-                "fp32 tiles alias the bf16 images");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short* xb = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* xr = xb + 3 * SP::TERM;
-  unsigned short* dr = xr + 3 * XR_TERM;
-  float* douts = reinterpret_cast<float*>(dr + 3 * DR_TERM);   // NCO x NPX
-  float* b1s = douts + NCO * NPX;                               // HID
-  float* w2s = b1s + HID;                                       // NCO x HID
-  float* tmpf = reinterpret_cast<float*>(dr);    // C x PITCH fp32: staging tile for the split pass, later the gout tile
-  float* part = reinterpret_cast<float*>(xr);    // C x PITCH fp32: dx partials of the hm = 1 waves (after the chunk loop)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int l15 = lane & 15;
-  const int hm = wave / NTN, nt = wave % NTN;
-  const int n0 = nt * 32;
-  const int dgrp = wave / TILES, dtl = wave % TILES;
-  const int dmt = dtl / MT, dnt = dtl % MT;  // dW1 tile: hidden 32-block, channel 32-block
-
-  for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
-  for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
-  f32x16 dw1acc[CPW];
-#pragma unroll
-  for (int k = 0; k < CPW; ++k)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dw1acc[k][r] = 0.f;
-  // lane accumulates hidden row  ch*64 + hm*32 + acc_row32(reduce16_id(lane), half)  of every chunk
-  float sdb1[NCH], sdw2[NCH][NCO];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    sdb1[ch] = 0.f;
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) sdw2[ch][co] = 0.f;
-  }
-
-  bf16x8 afn[KB][3];     // A fragments (W1 rows of this wave) of the chunk about to be recomputed
-  auto load_w1 = [&](int ch) {
-    const unsigned short* wa = a.wa1 + ((size_t)((ch * 2 + hm) * KB * 3) * 64 + lane) * 8;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) afn[kb][t] = ld8h(wa + (size_t)(kb * 3 + t) * 64 * 8);
-  };
-  using PFX = TilePrefetch<NPX, NT, C, C>;
-  PFX pfx;      // next tile's u_L rows, in flight during this tile
-  if ((int)blockIdx.x < a.ntiles)
-    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
-
-  int tslot = 0;
-  FNO_TRACE_IF(FNO_TRACE_WHICH == 1);
-  FNO_SIMD_PARTNER_PRIO(wave, NW);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int b = tile / a.tiles_per_plane;
-    const int px0 = (tile % a.tiles_per_plane) * NPX;
-    FNO_STAMP(tslot + 0);
-    // commit: a = act(u) -> fp32 staging tile + row-major bf16x3 image
-#pragma unroll
-    for (int i = 0; i < PFX::ITER; ++i) {
-      const int idx = tid + i * NT;
-      const int c = idx / (NPX / 4), q = idx % (NPX / 4);
-      float4 t = pfx.v[i];
-      if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
-      st4(tmpf + c * PITCH + 4 * q, t);
-      const float tv[4] = {t.x, t.y, t.z, t.w};
-      unsigned short hh[4], mm[4], ll[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) split3(tv[j], hh[j], mm[j], ll[j]);
-      unsigned short* dst = xr + c * RP + 4 * q;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16));
-      *reinterpret_cast<uint2*>(dst + XR_TERM) = make_uint2(mm[0] | ((unsigned)mm[1] << 16), mm[2] | ((unsigned)mm[3] << 16));
-      *reinterpret_cast<uint2*>(dst + 2 * XR_TERM) = make_uint2(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16));
-    }
-    for (int idx = tid; idx < NCO * NPX; idx += NT) {
-      const int co = idx / NPX, p = idx % NPX;
-      douts[idx] = (co < a.CO) ? a.dy[((size_t)b * a.CO + co) * a.PW + px0 + p] : 0.f;
-    }
-    FNO_STAMP(tslot + 1);
-    __syncthreads();
-    FNO_STAMP(tslot + 2);
-    {
-      const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles) {
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));      // (no hoisted per-lane 64-bit prefetch addresses: k_pw_fwd_x3)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, t_);
-      }
-    }
-    // split pass: fp32 tile [c][px] -> pixel-major bf16x3 image (A1's B operand)
-    for (int it = tid; it < NPX * (C / 8); it += NT) {
-      const int px = it % NPX, cg = it / NPX;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = tmpf[(cg * 8 + j) * PITCH + px];
-      bf16x8 h, m, l;
-      split3x8(v, h, m, l);
-      unsigned short* dst = xb + px * SP::PBH + cg * 8;
-      st8h(dst, h);
-      st8h(dst + SP::TERM, m);
-      st8h(dst + 2 * SP::TERM, l);
-    }
-    FNO_STAMP(tslot + 3);
-    __syncthreads();            // tmpf (= dr) is free from here on
-    FNO_STAMP(tslot + 4);
-    const unsigned short* xbp = xb + (n0 + l31) * SP::PBH + 8 * half;   // this lane's pixel row
-    float dyl[NCO];
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) dyl[co] = douts[co * NPX + n0 + l31];
-
-    f32x16 acc2[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
-    if (tile == (int)blockIdx.x) load_w1(0);     // later tiles: chunk 0 was prefetched by the previous tile's last chunk
-
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (ch == 1) FNO_STAMP(tslot + 5);
-      // ---- A1 ------------------------------------------------------------
-      f32x16 acc, lo1;     // hh products / cross terms of the split (fno_dev.h: mfma_x3s)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo1[r] = 0.f; }
-      {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          bf16x8 bf[3];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) bf[t] = ld8h(xbp + t * SP::TERM + kb * 16);
-          mfma_x3s(afn[kb], bf, acc, lo1);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += lo1[r];
-      }
-      if (ch == 1) FNO_STAMP(tslot + 6);
-      // ---- E ---------------------------------------------------------------
-      bf16x8 bd[2][3];      // dP1 split: accumulator registers 8s..8s+7 = B fragment of hidden k-block s
-      {
-        unsigned short* drp = dr + (hm * 32 + 4 * half) * RP + n0 + l31;
-        const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
-        const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
-        float dpv[16], glv[NCO][16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = (r & 3) + 8 * (r >> 2);
-          float t = 0.f;
-#pragma unroll
-          for (int co = 0; co < NCO; ++co) t = fmaf(w2p[co * HID + ro], dyl[co], t);
-          float gl, dg;
-          if constexpr (RELU) {          // hidden ReLU (rno.py:136-137 regressor head): relu'(0) = 0 as torch
-            const float p1 = acc[r] + b1p[ro];
-            gl = fmaxf(p1, 0.f);
-            dg = p1 > 0.f ? 1.f : 0.f;
-          } else {
-            gelu_both(acc[r] + b1p[ro], gl, dg);
-          }
-          const float dp = dg * t;
-          unsigned short ph, pm, pl;
-          split3(dp, ph, pm, pl);
-          bd[r >> 3][0][r & 7] = (short)ph;
-          bd[r >> 3][1][r & 7] = (short)pm;
-          bd[r >> 3][2][r & 7] = (short)pl;
-          drp[ro * RP] = ph;
-          drp[ro * RP + DR_TERM] = pm;
-          drp[ro * RP + 2 * DR_TERM] = pl;
-          dpv[r] = dp;
-#pragma unroll
-          for (int co = 0; co < NCO; ++co) glv[co][r] = gl * dyl[co];
-        }
-        // pixel sums of this wave's 32 columns: lane -> accumulator register reduce16_id(lane)
-        const float rdb = half_reduce16(dpv, lane);
-        float rdw[NCO];
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) rdw[co] = half_reduce16(glv[co], lane);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-          if (k == ch) {
-            sdb1[k] += rdb;
-#pragma unroll
-            for (int co = 0; co < NCO; ++co) sdw2[k][co] += rdw[co];
-          }
-      }
-      if (ch == 1) FNO_STAMP(tslot + 7);
-      // ---- A3: W1^T fragments come in the accumulator's k order (k_pack_w1_x3) ------------
-      {
-        const unsigned short* wa = a.wa3 + ((size_t)((ch * 2 + hm) * 2 * MT * 3) * 64 + lane) * 8;
-#pragma unroll
-        for (int mc = 0; mc < MT; ++mc) {
-          f32x16 lo3;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) lo3[r] = 0.f;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            bf16x8 af[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) af[t] = ld8h(wa + (size_t)((s * MT + mc) * 3 + t) * 64 * 8);
-            mfma_x3s(af, bd[s], acc2[mc], lo3);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc2[mc][r] += lo3[r];
-        }
-      }
-      // W1 fragments of the NEXT chunk: L2 latency hides behind the barrier and the dW1 phase
-      load_w1(ch + 1 < NCH ? ch + 1 : 0);
-      if (ch == 1) FNO_STAMP(tslot + 8);
-      __syncthreads();
-      if (ch == 1) FNO_STAMP(tslot + 9);
-      // ---- B: dW1[hid][c] += sum_px dP1[hid][px] a[c][px], both operands row-major bf16x3 -----
-      if (dgrp == ch % G) {
-        const unsigned short* ga = dr + (dmt * 32 + l31) * RP + 8 * half;
-        const unsigned short* ab = xr + (dnt * 32 + l31) * RP + 8 * half;
-#pragma unroll
-        for (int k = 0; k < CPW; ++k)
-          if (k == ch / G) {
-            f32x16 dacc = dw1acc[k];
-#pragma unroll 2
-            for (int kq = 0; kq < NPX / 16; ++kq) {
-              bf16x8 af[3], bf[3];
-#pragma unroll
-              for (int t = 0; t < 3; ++t) {
-                af[t] = ld8h(ga + t * DR_TERM + kq * 16);
-                bf[t] = ld8h(ab + t * XR_TERM + kq * 16);
-              }
-              dacc = mfma_x3(af, bf, dacc);
-            }
-            dw1acc[k] = dacc;
-          }
-      }
-      if (ch == 1) FNO_STAMP(tslot + 10);
-      __syncthreads();   // dr is rewritten by the next chunk
-      if (ch == 1) FNO_STAMP(tslot + 11);
-    }
-
-    FNO_STAMP(tslot + 12);
-    // ---- dx: add the two hidden halves, (x act'), store, row DFT -------------
-    // C = 64: wave (hm, nt) finalises channel block m = hm of its 32 pixels and hands the other block to its
-    // partner; C = 32: the hm = 0 wave finalises the single block
-    {
-      float* pp = part + (4 * half) * PITCH + n0 + l31;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if (!((MT == 2) ? (m == hm) : (hm == 0))) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) pp[(m * 32 + (r & 3) + 8 * (r >> 2)) * PITCH] = acc2[m][r];
-        }
-    }
-    __syncthreads();
-    {
-      const float* pp = part + (4 * half) * PITCH + n0 + l31;
-      float* xp = tmpf + (4 * half) * PITCH + n0 + l31;
-      const size_t goff = ((size_t)b * C + 4 * half) * a.PW + px0 + n0 + l31;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        if ((MT == 2) ? (m == hm) : (hm == 0)) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-            float v = acc2[m][r] + pp[ro * PITCH];
-            if (a.act_in) v *= gelu_grad_f(a.x[goff + (size_t)ro * a.PW]);
-            a.gout[goff + (size_t)ro * a.PW] = v;
-            if (a.x1g) xp[ro * PITCH] = v;
-          }
-        }
-    }
-    FNO_STAMP(tslot + 13);
-    if (a.x1g) {
-      __syncthreads();
-      FNO_STAMP(tslot + 14);
-      row_dft_epilogue<C, NPX, NW>(tmpf, a.tfwd, a.W, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
-    }
-    FNO_STAMP(tslot + 15);
-    __syncthreads();
-    tslot += 16;
-  }
-
-  // ---- partial slabs -------------------------------------------------------
-#pragma unroll
-  for (int k = 0; k < CPW; ++k) {
-    const int ch = dgrp + k * G;
-    if (dgrp >= G) break;
-    float* dst = a.dw1_part + (size_t)blockIdx.x * HID * C;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      dst[(size_t)(ch * 64 + dmt * 32 + acc_row32(r, half)) * C + dnt * 32 + l31] = dw1acc[k][r];
-  }
-  if ((lane & 16) == 0) {      // lanes 16-31 / 48-63 hold duplicates
-    const size_t slab = (size_t)blockIdx.x * NTN + nt;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int hid = ch * 64 + hm * 32 + acc_row32(reduce16_id(lane), half);
-      a.db1_part[slab * HID + hid] = sdb1[ch];
-#pragma unroll
-      for (int co = 0; co < NCO; ++co)
-        if (co < a.CO) a.dw2_part[(slab * a.CO + co) * HID + hid] = sdw2[ch][co];
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Split-precision (bf16x3 on the matrix cores, see fno_dev.h) variant of k_proj_fwd.
 // W1 is split once per workgroup into MFMA A-fragment order and stays in LDS:
@@ -825,34 +503,5 @@ __global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_x3(ProjFwdArgs a) {
           a.y[((size_t)b * a.CO + co) * a.PW + px0 + n0 + l31] = ysum[co] + ysh[co * NPX + n0 + l31] + a.b2[co];
     }
     __syncthreads();
-  }
-}
-
-// W1 (HID, C) fp32 -> bf16x3 MFMA A-fragments for k_proj_bwd_x3 (once per step, 2 x 96 KB at C = 64):
-//   wa1[((mt*KB + kb)*3 + t)*64 + lane][j] = term t of W1[mt*32 + (lane&31)][kb*16 + 8*(lane>>5) + j]
-//   wa3[(((mt*2 + s)*MT + mc)*3 + t)*64 + lane][j] = term t of W1[mt*32 + 16s + 8(j>>2) + 4(lane>>5) + (j&3)][mc*32 + (lane&31)]
-__global__ void k_pack_w1_x3(const float* __restrict__ w1, unsigned short* __restrict__ wa1,
-                             unsigned short* __restrict__ wa3, int HID, int C) {
-  const int KB = C / 16, MT = C / 32;
-  const int n1 = (HID / 32) * KB * 64, n3 = (HID / 32) * 2 * MT * 64;
-  const int it = blockIdx.x * blockDim.x + threadIdx.x;
-  float v[8];
-  bf16x8 h, m, l;
-  if (it < n1) {
-    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
-    split3x8(v, h, m, l);
-    unsigned short* dst = wa1 + ((size_t)((mt * KB + kb) * 3) * 64 + ln) * 8;
-    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
-  } else if (it < n1 + n3) {
-    const int i3 = it - n1;
-    const int ln = i3 & 63, mc = (i3 >> 6) % MT, s = ((i3 >> 6) / MT) & 1, mt = (i3 >> 6) / MT / 2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      v[j] = w1[(size_t)(mt * 32 + 16 * s + 8 * (j >> 2) + 4 * (ln >> 5) + (j & 3)) * C + mc * 32 + (ln & 31)];
-    split3x8(v, h, m, l);
-    unsigned short* dst = wa3 + ((size_t)(((mt * 2 + s) * MT + mc) * 3) * 64 + ln) * 8;
-    st8h(dst, h); st8h(dst + 64 * 8, m); st8h(dst + 2 * 64 * 8, l);
   }
 }

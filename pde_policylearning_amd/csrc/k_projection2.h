@@ -97,11 +97,7 @@ FNO_DEV void absmax3_block(const float* __restrict__ x0, size_t n0, int g0, cons
     absmax_publish(r, dst + job);
   }
 }
-__global__ void k_absmax3(const float* __restrict__ x0, size_t n0, int g0, const float* __restrict__ x1, size_t n1, int g1,
-                          const float* __restrict__ x2, size_t n2, float* __restrict__ dst, float* __restrict__ sum0) {
-  absmax3_block(x0, n0, g0, x1, n1, g1, x2, n2, (int)gridDim.x - g0 - g1, dst, sum0);
-}
-// k_absmax3 and k_pack_w1_t<2> in ONE launch (round 5: two ~5 us launches at the head of every backward pass): blocks
+// the scan (max |dy|, max |W1|, max |w2|, partial sums of dy) and k_pack_w1_t<2> in ONE launch (round 5: two ~5 us launches at the head of every backward pass): blocks
 // [0, g0 + g1 + g2) are k_absmax3's, the rest split x1 = W1 (HID x C) into its two fp16 terms.  The split needs max |W1|, which
 // the scan blocks of the same launch are still producing: every split block takes the maximum over W1 itself (64 KB out of
 // L2, 16 loads per thread) - the same float the scan publishes in dst[1], so the kernels that read the bound see the scale

@@ -60,150 +60,6 @@ FNO_DEV float wg_absmax(const float* __restrict__ w, int n, float* scratch, int 
   return r;
 }
 
-// k_proj_fwd_x3 with two fp16 terms.  a.xmax: device scalar, a bound of |x| (required)
-template <int C, int HID, int NPX, int NCO, bool RELU = false>
-__global__ void __launch_bounds__(NPX * 4, 2) k_proj_fwd_h2(ProjFwdArgs a) {
-  FNO_CLK_ENTRY();
-  constexpr int NTN = NPX / 32;
-  constexpr int NW = 2 * NTN;
-  constexpr int NT = NW * 64;
-  constexpr int KB = C / 16;
-  constexpr int NCH = HID / 64;
-  using PF = SplitTilePrefetchH2<NPX, NT, C>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short* xb = reinterpret_cast<unsigned short*>(smem);          // 2 x NPX x (C+8) halfs
-  unsigned short* w1b = xb + 2 * PF::TERM;                                // (HID/32) x KB x 2 x 64 x 8 halfs
-  float* b1s = reinterpret_cast<float*>(w1b + (HID / 32) * KB * 2 * 64 * 8);   // HID
-  float* w2s = b1s + HID;                                                 // NCO x HID
-  float* ysh = w2s + NCO * HID;                                           // NCO x NPX (first floats: reduction scratch)
-  float gk_six, gk_inf;
-  gelu_consts(gk_six, gk_inf);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int hm = wave / NTN, nt = wave % NTN;
-  const int n0 = nt * 32;
-
-  const float sx = h2_scale(*a.xmax);                                     // activation scale (|gelu(x)| <= |x|)
-  const float sw = h2_scale(wg_absmax<NT>(a.w1, HID * C, ysh, tid));      // weight scale
-  const float inv = 1.0f / (sx * sw);                                     // exact: powers of two
-  for (int i = tid; i < HID; i += NT) b1s[i] = a.b1[i];
-  for (int i = tid; i < NCO * HID; i += NT) w2s[i] = (i < a.CO * HID) ? a.w2[i] : 0.f;
-  for (int it = tid; it < (HID / 32) * KB * 64; it += NT) {      // item = (mt, kb, lane)
-    const int ln = it & 63, kb = (it >> 6) % KB, mt = (it >> 6) / KB;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = a.w1[(size_t)(mt * 32 + (ln & 31)) * C + kb * 16 + 8 * (ln >> 5) + j];
-    f16x8 h, l;
-    split2x8(v, sw, h, l);
-    unsigned short* dst = w1b + ((size_t)((mt * KB + kb) * 2) * 64 + ln) * 8;
-    *reinterpret_cast<f16x8*>(dst) = h;
-    *reinterpret_cast<f16x8*>(dst + 64 * 8) = l;
-  }
-
-  PF pfx;
-  if ((int)blockIdx.x < a.ntiles)
-    pfx.issue(a.x + (size_t)(blockIdx.x / a.tiles_per_plane) * C * a.PW + (blockIdx.x % a.tiles_per_plane) * NPX, a.PW, tid);
-
-  FNO_CLK_BEGIN();
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const int b = tile / a.tiles_per_plane;
-    const int px0 = (tile % a.tiles_per_plane) * NPX;
-    pfx.commit(xb, a.act_in != 0, sx, gk_six, gk_inf, tid);
-    __syncthreads();
-    {
-      const int nt2 = tile + gridDim.x;
-      if (nt2 < a.ntiles)
-        pfx.issue(a.x + (size_t)(nt2 / a.tiles_per_plane) * C * a.PW + (nt2 % a.tiles_per_plane) * NPX, a.PW, tid);
-    }
-    // this wave's activation fragments: B[k = c][n = px], 8 consecutive channels per lane
-    f16x8 bfrag[KB][2];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        bfrag[kb][t] = *reinterpret_cast<const f16x8*>(xb + t * PF::TERM + (n0 + l31) * PF::PBH + kb * 16 + 8 * half);
-
-    float ysum[NCO];
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) ysum[co] = 0.f;
-    // One-chunk software pipeline (round 4 experiment, -DPFWD_PIPE=1): the products of chunk ch + 1 ISSUED before the GELU of
-    // chunk ch, so that a wave's matrix work runs under its own vector work.  Measured 0.194-0.199 vs 0.200-0.212 ms per
-    // launch at config 2 (within the noise of the boxes) for 208 instead of 168 VGPRs, and the four-output variant spills with
-    // it: off.  (One output channel takes k_proj_fwd_w below by default.)
-#ifndef PFWD_PIPE
-#define PFWD_PIPE 0
-#endif
-    auto products = [&](int ch, f32x16& acc, f32x16& lo) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[r] = 0.f; lo[r] = 0.f; }
-      const unsigned short* wa = w1b + ((size_t)((ch * 2 + hm) * KB * 2) * 64 + lane) * 8;
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        f16x8 af[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const f16x8*>(wa + (size_t)(kb * 2 + t) * 64 * 8);
-        mfma_h2s(af, bfrag[kb], acc, lo);
-      }
-    };
-    auto activate = [&](int ch, const f32x16& acc, const f32x16& lo) {
-      const float* b1p = b1s + ch * 64 + hm * 32 + 4 * half;
-      const float* w2p = w2s + ch * 64 + hm * 32 + 4 * half;
-      f32x2 hp[8];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        hp[r >> 1][0] = fmaf(acc[r] + lo[r], inv, b1p[(r & 3) + 8 * (r >> 2)]);
-        hp[r >> 1][1] = fmaf(acc[r + 1] + lo[r + 1], inv, b1p[((r + 1) & 3) + 8 * ((r + 1) >> 2)]);
-      }
-      if constexpr (RELU) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { hp[k][0] = fmaxf(hp[k][0], 0.f); hp[k][1] = fmaxf(hp[k][1], 0.f); }
-      } else gelu_pairs<8>(hp, gk_six, gk_inf);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = (r & 3) + 8 * (r >> 2);
-        const float gl = hp[r >> 1][r & 1];
-#pragma unroll
-        for (int co = 0; co < NCO; ++co) ysum[co] = fmaf(w2p[co * HID + ro], gl, ysum[co]);
-      }
-    };
-#if PFWD_PIPE
-    static_assert(NCH % 2 == 0, "two accumulator sets alternate");
-    f32x16 accA, loA, accB, loB;
-    products(0, accA, loA);
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch += 2) {
-      products(ch + 1, accB, loB);
-      __builtin_amdgcn_sched_barrier(0);        // (the products above stay ahead of the vector work below)
-      activate(ch, accA, loA);
-      if (ch + 2 < NCH) products(ch + 2, accA, loA);
-      __builtin_amdgcn_sched_barrier(0);
-      activate(ch + 1, accB, loB);
-    }
-#else
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      f32x16 acc, lo;      // hh products / cross terms
-      products(ch, acc, lo);
-      activate(ch, acc, lo);
-    }
-#endif
-#pragma unroll
-    for (int co = 0; co < NCO; ++co) {
-      ysum[co] += __shfl_xor(ysum[co], 32, 64);
-      if (hm == 1 && half == 0) ysh[co * NPX + n0 + l31] = ysum[co];
-    }
-    __syncthreads();
-    if (hm == 0 && half == 0) {
-#pragma unroll
-      for (int co = 0; co < NCO; ++co)
-        if (co < a.CO)
-          a.y[((size_t)b * a.CO + co) * a.PW + px0 + n0 + l31] = ysum[co] + ysh[co * NPX + n0 + l31] + a.b2[co];
-    }
-    __syncthreads();
-  }
-  FNO_CLK_END(2);
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Projection forward, third generation ("w": independent waves; round 4).  tools/occupancy_valu_test.hip measured what bounds

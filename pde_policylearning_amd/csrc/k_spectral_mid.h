@@ -167,98 +167,6 @@ __device__ __forceinline__ void mode_decompose(const ModeMap& mm, int k, int& co
   }
 }
 
-// Wp[k][i][o] and Wpt[k][o][i] from corner tensors (Cin, Cout, m1, [m2], wl_stride)
-__global__ void k_pack_w(CornerPtrs cw, float2* __restrict__ wp, float2* __restrict__ wpt, ModeMap mm) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t n = (size_t)mm.Ktot * mm.Cin * mm.Cout;
-  if (e >= n) return;
-  const int o = e % mm.Cout;
-  const int i = (e / mm.Cout) % mm.Cin;
-  const int k = e / ((size_t)mm.Cout * mm.Cin);
-  int corner; size_t loc;
-  mode_decompose(mm, k, corner, loc);
-  size_t per = (size_t)mm.m[0] * mm.wl_stride;
-  if (mm.nlead == 2) per *= mm.m[1];
-  const float2 v = cw.p[corner][((size_t)i * mm.Cout + o) * per + loc];
-  wp[e] = v;
-  wpt[((size_t)k * mm.Cout + o) * mm.Cin + i] = v;
-}
-
-// corner-layout gradients from mode-major dWp[k][i][o]; entries of the stored
-// weight outside the kept last-dim range get zero gradient.
-//   block (bx, 256 / bx): x runs along one (corner, i, o) row of per_c contiguous float2 (coalesced stores, 32-bit index
-//   arithmetic), y picks the row;  grid (ceil(rows / by), ceil(per_c / bx))
-__global__ void __launch_bounds__(256) k_unpack_dw(const float2* __restrict__ dwp, CornerPtrsMut gw, ModeMap mm, int per_c) {
-  const int row = blockIdx.x * blockDim.y + threadIdx.y;          // (corner * Cin + i) * Cout + o
-  const int loc = blockIdx.y * blockDim.x + threadIdx.x;
-  const int nrow = (1 << mm.nlead) * mm.Cin * mm.Cout;
-  if (row >= nrow || loc >= per_c) return;
-  const int io = row % (mm.Cin * mm.Cout), corner = row / (mm.Cin * mm.Cout);
-  const int rest = loc / mm.wl_stride, kl = loc - rest * mm.wl_stride;
-  float2 v = make_float2(0.f, 0.f);
-  if (kl < mm.K[mm.nlead]) {
-    int k;
-    if (mm.nlead == 2) {
-      const int l1 = rest / mm.m[1], l2 = rest - l1 * mm.m[1];
-      const int k1 = l1 + (corner >> 1) * mm.m[0], k2 = l2 + (corner & 1) * mm.m[1];
-      k = (k1 * mm.K[1] + k2) * mm.K[2] + kl;
-    } else {
-      k = (rest + corner * mm.m[0]) * mm.K[1] + kl;
-    }
-    v = dwp[(size_t)k * mm.Cin * mm.Cout + io];
-  }
-  gw.p[corner][(size_t)io * per_c + loc] = v;
-}
-
-// all layers in one launch (blockIdx.y = layer); per-layer outputs are `stride` float2 apart
-__global__ void k_pack_w_layers(CornerPtrsL cw, float2* __restrict__ wp, float2* __restrict__ wpt, ModeMap mm,
-                                size_t stride) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t n = (size_t)mm.Ktot * mm.Cin * mm.Cout;
-  if (e >= n) return;
-  const int l = blockIdx.y;
-  const int o = e % mm.Cout;
-  const int i = (e / mm.Cout) % mm.Cin;
-  const int k = e / ((size_t)mm.Cout * mm.Cin);
-  int corner; size_t loc;
-  mode_decompose(mm, k, corner, loc);
-  size_t per = (size_t)mm.m[0] * mm.wl_stride;
-  if (mm.nlead == 2) per *= mm.m[1];
-  const float2 v = cw.p[l][corner][((size_t)i * mm.Cout + o) * per + loc];
-  wp[l * stride + e] = v;
-  wpt[l * stride + ((size_t)k * mm.Cout + o) * mm.Cin + i] = v;
-}
-
-__global__ void k_unpack_dw_layers(const float2* __restrict__ dwp, CornerPtrsMutL gw, ModeMap mm, size_t stride) {
-  size_t per_c = (size_t)mm.m[0] * mm.wl_stride;
-  if (mm.nlead == 2) per_c *= mm.m[1];
-  const int ncorner = 1 << mm.nlead;
-  const size_t n = (size_t)ncorner * mm.Cin * mm.Cout * per_c;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int l = blockIdx.y;
-  const size_t loc = e % per_c;
-  const int o = (e / per_c) % mm.Cout;
-  const int i = (e / (per_c * mm.Cout)) % mm.Cin;
-  const int corner = e / (per_c * mm.Cout * mm.Cin);
-  const int kl = loc % mm.wl_stride;
-  float2 v = make_float2(0.f, 0.f);
-  if (kl < mm.K[mm.nlead]) {
-    int k;
-    if (mm.nlead == 2) {
-      const int l2 = (loc / mm.wl_stride) % mm.m[1];
-      const int l1 = loc / ((size_t)mm.wl_stride * mm.m[1]);
-      const int k1 = l1 + (corner >> 1) * mm.m[0], k2 = l2 + (corner & 1) * mm.m[1];
-      k = (k1 * mm.K[1] + k2) * mm.K[2] + kl;
-    } else {
-      const int l1 = loc / mm.wl_stride;
-      k = (l1 + corner * mm.m[0]) * mm.K[1] + kl;
-    }
-    v = dwp[l * stride + ((size_t)k * mm.Cin + i) * mm.Cout + o];
-  }
-  gw.p[l][corner][((size_t)i * mm.Cout + o) * per_c + loc] = v;
-}
-
 // LDS-tiled forms of the two layout changes.  The corner tensors are (i, o)-major with the kept modes innermost, the
 // packed arrays mode-major with (i, o) innermost: a thread-per-element copy is coalesced on one side only and moves 8 bytes
 // per 64-byte sector on the other (the PINO observers carry 0.2 - 1 GB of spectral weights per layer).  A workgroup owns

@@ -325,16 +325,3 @@ def test_corner_weight_of_the_wrong_extent_is_an_error_not_a_fault(dev):
     assert torch.isfinite(F.fno_blocks(x, skip, good, bias, modes, "ortho")).all()
     with pytest.raises(RuntimeError, match="spectral weight"):
         F.fno_blocks(x, skip, small, bias, modes, "ortho")
-
-
-def test_opt_in_projection_backward_arm_matches_default():
-    """k_proj_bwd_q (csrc/k_projection3.h: 16 waves, four per SIMD; FNO_PBWD_Q=1) is an A/B arm that the default never runs: every
-    gradient of a config-2-shaped step from a process with the switch against one without (tools/pbq_check.py; the switch is read
-    once per process)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pbq_check.py"), "8"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "k_proj_bwd per launch" in r.stdout

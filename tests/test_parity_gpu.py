@@ -250,7 +250,8 @@ def _oracle_fno_fp64(p, x, tgt, modes, L):
                                            (32, 128, (16, 16), 1, 3), (64, 256, (12, 12), 1, 1),
                                            (64, 32, (16, 16), 2, 2),      # 4 rows per tile x 8 modes: more Z rows than threads
                                            (64, 96, (12, 12), 2, 4), (32, 160, (16, 12), 1, 3),     # "loose rows": 96 and 160 do not tile
-                                           (64, 48, (8, 8), 2, 2)])                                 # the 128 / 256-pixel tiles
+                                           (64, 48, (8, 8), 2, 2),                                  # the 128 / 256-pixel tiles
+                                           (32, 256, (8, 8), 1, 2)])                                # 256-pixel tiles at 32 channels
 def test_fno2d_vs_oracle(dev, C, S, modes, B, L, gemm_mode):
     if gemm_mode == "f32" and 128 % S != 0 and S % 128 != 0:
         pytest.skip("loose rows run on the split-precision GEMM kernels only (fno_model_plan_create rejects them in f32 mode)")
@@ -724,7 +725,9 @@ def test_fno2d_observer_train_trajectory_fused_tail(dev):
         assert abs(float(loss) - float(g["losses"][step])) < 5e-5 * abs(float(g["losses"][step])), step
 
 
-@pytest.mark.parametrize("shape,modes,cout", [((70, 64, 32, 32), (6, 5), 64), ((3, 32, 16, 32), (4, 4), 32), ((33, 64, 8, 8, 16), (2, 3, 4), 64)])
+@pytest.mark.parametrize("shape,modes,cout", [((70, 64, 32, 32), (6, 5), 64), ((3, 32, 16, 32), (4, 4), 32), ((33, 64, 8, 8, 16), (2, 3, 4), 64),
+                                              ((40, 32, 16, 32), (4, 4), 32),              # more than 32 samples at 32 channels
+                                              ((3, 64, 32, 32, 32), (8, 8, 8), 64)])      # three samples, 2^21 weights per block: the streaming kernels
 def test_mode_contraction_matrix_cores_equal_valu_kernels(dev, shape, modes, cout):
     """'bixy,ioxy->boxy' as one real GEMM per mode on the fp32 matrix cores (k_mode_gemm_mfma / k_mode_gemm_dw_mfma: the
     default for 32 / 64 channels, so every other parity test runs it) vs the VALU kernels it replaces (fno_set_mode_gemm(0)):
@@ -777,7 +780,7 @@ def test_mode_contraction_matrix_cores_equal_valu_kernels(dev, shape, modes, cou
 
 
 @pytest.mark.parametrize("shape,modes", [((5, 64, 32, 64), (6, 6)), ((3, 32, 64, 32), (4, 8)), ((2, 64, 128, 128), (8, 5)),
-                                         ((4, 64, 32, 32), (2, 2))])
+                                         ((4, 64, 32, 32), (2, 2)), ((3, 32, 32, 32), (2, 4)), ((2, 32, 64, 64), (6, 6))])
 def test_fused_spectral_middle_equals_three_launches(dev, shape, modes):
     """k_spec_mid (leading-axis DFT -> mode contraction -> leading-axis inverse DFT of a fused 2-D block in ONE launch,
     the default) vs the k_axis_fwd -> k_mode_gemm -> k_axis_inv sequence it replaces (fno_set_fused_mid(0)): y, dx, dW,
@@ -824,6 +827,18 @@ def test_fused_spectral_middle_equals_three_launches(dev, shape, modes):
     ("A", (2, 64, 64, 128), (6, 6)),           # unfused FNO block convolution with bias
     ("C", (1, 32, 48, 44, 41), (20, 20, 20)),  # BASELINE config 5 as named: modes 20 -> kept extent 40 on both leading axes
     ("B", (2, 32, 64, 64), (16, 12)),          # kept extent 32 (k_axis_fwd<32, 4> / k_axis_inv<32, 8>)
+    # rows that are not tile rows (lanes <-> channels kernels), by padded count of kept last-dim bins (8 / 16 / 32) ...
+    ("C", (2, 32, 8, 40), (3, 12)),            # 16 bins, 32 channels, planes of 320 floats: chan4 forward, flat-tile inverse
+    ("C", (2, 34, 8, 73), (3, 12)),            # 16 bins, 34 channels (the shipped RNO width), odd rows: chan forward, chan inverse
+    ("C", (2, 34, 8, 73), (3, 20)),            # 32 bins
+    ("C", (2, 32, 5, 33), (2, 6)),             # odd planes (165 floats): the row-tile matrix-core inverse, 8 bins
+    ("C", (2, 32, 5, 33), (2, 12)),            # ... 16 bins
+    ("C", (2, 32, 5, 33), (2, 17)),            # ... 32 bins
+    # ... and shapes only the generic row kernels take: more than 64 channels; more than 32 kept bins
+    ("C", (1, 96, 8, 40), (3, 6)), ("C", (1, 96, 8, 40), (3, 12)), ("C", (1, 96, 8, 40), (3, 20)),
+    ("C", (1, 16, 6, 80), (2, 36)),
+    ("C", (1, 200, 4, 256), (2, 6)), ("C", (1, 200, 4, 256), (2, 12)), ("C", (1, 200, 4, 256), (2, 20)),   # rows x channels beyond one LDS tile
+    ("C", (16, 64, 128, 40), (3, 12)),         # enough (8-channel, 8-row) tiles for the long-run forward kernel at 16 bins
 ])
 def test_specconv_tile_rows_vs_oracle(dev, dialect, shape, modes):
     from pde_policylearning_amd import functional as F
@@ -1246,8 +1261,11 @@ def test_rno_gates_match_torch_formulas(dev):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("C,cin,cout,L,S,B", [(32, 1, 1, 1, 32, 1),      # single layer, single sample, one input channel
                                               (64, 2, 2, 3, 64, 2),      # two outputs: the NCO = 4 projection kernels
-                                              (32, 4, 4, 6, 32, 2)])     # widest lifting / projection, six layers (gate: l < L - l)
-def test_fno2d_channel_and_layer_edges_vs_oracle(dev, C, cin, cout, L, S, B):
+                                              (32, 4, 4, 6, 32, 2),      # widest lifting / projection, six layers (gate: l < L - l)
+                                              (64, 3, 1, 1, 64, 2),      # one layer at 64 channels: block 0 with a fused lifting and no epilogue
+                                              (32, 1, 1, 1, 256, 1), (32, 2, 4, 2, 256, 1), (32, 4, 2, 1, 256, 1),      # rows of 256: every lifting width,
+                                              (64, 1, 1, 1, 256, 1), (64, 2, 3, 1, 256, 1), (64, 4, 4, 2, 256, 1)])     # several output channels
+def test_fno2d_channel_and_layer_edges_vs_oracle(dev, C, cin, cout, L, S, B, gemm_mode):
     from pde_policylearning_amd import functional as F
     modes = (8, 6)
     half = [m // 2 for m in modes]
@@ -1259,6 +1277,41 @@ def test_fno2d_channel_and_layer_edges_vs_oracle(dev, C, cin, cout, L, S, B):
     O.lp_loss_rel_sum(O.fno_forward(pc, x, modes, n_layers=L), tgt).backward()
     y, pg = _run_fused(p, x, modes, dev, n_layers=L)
     assert y.shape == (B, cout, S, S)
+    assert rel_l2(_cpu(y), y64) < TOL_Y
+    O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
+    for k in p:
+        _within_budget(rel_l2(_cpu(pg[k].grad), g64[k]), rel_l2(pc[k].grad.numpy(), g64[k]), k)
+
+
+@pytest.mark.parametrize("L,mask", [(1, None), (2, None), (3, 0b110), (6, None)])
+def test_fno2d_strip_kernel_variants_vs_oracle(dev, L, mask):
+    """k_blk_fwd_s (csrc/k_block_fwd3.h) takes every block of a 64-channel model on rows of 128 floats once the problem has 1024
+    tiles (two-term mode); its compile-time variants are (activation on load, row-DFT epilogue none / plain / of the activated
+    output, fused lifting).  The headline model (L = 4, the reference's gate l < L - l) runs four of the nine; these layer
+    counts and one explicit activation mask run the others: L = 1 (lifting, no epilogue), L = 2 (activation on load, no
+    epilogue), L = 3 with mask 0b110 (lifting + plain epilogue; no activation on load + activated epilogue), L = 6 (no activation
+    either side with an epilogue).  Output and every gradient against the float64 oracle."""
+    from pde_policylearning_amd import functional as F
+    C, S, B, modes = 64, 128, 8, (12, 12)
+    half = [m // 2 for m in modes]
+    p = _fno_params(C, L, half, seed_tag="sv")
+    x = torch.from_numpy(fill_named("svx", (B, 3, S, S), 1.0))
+    tgt = torch.from_numpy(fill_named("svt", (B, 1, S, S), 1.0))
+    gate = O.fno_gelu_gate
+    try:
+        if mask is not None:
+            O.fno_gelu_gate = lambda l, n: bool((mask >> l) & 1)
+        y64, g64 = _oracle_fno_fp64(p, x, tgt, modes, L)
+        pc = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        O.lp_loss_rel_sum(O.fno_forward(pc, x, modes, n_layers=L), tgt).backward()
+    finally:
+        O.fno_gelu_gate = gate
+    pg = {k: v.to(dev).requires_grad_(True) for k, v in p.items()}
+    y = F.fno_model(x.to(dev), pg["lifting.fc.weight"], pg["lifting.fc.bias"],
+                    [pg[f"fno_blocks.fno_skips.{l}.weight"] for l in range(L)],
+                    [pg[f"fno_blocks.convs.weight.{i}.tensor"] for i in range(2 * L)],
+                    pg["fno_blocks.convs.bias"], pg["projection.fc1.weight"], pg["projection.fc1.bias"],
+                    pg["projection.fc2.weight"], pg["projection.fc2.bias"], modes=half, gelu_mask=mask)
     assert rel_l2(_cpu(y), y64) < TOL_Y
     O.lp_loss_rel_sum(y, tgt.to(dev)).backward()
     for k in p:
@@ -1357,18 +1410,21 @@ def test_pointwise_conv_add_vs_torch(dev, C, shape):
         assert rel_l2(_cpu(a.grad), b.grad.numpy()) < TOL_COMP, tuple(a.shape)
 
 
-@pytest.mark.parametrize("C,hid,shape,act", [(64, 128, (2, 64, 8, 16, 65), "gelu"), (32, 256, (1, 32, 16, 24), "gelu"),
-                                             (64, 256, (2, 64, 32, 32), "relu"), (32, 256, (1, 32, 16, 24), "relu")])
-def test_projection_head_vs_torch(dev, C, hid, shape, act):
+@pytest.mark.parametrize("C,hid,shape,act,cout", [(64, 128, (2, 64, 8, 16, 65), "gelu", 1), (32, 256, (1, 32, 16, 24), "gelu", 1),
+                                                  (64, 256, (2, 64, 32, 32), "relu", 1), (32, 256, (1, 32, 16, 24), "relu", 1),
+                                                  (32, 128, (2, 32, 16, 24), "gelu", 1),      # hidden 128 at 32 channels
+                                                  (32, 128, (2, 32, 16, 24), "gelu", 3),      # ... and several output channels
+                                                  (64, 256, (1, 64, 16, 16), "gelu", 2)])
+def test_projection_head_vs_torch(dev, C, hid, shape, act, cout):
     """fno_projection_*_act (fc1 -> gelu -> fc2, pinobserver.py:231-233; fc1 -> relu -> fc2, the RNO2d regressor head
     rno.py:171-175) vs the torch ops in fp32 on CPU."""
     from pde_policylearning_amd import functional as F
     x = torch.from_numpy(fill_named("phx", shape, 1.0))
     w1 = torch.from_numpy(fill_named("phw1", (hid, C), 0.15))
     b1 = torch.from_numpy(fill_named("phb1", (hid,), 0.1))
-    w2 = torch.from_numpy(fill_named("phw2", (1, hid), 0.1))
-    b2 = torch.from_numpy(fill_named("phb2", (1,), 0.1))
-    dy = torch.from_numpy(fill_named("phd", (shape[0], 1) + shape[2:], 1.0))
+    w2 = torch.from_numpy(fill_named("phw2", (cout, hid), 0.1))
+    b2 = torch.from_numpy(fill_named("phb2", (cout,), 0.1))
+    dy = torch.from_numpy(fill_named("phd", (shape[0], cout) + shape[2:], 1.0))
     ref = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
     xr = ref[0].movedim(1, -1)                                                   # channels-last as the reference applies it
     actf = torch.nn.functional.gelu if act == "gelu" else torch.relu
