@@ -373,7 +373,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_child:
         return cpu_child(json.loads(args.cpu_child))
-    if CONFIGS[args.config].get("graph") and not args.eager and args.gpus == 1:
+    if CONFIGS[args.config].get("graph") and not args.eager:
+        # (N > 1 too since round 6: the step replays as two graphs with the all-reduce of a plain bucket between them)
         args.graph = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -430,7 +431,7 @@ def main():
     model, inputs, tgt = make_workload(cfg, rank, dev)
     x = inputs[0]
     broadcast_parameters(model)
-    overlap = fused_model and dist_on and not args.no_overlap
+    overlap = fused_model and dist_on and not args.no_overlap and not args.graph      # (graph replay: plain bucket, one all-reduce)
     dp_choice = None
     if overlap and args.overlap == "auto":
         # let the data decide: three timed steps after two warm-ups with the overlapped two-part exchange and
@@ -468,6 +469,8 @@ def main():
         # the bucket is cleared in full so that the accumulating fallback starts from zeros)
         bucket = FlatGradBucket(model.parameters(), direct_module=model, zero_all=cfg["kind"].startswith("rno2d"))
     bucket.force_collective = force_dist
+    if not fused_model and dist_on and args.graph:
+        args.graph = False      # the observers' segmented, dead-slice-skipping exchange starts collectives inside the backward pass: eager under DP
     if not fused_model:
         # layer-ordered segments go on the wire as their gradients complete; dead last-dim slices of the dialect-C weights
         # (PINObserverFullField at T = 1: 11/12 of 906 MB) are never exchanged.  Single GPU: the plan is only reported.
@@ -497,8 +500,6 @@ def main():
 
     eager_step = step
     if args.graph:
-        if dist_on:
-            sys.exit("bench.py --graph is a single-GPU mode")
         from pde_policylearning_amd.trainer import GraphedTrainStep
         graphed = GraphedTrainStep(model, bucket, opt, inputs, tgt, loss_fn)
 

@@ -194,8 +194,9 @@ def gen_specconv_A(outdir):
 
 def gen_specconv_A_overlap(outdir):
     """Overlapping corners (2 * half_modes[0] > H): the reference assigns the corners in order into one zero-filled spectrum, so
-    rows that belong to both take the SECOND corner's product (spectral_convolution.py:330-337).  The engine rejects such
-    shapes (FNO_EUNSUPPORTED); the fixture pins what the reference does (tests/test_oracle_golden.py, tests/test_parity_gpu.py)."""
+    rows that belong to both take the SECOND corner's product (spectral_convolution.py:330-337).  The fixture pins what the
+    reference does for the oracle (tests/test_oracle_golden.py) and for the engine, which since round 6 follows the same
+    order on 2-D grids (tests/test_parity_gpu.py::test_specconv_A_golden[A2d_overlap])."""
     from neuralop.models.spectral_convolution import FactorizedSpectralConv
     cin, cout, n_modes, sp, B = 3, 4, (12, 6), (8, 16), 2
     torch.manual_seed(0)

@@ -244,8 +244,14 @@ static int make_geom(Geom& g, int ndim, const int* dims, const int* modes, int w
   if (g.Klast > g.W / 2 + 1) return fail(FNO_EINVAL, "modes[last]=%d exceeds W/2+1=%d", g.Klast, g.W / 2 + 1);
   g.Ktot = g.Klast;
   for (int d = 0; d < g.nlead; ++d) {
-    if (2 * modes[d] > dims[d])
-      return fail(FNO_EUNSUPPORTED, "overlapping corners: 2*modes[%d]=%d > dims=%d", d, 2 * modes[d], dims[d]);
+    if (modes[d] > dims[d]) return fail(FNO_EINVAL, "modes[%d]=%d exceeds dims=%d", d, modes[d], dims[d]);
+    // Overlapping corners (2 m > N).  The reference assigns the corners in order into one zero-filled spectrum
+    // (spectral_convolution.py:330-337, rno.py:71-74, basics.py:86-89): rows that belong to both take the SECOND corner's
+    // product, and the first corner's weights at those rows see neither data nor gradient.  One leading dim: the first
+    // corner's shadowed slots are switched off in the two truncating tables (make_tables) - nothing else changes, every
+    // kernel keeps its 2 m slots.  Two leading dims (four corners, three assignment orders to restate): still refused.
+    if (2 * modes[d] > dims[d] && g.nlead != 1)
+      return fail(FNO_EUNSUPPORTED, "overlapping corners: 2*modes[%d]=%d > dims=%d (supported on 2-D grids)", d, 2 * modes[d], dims[d]);
     g.Klead[d] = 2 * modes[d];
     g.Ktot *= g.Klead[d];
   }
@@ -302,10 +308,12 @@ static int make_tables(const Geom& g, Tables& t) {
     std::vector<float2> a((size_t)K * N), b((size_t)K * N), inv((size_t)N * K);
     for (int r = 0; r < K; ++r) {
       const int freq = r < m ? r : N - 2 * m + r;
+      // overlapping corners: slot r of the first corner is shadowed when the second corner holds the same row (make_geom)
+      const bool shadowed = r < m && r >= N - m;
       for (int n = 0; n < N; ++n) {
         const double ang = PI2 * (double)((long long)freq * n % N) / N;
         const double c = std::cos(ang), s = std::sin(ang);
-        const double sa = d == 0 ? g.s_f : 1.0, sb = d == 0 ? g.s_i : 1.0;
+        const double sa = shadowed ? 0.0 : (d == 0 ? g.s_f : 1.0), sb = shadowed ? 0.0 : (d == 0 ? g.s_i : 1.0);
         a[(size_t)n * K + r] = make_float2((float)(sa * c), (float)(-sa * s));
         b[(size_t)n * K + r] = make_float2((float)(sb * c), (float)(-sb * s));
         inv[(size_t)n * K + r] = make_float2((float)c, (float)s);

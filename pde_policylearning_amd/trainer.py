@@ -908,6 +908,16 @@ def _unit_gradient(loss):
 def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None):
     """zero_grad -> forward -> decode -> loss -> backward -> all-reduce -> optimizer step
     (run_pde_observers.py:185-193).  Returns the local loss tensor (no host sync)."""
+    loss = local_gradients(model_fn, bucket, inputs, target, loss_fn, decoder)
+    bucket.all_reduce()
+    if optimizer is not None:
+        optimizer.step()
+    return loss
+
+
+def local_gradients(model_fn, bucket, inputs, target, loss_fn, decoder=None):
+    """The rank-local part of train_step: zero_grad -> forward -> decode -> loss -> backward.  Leaves this rank's gradients
+    in the bucket and returns the local loss tensor; no collective (with a plain bucket), no optimizer step."""
     from . import functional as F
     bucket.zero()
     pred = model_fn(*inputs)
@@ -929,9 +939,6 @@ def train_step(model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=Non
     # `loss.backward()` with the unit gradient it would build handed in: torch fills a fresh ones_like(loss) per call (one
     # 4.7 us fill kernel per step on the measured stack); the same values, no launch
     loss.backward(_unit_gradient(loss))
-    bucket.all_reduce()
-    if optimizer is not None:
-        optimizer.step()
     return loss.detach()
 
 
@@ -941,7 +948,13 @@ class GraphedTrainStep(object):
     (BASELINE config 1) become one graph launch.  Everything the step enqueues goes through the engine's C ABI
     on the capture stream; no host-side scalar changes between replays (FusedAdam(capturable=True) keeps its step
     count on the device).  Warm-up steps run before capture on a side stream and their effect on the optimizer /
-    parameters is rolled back, so the first replay is step 1."""
+    parameters is rolled back, so the first replay is step 1.
+
+    Data parallel (round 6): when the bucket's exchange is a real collective (more than one rank, or `force_collective`) the
+    step is captured as TWO graphs - the rank-local part (zero_grad .. backward) and the optimizer step - with the
+    all-reduce of the flat bucket issued eagerly between their replays: the collective stays outside the capture (RCCL
+    inside a hipGraph ties the graph to one communicator state), the launch-bound part of the step is still two graph
+    launches.  Needs a plain bucket: the overlapped / segmented exchanges start collectives from inside the backward pass."""
 
     def __init__(self, model_fn, bucket, optimizer, inputs, target, loss_fn, decoder=None, warmup=2):
         assert isinstance(optimizer, FusedAdam) and optimizer.capturable, "GraphedTrainStep needs FusedAdam(capturable=True)"
@@ -967,9 +980,22 @@ class GraphedTrainStep(object):
         for dst, src in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev, bucket.flat), snap):
             dst.copy_(src)
         opt.step_count = host_step
+        self._bucket = bucket
+        self._dist = bool(bucket._collective_needed())
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = train_step(model_fn, bucket, opt, self.inputs, self.target, loss_fn, decoder)
+        if self._dist:
+            if getattr(bucket, "_late_numel", None) is not None or getattr(bucket, "_segments", None) is not None:
+                raise RuntimeError("GraphedTrainStep with a data-parallel exchange needs a plain FlatGradBucket (one all-reduce "
+                                   "between the two captured parts): the overlapped (for_fno) and segmented (enable_dp_exchange) "
+                                   "buckets start collectives from inside the backward pass")
+            with torch.cuda.graph(self.graph):
+                self.loss = local_gradients(model_fn, bucket, self.inputs, self.target, loss_fn, decoder)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                opt.step()
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = train_step(model_fn, bucket, opt, self.inputs, self.target, loss_fn, decoder)
         opt.step_count = host_step            # capture enqueued nothing
         # lr / betas / eps / weight decay are launch arguments of the captured Adam kernel: a scheduler that changes them
         # afterwards would be ignored silently on replay
@@ -996,6 +1022,9 @@ class GraphedTrainStep(object):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
         self.graph.replay()
+        if self._dist:
+            self._bucket.all_reduce()          # eager, on the replay stream: between the two captured parts
+            self.graph_opt.replay()
         return self.loss
 
 

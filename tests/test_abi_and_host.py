@@ -48,7 +48,12 @@ def test_plan_rejects_bad_arguments_without_gpu(lib):
     assert rc < 0 and b"ndim" in lib.fno_last_error()
     d.ndim = 2
     d.dims[0], d.dims[1] = 8, 8
-    d.modes[0], d.modes[1] = 5, 3            # 2*5 > 8: overlapping corners
+    d.modes[0], d.modes[1] = 9, 3            # more kept rows than the grid has
+    rc = lib.fno_spec_plan_create(ctypes.byref(d), ctypes.byref(h))
+    assert rc < 0 and b"exceeds" in lib.fno_last_error()
+    d.ndim = 3
+    d.dims[0], d.dims[1], d.dims[2] = 8, 8, 8
+    d.modes[0], d.modes[1], d.modes[2] = 5, 3, 3     # 2*5 > 8: overlapping corners are supported on 2-D grids only
     rc = lib.fno_spec_plan_create(ctypes.byref(d), ctypes.byref(h))
     assert rc < 0 and b"overlapping" in lib.fno_last_error()
 

@@ -44,7 +44,8 @@ def test_specconv_A(case):
     if case == "A2d_overlap":
         # 2 * half_modes[0] = 12 > H = 8: rows 2..5 belong to both corners and take the SECOND corner's product, the first
         # corner's weights get no gradient from them (spectral_convolution.py:330-337: in-order slice assignment) - the oracle
-        # restates the assignment order; the closed-form backward below assumes disjoint corners and the engine rejects the shape
+        # restates the assignment order; the closed-form backward below assumes disjoint corners (the engine switches the shadowed
+        # slots of the first corner off in its truncating tables: csrc/fno_abi.hip, make_geom / make_tables)
         return
     # hand-derived backward formulas agree with autograd
     dx2, dws2 = O.spectral_conv_A_backward(x.detach(), [w.detach() for w in ws], _t(g["dy"]),

@@ -43,7 +43,7 @@ def _cpu(t):
 # ---------------------------------------------------------------------------
 # standalone spectral convolution, all three dialects, vs reference goldens
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["A2d", "A2d_ortho_odd", "A2d_backward", "A3d"])
+@pytest.mark.parametrize("case", ["A2d", "A2d_ortho_odd", "A2d_backward", "A3d", "A2d_overlap"])      # (A2d_overlap: 2 m > H, the second corner wins)
 def test_specconv_A_golden(dev, case):
     from pde_policylearning_amd import functional as F
     g = load_golden("specconv_" + case)
@@ -1224,6 +1224,108 @@ def test_graphed_train_step_equals_eager(dev):
     o2.lr = 5e-4            # a scheduler step after capture: the captured launches carry the old rate - refused, not ignored
     with pytest.raises(RuntimeError, match="changed after capture"):
         step2()
+
+
+def _graph_dp_worker(rank, world, port, q):
+    """two ranks on ONE device over gloo: the two-graph step (local gradients | eager all-reduce | Adam) against the eager step"""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pde_policylearning_amd.neuralop.models import FNO2d
+        from pde_policylearning_amd.trainer import (FlatGradBucket, FusedAdam, FusedLpLoss, GraphedTrainStep, broadcast_parameters,
+                                                     train_step)
+        dev = torch.device("cuda:0")
+        torch.manual_seed(4)
+        m1 = FNO2d(8, 8, 32).to(dev)
+        m2 = FNO2d(8, 8, 32).to(dev)
+        m2.load_state_dict(m1.state_dict())
+        broadcast_parameters(m1); broadcast_parameters(m2)
+        g = torch.Generator(device="cpu").manual_seed(100 + rank)          # every rank its own shard of the batch
+        x = torch.randn(2, 3, 64, 64, generator=g).to(dev)
+        t = torch.randn(2, 1, 64, 64, generator=g).to(dev)
+        b1 = FlatGradBucket(m1.parameters(), direct_module=m1)
+        b2 = FlatGradBucket(m2.parameters(), direct_module=m2)
+        o1 = FusedAdam(b1, lr=1e-3, weight_decay=1e-4)
+        o2 = FusedAdam(b2, lr=1e-3, weight_decay=1e-4, capturable=True)
+        loss_fn = FusedLpLoss(size_average=False)
+        step2 = GraphedTrainStep(m2, b2, o2, (x,), t, loss_fn)
+        assert step2._dist and hasattr(step2, "graph_opt")
+        same = True
+        for _ in range(3):
+            l1 = train_step(m1, b1, o1, (x,), t, loss_fn)
+            l2 = step2()
+            same = same and float(l1) == float(l2)
+        same = same and bool(torch.equal(o1.flat_param, o2.flat_param))
+        ref = o2.flat_param.detach().clone()
+        dist.broadcast(ref, src=0)                                          # the replicas stayed identical
+        q.put((rank, same, bool(torch.equal(ref, o2.flat_param))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_train_step_data_parallel_two_ranks(dev):
+    """the launch-bound configurations keep hipGraph replay under data parallelism - the step is captured
+    as two graphs with the all-reduce of the flat bucket issued eagerly between them (trainer.GraphedTrainStep).  Two ranks
+    share this GPU over gloo (the collective moves the bucket through the host; RCCL needs one device per rank): three graphed
+    steps equal three eager data-parallel steps bit for bit on every rank, and the replicas stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_graph_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert all(r[2] for r in res), res
+
+
+def test_graphed_train_step_refuses_overlapped_bucket_under_dp(dev):
+    """the overlapped bucket starts its collective from inside the backward pass: not capturable as two graphs - refused"""
+    import torch.distributed as dist
+    from pde_policylearning_amd.neuralop.models import FNO2d
+    from pde_policylearning_amd.trainer import FlatGradBucket, FusedAdam, FusedLpLoss, GraphedTrainStep
+    torch.manual_seed(4)
+    m = FNO2d(8, 8, 32).to(dev)
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    t = torch.randn(2, 1, 64, 64, device=dev)
+    started = False
+    if not dist.is_initialized():
+        import os, socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        started = True
+    try:
+        b = FlatGradBucket.for_fno(m, split_layer=1)
+        b.force_collective = True
+        o = FusedAdam(b, lr=1e-3, capturable=True)
+        with pytest.raises(RuntimeError, match="plain FlatGradBucket"):
+            GraphedTrainStep(m, b, o, (x,), t, FusedLpLoss(size_average=False))
+        b.close()
+        # a plain bucket with the collective forced: the two-graph path on RCCL with one rank equals the eager step
+        m2 = FNO2d(8, 8, 32).to(dev)
+        m2.load_state_dict(m.state_dict())
+        from pde_policylearning_amd.trainer import train_step
+        b1 = FlatGradBucket(m.parameters(), direct_module=m)
+        b2 = FlatGradBucket(m2.parameters(), direct_module=m2)
+        b1.force_collective = b2.force_collective = True
+        o1 = FusedAdam(b1, lr=1e-3, weight_decay=1e-4)
+        o2 = FusedAdam(b2, lr=1e-3, weight_decay=1e-4, capturable=True)
+        lf = FusedLpLoss(size_average=False)
+        step2 = GraphedTrainStep(m2, b2, o2, (x,), t, lf)
+        assert step2._dist
+        for i in range(3):
+            assert float(train_step(m, b1, o1, (x,), t, lf)) == float(step2()), i
+        assert torch.equal(o1.flat_param, o2.flat_param)
+    finally:
+        if started:
+            dist.destroy_process_group()
 
 
 def test_rno_gates_match_torch_formulas(dev):
