@@ -843,15 +843,8 @@ static int row_inverse(hipStream_t st, const Geom& g, const float* tinv, const f
   while (rb > 1 && need(rb) > 64 * 1024) rb >>= 1;
   if (need(rb) > 160 * 1024) return fail(FNO_EUNSUPPORTED, "row spectra of %d channels x %d bins exceed LDS", C, g.Klast);
   const dim3 grid(B * ((g.P + rb - 1) / rb));
-  if (g.Klast <= 8)
-    return launch("k_rowidft_generic", k_rowidft_generic<8>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
-                  C, g.P, g.W, g.Klast, rb);
-  if (g.Klast <= 16)
-    return launch("k_rowidft_generic", k_rowidft_generic<16>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
-                  C, g.P, g.W, g.Klast, rb);
-  if (g.Klast <= 32)
-    return launch("k_rowidft_generic", k_rowidft_generic<32>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias,
-                  C, g.P, g.W, g.Klast, rb);
+  // (<= 32 kept bins always fit one of the tile / lanes-as-channels kernels above: plan creation refuses rows whose channel tile
+  // exceeds LDS; what is left for the generic kernel is more than 32 bins, its run-time-bound form)
   return launch("k_rowidft_generic", k_rowidft_generic<0>, grid, dim3(256), need(rb), st, (const float2*)z, y, tinv, bias, C,
                 g.P, g.W, g.Klast, rb);
 }

@@ -837,7 +837,6 @@ def test_fused_spectral_middle_equals_three_launches(dev, shape, modes):
     # ... and shapes only the generic row kernels take: more than 64 channels; more than 32 kept bins
     ("C", (1, 96, 8, 40), (3, 6)), ("C", (1, 96, 8, 40), (3, 12)), ("C", (1, 96, 8, 40), (3, 20)),
     ("C", (1, 16, 6, 80), (2, 36)),
-    ("C", (1, 200, 4, 256), (2, 6)), ("C", (1, 200, 4, 256), (2, 12)), ("C", (1, 200, 4, 256), (2, 20)),   # rows x channels beyond one LDS tile
     ("C", (16, 64, 128, 40), (3, 12)),         # enough (8-channel, 8-row) tiles for the long-run forward kernel at 16 bins
 ])
 def test_specconv_tile_rows_vs_oracle(dev, dialect, shape, modes):
