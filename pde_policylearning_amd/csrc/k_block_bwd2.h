@@ -16,6 +16,9 @@
 #include "fno_dev.h"
 #include "k_block_bwd.h"
 
+#ifndef FNO_BBT_LINE_ST
+#define FNO_BBT_LINE_ST 1      // k_block_bwd_t: gout in whole lines from the LDS tile (A/B arm 0: 16 bytes per channel row from registers)
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -182,13 +185,14 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
   const int grow0 = mt * 32 + (lane >> 3);
   float xa[NKL];                // LIFT: x[k = half + 2 s][pixel n0 + l31] of the next tile
   float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile_) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;      // (zigzag along the kernel chain: fno_abi.hip)
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     const size_t ro = ((size_t)b * C + crow) * a.PW + px0 + n0 + 4 * half;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)      // g: whole 128-byte lines per 8 lanes (row grow0 + 8 i, pixels n0 + 4 (lane & 7) ..)
-      gq[i] = ld4(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
+    for (int i = 0; i < 4; ++i)      // g: whole 128-byte lines per 8 lanes (row grow0 + 8 i, pixels n0 + 4 (lane & 7) ..); read once: streaming
+      gq[i] = ld4s(a.g + ((size_t)b * C + grow0 + 8 * i) * a.PW + px0 + n0 + 4 * (lane & 7));
     if constexpr (LIFT) {
 #pragma unroll
       for (int s = 0; s < NKL; ++s) {
@@ -197,6 +201,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
       }
     } else {
 #pragma unroll
+      // (default cache policy, NOT streaming: in this layout a 128-byte line is touched by four instructions, and a line that
+      // the L2 does not keep is fetched again for each of them - 0.36 -> 0.46 ms per launch at FNO3d, round 6)
       for (int i = 0; i < 4; ++i) uq[i] = ld4(a.uin + ro + 8 * i);
     }
     if (tid < zc4(px0)) zv = ld4(a.zg + ((size_t)b * a.P + px0 / a.W) * a.K2in * C * 2 + 4 * tid);
@@ -205,7 +211,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
 
   int tslot = 0, par = 0;
   FNO_TRACE_IF(FNO_TRACE_WHICH == 2 && a.x1g != nullptr);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, par ^= 1) {
+  for (int tile_ = blockIdx.x; tile_ < a.ntiles; tile_ += gridDim.x, par ^= 1) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     float* xlt = xls + par * 8 * PITCH;
@@ -244,7 +251,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
     FNO_STAMP(tslot + 1);
     __syncthreads();
     FNO_STAMP(tslot + 2);
-    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    if (tile_ + (int)gridDim.x < a.ntiles) issue(tile_ + gridDim.x);
 
     // ---- dW[o][i] += sum_px g[o][px] a[i][px]: row reads of both images, 8 consecutive pixels per lane ----------------
     // (one accumulator for all six products: a per-element bias of 1e-8 is harmless here, nothing sums dW any further)
@@ -335,7 +342,9 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
           v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
         }
         if (a.act_in) { v.x *= dg[i].x; v.y *= dg[i].y; v.z *= dg[i].z; v.w *= dg[i].w; }
-        if (a.gout) st4(a.gout + ro + 8 * i, v);
+        // (with a gout tile in LDS the tile leaves in whole lines behind the barrier, below: from this layout - lane <-> channel
+        // row, 16 bytes - one store instruction touches 32 lines for 32 bytes each)
+        if (a.gout && !(FNO_BBT_LINE_ST && (a.x1g || a.xin))) st4(a.gout + ro + 8 * i, v);
         if (a.gmax_out) vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
         if (a.x1g || a.xin) st4(r3p + 8 * i, v);
       }
@@ -343,6 +352,14 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32) * 64, 2) k_block_bwd_t(B
     FNO_STAMP(tslot + 5);
     __syncthreads();          // images are free for the next commit; the gout tile is complete
     FNO_STAMP(tslot + 6);
+    if (FNO_BBT_LINE_ST && a.gout && (a.x1g || a.xin)) {      // gout: row tid / 32 + (NT / 32) i of the tile, 16-byte piece tid % 32: whole 512-byte rows
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));         // (opaque: the offsets are derived per tile, not hoisted into registers live through the GEMMs)
+      const float* r3l = r3 + (t_ >> 5) * PITCH + 4 * (t_ & 31);
+      float* gl = a.gout + ((size_t)b * C + (t_ >> 5)) * a.PW + px0 + 4 * (t_ & 31);
+#pragma unroll
+      for (int i = 0; i < C * 32 / NT; ++i) st4(gl + (size_t)i * (NT / 32) * a.PW, ld4(r3l + i * (NT / 32) * PITCH));
+    }
     if (a.x1g) row_dft_epilogue<C, NPX, NW>(r3, tfwd_s, a.W + 4, a.x1g, b, px0, a.P, a.W, a.K2out, a.NJ, wave, lane);
     if (a.xin) {
       // dl[c][n] += sum_px gout[c][px] * xext[n][px],  xext = [x_in rows | ones | 0..]

@@ -40,9 +40,6 @@ static inline size_t blk_fwd_t_lds_bytes(int c, int W, int K2in, int NJ, bool ha
   return bytes;
 }
 
-__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int soff, const float4& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{v.x, v.y, v.z, v.w}), r, voff, soff, 0);
-}
 
 // LIFT: block 0 of a model with a lifting layer: the tile is u_0 = W_l x + b_l of the <= 4-channel model input, computed on
 // commit (k_pointwise.h, LiftSplitTilePrefetch).  RELU: the stored tensor is max(u, 0) (rno.py:92-106 regressor layers).

@@ -140,6 +140,8 @@ template <int C, int HID, bool RELU = false, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   FNO_CLK_ENTRY();
   constexpr int NPX = 128, NTN = 4, NT = 512, KB = C / 16, MT = C / 32, XI = C / 16;
+  constexpr bool LINE_ST = NT3 == 2 || MT == 1;      // gout leaves in whole lines from the LDS tile (not the three-term 64-channel
+                                                       // kernel: it has no register to spare for it)
   static_assert(C == 32 || C == 64, "32 or 64 channels");
   constexpr int NCH = HID / 64, CPW = NCH / 2;
   constexpr int PITCH = NPX + 4;
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       }
       // (with a gout tile in LDS for the row DFT the tile leaves in whole lines behind the barrier, below: stored from the
       // accumulator layout - lane <-> channel row, 16 bytes - one instruction touches 32 lines for 32 bytes each)
-      if (!a.x1g) {
+      if (!(LINE_ST && a.x1g)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st4(a.gout + ro + 8 * i, v[i]);
       }
@@ -458,19 +460,23 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         if (a.act_in) {
           { float4 uu = uq[j], dd; gelu_both4(uu, dd); v.x *= dd.x; v.y *= dd.y; v.z *= dd.z; v.w *= dd.w; }
         }
-        st4(a.gout + ro + 8 * i, v);
+        if (!(LINE_ST && a.x1g)) st4(a.gout + ro + 8 * i, v);
         if (a.gmax_out) gvmax = fmaxf(fmaxf(gvmax, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
         if (a.x1g) st4(r3p + 8 * i, v);
       }
     }
     if (a.x1g) {
       __syncthreads();
-      if constexpr (MT == 2) {      // gout: row tid / 32 + 16 i of the tile, 16-byte piece tid % 32 - whole 512-byte rows
+      if constexpr (LINE_ST) {      // gout: row tid / 32 + 16 i of the tile, 16-byte piece tid % 32 - whole 512-byte rows
+        // (buffer stores on the x loads' lane offset; the LDS offset from an opaque copy of the thread index: derived per tile,
+        // not hoisted into registers that would be live through the chunk loop - the kernel sits at its 256-register cap)
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const float* r3l = (MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + R3B_OFF)) + (t_ >> 5) * PITCH + 4 * (t_ & 31);
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gout + (size_t)b * C * a.PW, (unsigned)(C * a.PW * 4));
 #pragma unroll
-        for (int i = 0; i < C / 16; ++i) {
-          const int row = (tid >> 5) + 16 * i;
-          st4(a.gout + ((size_t)b * C + row) * a.PW + px0 + 4 * (tid & 31), ld4(r3 + row * PITCH + 4 * (tid & 31)));
-        }
+        for (int i = 0; i < C / 16; ++i)
+          buf_st4(rg, xvoff + (16 * i * a.PW + px0) * 4, 0, ld4(r3l + 16 * i * PITCH));
       }
       row_dft_epilogue<C, NPX, 8>(MT == 2 ? r3 : reinterpret_cast<float*>(dr0 + R3B_OFF), tfwd_s, a.W + 4, a.x1g, b, px0, a.P,
                                   a.W, a.K2out, a.NJ, wave, lane);
