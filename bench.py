@@ -91,8 +91,8 @@ CONFIGS = {
 }
 
 
-PMC_TRAFFIC_JSON = "r05_pmc_traffic.json"
-PMC_SQ_CSV = "r05_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
+PMC_TRAFFIC_JSON = "r06_pmc_traffic.json"
+PMC_SQ_CSV = "r06_pmc_sq.csv"          # tools/pmc_sq.py summary of the SQ passes (tools/collect_profiles.sh)
 
 
 # profile label -> the instantiation rocprofv3 --kernel-trace lists for it (headline workload, default GEMM mode)
@@ -536,19 +536,21 @@ def main():
     # ---- the precision-matched arm: the same step with every channel GEMM on the exact-fp32 matrix instructions
     # (fno_set_gemm_mode(0): v_mfma_f32_32x32x2_f32, no split-precision products) - a short second timed block, same bracketing
     exact_fp32 = None
-    if fused_model and not args.graph and not args.no_exact_fp32 and _lib.lib().fno_get_gemm_mode() == 1:
+    if not args.no_exact_fp32 and _lib.lib().fno_get_gemm_mode() == 1:
+        # (every workload since round 6: the observers' modules take the unfused compositions where a fused path exists in
+        # split precision only - loose rows, the regressor tails; eager steps: a captured graph holds the split-precision launches)
         Lb = _lib.lib()
         Lb.fno_set_gemm_mode(0)
         try:
             for _ in range(3):
-                step()
+                eager_step()
             eb = []
-            nst = max(5, args.steps // 2)
+            nst = max(3, args.steps // 2)
             for _ in range(3):
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(nst):
-                    step()
+                    eager_step()
                 sync()
                 eb.append(time.perf_counter() - t0)
             if dist_on:
@@ -558,10 +560,13 @@ def main():
             em = sorted(eb)[1]
             exact_fp32 = dict(value=round(B * world * nst / em, 2), ms_per_step=round(1e3 * em / nst, 4), steps=nst, repeats=3,
                               gemm_mode="f32 (v_mfma_f32_32x32x2_f32 everywhere: fno_set_gemm_mode(0))",
-                              step_hbm_frac=round(algorithmic_bytes_per_field(cfg) * B / (em / nst) / (PEAK_HBM_GBS * 1e9), 4))
+                              step_hbm_frac=round(algorithmic_bytes_per_field(cfg) * B / (em / nst) / (PEAK_HBM_GBS * 1e9), 4),
+                              launch="eager")
+        except RuntimeError as e:
+            exact_fp32 = dict(unavailable=str(e)[:300])
         finally:
             Lb.fno_set_gemm_mode(1)
-        step()      # back on the default kernels before the profiled steps
+        eager_step()      # back on the default kernels before the profiled steps
 
     # ---- the mode contraction on the matrix cores, beside the default (north_star: 'bixy,ioxy->boxy' as a batched complex GEMM on
     # MFMA).  The default 2-D path runs the contraction inside k_spec_mid as a mat-vec per (sample, bin) workgroup on the vector
@@ -607,7 +612,7 @@ def main():
                 default="k_spec_mid: leading-axis DFT + contraction (vector lanes, mat-vec per (sample, bin)) + inverse DFT in one launch",
                 mfma_arm=dict(value=round(B * world * nst / mm, 2), ms_per_step=round(1e3 * mm / nst, 4), kernels=arm,
                               what="fno_set_fused_mid(0): k_axis_fwd -> k_mode_gemm on v_mfma_f32_32x32x2_f32 -> k_axis_inv per block "
-                                   "and direction; SQ_INSTS_MFMA of k_mode_gemm: profiles/r05_pmc_sq_mfma_arm.csv"))
+                                   "and direction; SQ_INSTS_MFMA of k_mode_gemm: profiles/r06_pmc_sq_mfma_arm.csv"))
         finally:
             Lb.fno_set_fused_mid(1)
         step()
@@ -694,7 +699,8 @@ def main():
                     pt = pj["kernels"]
                     base = {"k_pw_fwd_block": "k_pw_fwd", "k_pw_fwd_lift": "k_pw_fwd"}.get(dom["name"], dom["name"])
                     cands = [k for k in pt if k.split("<")[0] in (base, base + "_x3", base + "_t", base + "_g2")]
-                    key = next((k for k in cands if not k.endswith(", true>")), cands[0])   # not the block-0 LIFT variants
+                    inst = INSTANTIATION.get(args.config, {}).get(dom["name"])
+                    key = inst if inst in pt else next((k for k in cands if "<true" not in k), cands[0])   # not the block-0 LIFT variants
                     roofline["traffic"] = round(pt[key]["fetch_bytes"] + pt[key]["write_bytes"])
                     roofline["traffic_source"] = (f"profiles/{PMC_TRAFFIC_JSON} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                                   "separate passes, corrected; same command and workload)")
