@@ -920,6 +920,8 @@ struct FnoModelPlan {
     bool h2_u0 = false;          // ... and the bound of |u_0| (fused lifting)
     bool gchain_valid = false;   // the last backward part left max |g| of its output gradient (amax[32 + l_lo])
     bool bwd_clean = false;      // the forward cleared all bound slots and no backward pass has written its range [32, 64) since
+    int B = 0;                   // batch of the forward that published this record (a relocated copy of another
+                                 // forward's `saved` can land on this address - a record for a different batch is a miss)
   };
   mutable std::mutex call_mu;
   mutable std::vector<std::pair<const void*, CallState>> calls;      // most recent last; capped (kMaxCalls)
@@ -934,10 +936,14 @@ struct FnoModelPlan {
   // miss (`found` = false): the buffer was evicted (more than kMaxCalls forwards since) or autograd handed `saved` back at another
   // address (saved_tensors_hooks, offload, checkpoint repack).  The caller then falls back to what a forward pass of this plan
   // does under the current switches for u0_skipped (model_backward_impl) and to the three-term paths, which need no bounds.
-  CallState get_call(const void* saved, bool* found) const {
+  CallState get_call(const void* saved, int B, bool* found) const {
     std::lock_guard<std::mutex> lk(call_mu);
     for (size_t i = calls.size(); i-- > 0;)
-      if (calls[i].first == saved) { *found = true; return calls[i].second; }
+      if (calls[i].first == saved) {
+        if (calls[i].second.B != B) break;      // stale: another forward's record for this address
+        *found = true;
+        return calls[i].second;
+      }
     *found = false;
     return CallState();
   }
@@ -1482,6 +1488,7 @@ static int model_forward_impl(const FnoModelPlan* p, int B, const FnoModelParams
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
   bool lift_xmax = false;      // max |x| of the model input was published (k_lift_rowdft)
   FnoModelPlan::CallState cs;
+  cs.B = B;
   PwFwdArgs a;
   if (has_lift) {
     // lifting (tfno.py:19-20) + row DFT of its output
@@ -1622,7 +1629,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
 
   const bool has_lift = d.Cin > 0, has_proj = d.Cout > 0;
   bool cs_found = false;
-  FnoModelPlan::CallState cs = p->get_call(saved, &cs_found);      // what the forward pass that filled `saved` published
+  FnoModelPlan::CallState cs = p->get_call(saved, B, &cs_found);      // what the forward pass that filled `saved` published
   if (!cs_found) {
     // an unknown buffer: u_0 was written or not exactly as a forward of this plan decides it (a default of "written" would let
     // block 0 read memory the forward never filled); no bounds are assumed published
@@ -1630,6 +1637,7 @@ static int model_backward_impl(const FnoModelPlan* p, int B, const FnoModelParam
     if (strict) return fail(FNO_EINVAL, "fno_model_backward: `saved` buffer %p was not filled by a forward pass of this plan", saved);
     cs.u0_skipped = has_lift && lift_fused(p);
   }
+  cs.B = B;
   bool gvalid = false;      // amax[32 + l + 1] bounds the gradient the next block kernel reads (two-term fp16 GEMMs)
   float* amax_b = const_cast<float*>(wps) + (size_t)2 * L * s.n_wp;
   if (l_hi < L - 1 && g_gemm_x3 && g_h2 && cs.h2_fwd) gvalid = cs.gchain_valid;      // a later part: left by the previous part's last kernel

@@ -112,22 +112,26 @@ __global__ void __launch_bounds__(256) k_absmax3_pack_w1(const float* __restrict
     absmax3_block(x0, n0, g0, w1, (size_t)HID * C, g1, x2, n2, g2, dst, sum0);
     return;
   }
-  float m = 0.f;
+  // max of the BIT PATTERNS of |w| - as absmax_publish forms the published bound (a NaN orders above every number there; fmaxf
+  // would drop it here and the fragments' scale would disagree with the bound the consumers read: ADVICE r05)
+  unsigned mu = 0u;
+  auto upd = [&](float v) { const unsigned u = __builtin_bit_cast(unsigned, v) & 0x7fffffffu; mu = u > mu ? u : mu; };
   const int n4 = HID * C / 4;                        // (C is 32 or 64: whole float4s)
   if ((reinterpret_cast<uintptr_t>(w1) & 15) == 0) {
     for (int i = threadIdx.x; i < n4; i += 256) {
       const float4 a = ld4(w1 + 4 * i);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      upd(a.x); upd(a.y); upd(a.z); upd(a.w);
     }
   } else {                                           // a parameter that is a view at an odd offset of a flat bucket
-    for (int i = threadIdx.x; i < 4 * n4; i += 256) m = fmaxf(m, fabsf(w1[i]));
+    for (int i = threadIdx.x; i < 4 * n4; i += 256) upd(w1[i]);
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  __shared__ float wmx[4];
-  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = m;
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mu, o, 64); mu = t > mu ? t : mu; }
+  __shared__ unsigned wmx[4];
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mu;
   __syncthreads();
-  m = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+  mu = max(max(wmx[0], wmx[1]), max(wmx[2], wmx[3]));
+  const float m = __builtin_bit_cast(float, mu);
   pack_w1_t_item<2>(w1, wa1, wb3, HID, C, h2_scale(m), ((int)blockIdx.x - nscan) * 256 + threadIdx.x);
 }
 

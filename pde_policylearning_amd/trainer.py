@@ -901,6 +901,10 @@ def _unit_gradient(loss):
     key = (loss.device, loss.dtype)
     g = _UNIT_GRADS.get(key)
     if g is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            # first use inside a graph capture: the fill would only be RECORDED, and the cached tensor - in the graph's private
+            # pool - would hold uninitialised memory for any eager step before the first replay: torch's own default
+            return None
         g = _UNIT_GRADS[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     return g
 

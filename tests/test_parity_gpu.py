@@ -227,7 +227,10 @@ def _fno_params(C, L, half_modes, cin=3, cout=1, seed_tag="p"):
 # itself above 1e-5 (dead-mode spectral weights, the 1e-6-scaled input: profiles/r05_hostile_errors.txt and
 # r05_fullsize_budget_ratios.txt hold every achieved number).  On such tensors both float32 evaluations are draws of a
 # conditioned quantity; the engine's split-precision GEMMs are ~1.5 x noisier there than torch's CPU float32, never 2 x.
-BUDGET_SLACK = 2.0
+# Round 6: 2.0 -> 1.75.  The largest ratios of profiles/r06_hostile_errors.txt on tensors whose float32-oracle error exceeds 5e-6
+# are 1.70 / 1.69 / 1.52 (target_norm_1e-6: the SECOND-corner spectral weights of blocks 0-2, whose float32 oracle is itself
+# 6e-6 .. 5e-5 from float64); every first-corner weight, skip weight and bias is below 1.2.
+BUDGET_SLACK = 1.75
 
 
 def _within_budget(err_engine, err_ref32, what):
