@@ -230,13 +230,60 @@ FNO_DEV void gelu_both2(f32x2 x, f32x2& g, f32x2& dg) {
   g = x * cdf;
   dg = __builtin_elementwise_fma(x * f32x2{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
 }
+// NP pairs in lock step (gelu_both2's operations per element, bit-identical): gfx950 needs one wait state between a vector
+// instruction and a packed one that reads its result through op_sel (the broadcast constants), and the compiler schedules ONE
+// pair's chain depth first and fills the gaps with s_nop 0 (k_proj_bwd_t: 103 of them per chunk, a wave alone on its SIMD pays 4
+// cycles each).  Written step by step over the pairs, the next pair's instruction sits in every gap.
+#ifndef FNO_GELU_LOCKSTEP
+#define FNO_GELU_LOCKSTEP 1      // 0: one pair after the other (A/B arm)
+#endif
+template <int NP>
+FNO_DEV void gelu_both_pairs(const f32x2 (&x)[NP], f32x2 (&g)[NP], f32x2 (&dg)[NP]) {
+#if !FNO_GELU_PK || !FNO_GELU_LOCKSTEP
+#pragma unroll
+  for (int p = 0; p < NP; ++p) gelu_both2(x[p], g[p], dg[p]);
+  return;
+#endif
+  constexpr float ca = 0.3275911f * 0.70710678118654752440f;
+  constexpr float cp[5] = {0.5f * 1.061405429f, 0.5f * -1.453152027f, 0.5f * 1.421413741f, 0.5f * -0.284496736f, 0.5f * 0.254829592f};
+  f32x2 t[NP], poly[NP], e[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    t[p] = __builtin_elementwise_fma(f32x2{__builtin_fabsf(x[p][0]), __builtin_fabsf(x[p][1])}, f32x2{ca, ca}, f32x2{1.0f, 1.0f});
+#pragma unroll
+  for (int p = 0; p < NP; ++p) e[p] = (x[p] * x[p]) * f32x2{-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f};
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { t[p][0] = __builtin_amdgcn_rcpf(t[p][0]); t[p][1] = __builtin_amdgcn_rcpf(t[p][1]); }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { e[p][0] = __builtin_amdgcn_exp2f(e[p][0]); e[p][1] = __builtin_amdgcn_exp2f(e[p][1]); }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) poly[p] = __builtin_elementwise_fma(t[p], f32x2{cp[0], cp[0]}, f32x2{cp[1], cp[1]});
+#pragma unroll
+  for (int k = 2; k < 5; ++k)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) poly[p] = __builtin_elementwise_fma(t[p], poly[p], f32x2{cp[k], cp[k]});
+#pragma unroll
+  for (int p = 0; p < NP; ++p) poly[p] = poly[p] * t[p];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) poly[p] = poly[p] * e[p];                                   // q = 0.5 erfc(|x| / sqrt 2)
+#pragma unroll
+  for (int p = 0; p < NP; ++p) poly[p] = f32x2{0.5f, 0.5f} - poly[p];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { poly[p][0] = __builtin_copysignf(poly[p][0], x[p][0]); poly[p][1] = __builtin_copysignf(poly[p][1], x[p][1]); }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) poly[p] = f32x2{0.5f, 0.5f} + poly[p];                      // cdf
+#pragma unroll
+  for (int p = 0; p < NP; ++p) t[p] = x[p] * f32x2{0.39894228040143267794f, 0.39894228040143267794f};
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { g[p] = x[p] * poly[p]; dg[p] = __builtin_elementwise_fma(t[p], e[p], poly[p]); }
+}
 // four values at once (a float4 of activations): value back in v, derivative in d
 FNO_DEV void gelu_both4(float4& v, float4& d) {
-  f32x2 g0, g1, d0, d1;
-  gelu_both2(f32x2{v.x, v.y}, g0, d0);
-  gelu_both2(f32x2{v.z, v.w}, g1, d1);
-  v = make_float4(g0[0], g0[1], g1[0], g1[1]);
-  d = make_float4(d0[0], d0[1], d1[0], d1[1]);
+  const f32x2 x[2] = {f32x2{v.x, v.y}, f32x2{v.z, v.w}};
+  f32x2 g[2], dd[2];
+  gelu_both_pairs<2>(x, g, dd);
+  v = make_float4(g[0][0], g[0][1], g[1][0], g[1][1]);
+  d = make_float4(dd[0][0], dd[0][1], dd[1][0], dd[1][1]);
 }
 
 // sum over the 32 lanes of each wave half (lanes 0-31 / 32-63); every lane gets its half's sum.

@@ -84,7 +84,8 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   float xin[4];                                          // LIFT: the model input at this thread's pixel
   constexpr int ZP = 2;                                  // float4 pieces of spectral rows prefetched per thread
   float4 zpf[ZP];
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile_) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;      // (zigzag along the kernel chain: k_blk_fwd_s)
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     if constexpr (LIFT) {
@@ -240,7 +241,8 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
   float vmax = 0.f;          // max |u| stored by this thread (a.umax)
   FNO_TRACE_IF(true);
   FNO_CLK_BEGIN();
-  for (int tile = ts.first; tile < ts.end; tile += ts.step) {
+  for (int tile_ = ts.first; tile_ < ts.end; tile_ += ts.step) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__((C / 32) * 2 * 64, 2) k_blk_fwd_t(PwFwdArgs a)
     }
     // the next tile's loads go out behind the GEMM (their 32 registers must not be live beside the weight fragments, the
     // accumulators and the fragment double buffer); epilogue, row DFT and the other workgroup's phases cover their latency
-    if (tile + ts.step < ts.end) issue(tile + ts.step);
+    if (tile_ + ts.step < ts.end) issue(tile_ + ts.step);
     FNO_STAMP(tslot + 3);
     __syncthreads();        // every wave is done with the images (the fp32 output tile reuses them)
     FNO_STAMP(tslot + 4);

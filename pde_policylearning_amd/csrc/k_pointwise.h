@@ -314,7 +314,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
   if constexpr (LIFT) stage_lift_params<C>(lws, a.lw, a.lb, a.CL, tid, NT);     // visible after the first tile's barrier? no: sync here
   if constexpr (LIFT) __syncthreads();
   float4 zpf = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto issue = [&](int tile) {
+  auto issue = [&](int tile_) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;      // (zigzag along the kernel chain: k_blk_fwd_s)
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     // the thread index goes through an opaque move: hoisted out of the tile loop, the per-lane 64-bit base addresses of the
@@ -329,7 +330,8 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
 
   int tslot = 0;
   FNO_TRACE_IF(FNO_TRACE_SEL);
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  for (int tile_ = blockIdx.x; tile_ < a.ntiles; tile_ += gridDim.x) {
+    const int tile = a.rev ? a.ntiles - 1 - tile_ : tile_;
     const int b = tile / a.tiles_per_plane;
     const int px0 = (tile % a.tiles_per_plane) * NPX;
     FNO_STAMP(tslot + 0);
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
     FNO_STAMP(tslot + 1);
     __syncthreads();
     FNO_STAMP(tslot + 2);
-    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    if (tile_ + (int)gridDim.x < a.ntiles) issue(tile_ + gridDim.x);
 
     f32x16 acc[NTW];
 #pragma unroll

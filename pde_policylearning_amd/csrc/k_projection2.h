@@ -305,17 +305,20 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
         for (int i = 0; i < 4; ++i) {
           const float4 dy4 = ld4(douts + n0 + 8 * i + 4 * half);
           const f32x2 dyp[2] = {f32x2{dy4.x, dy4.y}, f32x2{dy4.z, dy4.w}};
-          f32x2 dpp[2];
+          f32x2 dpp[2], pv[2], gv[2], dv[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) pv[h2] = f32x2{acc[4 * i + 2 * h2], acc[4 * i + 2 * h2 + 1]} + b1p;
+          if constexpr (RELU) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              dv[h2] = f32x2{pv[h2][0] > 0.f ? 1.f : 0.f, pv[h2][1] > 0.f ? 1.f : 0.f};
+              gv[h2] = f32x2{fmaxf(pv[h2][0], 0.f), fmaxf(pv[h2][1], 0.f)};
+            }
+          } else gelu_both_pairs<2>(pv, gv, dv);          // value and derivative, two pairs in lock step (fno_dev.h)
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
-            const f32x2 pv = f32x2{acc[4 * i + 2 * h2], acc[4 * i + 2 * h2 + 1]} + b1p;
-            f32x2 gv, dv;
-            if constexpr (RELU) {
-              dv = f32x2{pv[0] > 0.f ? 1.f : 0.f, pv[1] > 0.f ? 1.f : 0.f};
-              gv = f32x2{fmaxf(pv[0], 0.f), fmaxf(pv[1], 0.f)};
-            } else gelu_both2(pv, gv, dv);          // value and derivative on pairs (fno_dev.h)
-            dpp[h2] = dv * (w2p * dyp[h2]);
-            sdw = __builtin_elementwise_fma(gv, dyp[h2], sdw);
+            dpp[h2] = dv[h2] * (w2p * dyp[h2]);
+            sdw = __builtin_elementwise_fma(gv[h2], dyp[h2], sdw);
             sdb = sdb + dpp[h2];
           }
           put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dpp[0][0], dpp[0][1], dpp[1][0], dpp[1][1]), sd);
