@@ -43,7 +43,7 @@ static void run(int B, int W, int K2, int reps) {
   if (LIFT) { a.lw = dev(lw); a.lb = dev(lb); a.CL = CL; }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int ncu = prop.multiProcessorCount;
-  const size_t lds_old = blk_fwd_t_lds_bytes(C, W, K2, NJ, true, EPI != 0), lds_new = blk_fwd_s_lds_bytes(K2, EPI != 0);
+  const size_t lds_old = blk_fwd_t_lds_bytes(C, W, K2, NJ, true, EPI != 0), lds_new = blk_fwd_s_lds_bytes(K2, EPI != 0) + (getenv("LDSPAD") ? atoi(getenv("LDSPAD")) : 0);      // (LDSPAD: occupancy experiment)
   auto kold = k_blk_fwd_t<C, LIFT, false, AIN, EPI, false, 1, 2>;
   auto knew = k_blk_fwd_s<AIN, EPI, LIFT>;
   CK(hipFuncSetAttribute((const void*)kold, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
