@@ -247,9 +247,13 @@ FNO_DEV void gelu_both_pairs(const f32x2 (&x)[NP], f32x2 (&g)[NP], f32x2 (&dg)[N
   constexpr float ca = 0.3275911f * 0.70710678118654752440f;
   constexpr float cp[5] = {0.5f * 1.061405429f, 0.5f * -1.453152027f, 0.5f * 1.421413741f, 0.5f * -0.284496736f, 0.5f * 0.254829592f};
   f32x2 t[NP], poly[NP], e[NP];
+  // (1 + ca |x| on single lanes: |x| is a source modifier of v_fma_f32 and costs nothing there; the packed form has no such
+  // modifier and spends two v_and_b32 per pair on it)
 #pragma unroll
-  for (int p = 0; p < NP; ++p)
-    t[p] = __builtin_elementwise_fma(f32x2{__builtin_fabsf(x[p][0]), __builtin_fabsf(x[p][1])}, f32x2{ca, ca}, f32x2{1.0f, 1.0f});
+  for (int p = 0; p < NP; ++p) {
+    t[p][0] = __builtin_fmaf(__builtin_fabsf(x[p][0]), ca, 1.0f);
+    t[p][1] = __builtin_fmaf(__builtin_fabsf(x[p][1]), ca, 1.0f);
+  }
 #pragma unroll
   for (int p = 0; p < NP; ++p) e[p] = (x[p] * x[p]) * f32x2{-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f};
 #pragma unroll
@@ -485,6 +489,25 @@ FNO_DEV f32x2 natural_pair(float lo, float hi) {
 #ifndef FNO_SPLIT2_VARIANT
 #define FNO_SPLIT2_VARIANT 0
 #endif
+// low term of the two-term split, l = fp16(v - float(h)) for both halves of a packed h: ONE v_fma_mix{lo,hi}_f16 each
+// (fma(v, 1.0, -h) with h read as fp16 straight from its half of the packed register; the difference is exact in fp32, so the
+// single rounding to fp16 is the one that v_cvt_f32_f16 / v_sub_f32 / v_cvt_f16_f32 make - 2 instructions per pair instead of
+// 4, and the split is paid per element of every GEMM operand.  tools/mix_split_test.hip: bit-identical on 2^23 values incl.
+// the fp16 denormal and overflow ranges, alone and beside another wave's MFMAs).  -DFNO_SPLIT2_MIX=0: the compiler's form.
+#ifndef FNO_SPLIT2_MIX
+#define FNO_SPLIT2_MIX 1
+#endif
+FNO_DEV f16x2 split2_low(f32x2 v, f16x2 h) {
+#if FNO_SPLIT2_MIX
+  unsigned l;
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(v[0]), "v"(v[1]), "v"(hu));
+  return __builtin_bit_cast(f16x2, l);
+#else
+  return __builtin_convertvector(v - __builtin_convertvector(h, f32x2), f16x2);
+#endif
+}
 FNO_DEV void split2x8(const float (&x)[8], float s, f16x8& h, f16x8& l) {
 #if FNO_SPLIT2_VARIANT == 1
 #pragma unroll
@@ -502,7 +525,7 @@ FNO_DEV void split2x8(const float (&x)[8], float s, f16x8& h, f16x8& l) {
 #if FNO_SPLIT2_VARIANT == 0
     const f32x2 v = natural_pair(x[j], x[j + 1]) * f32x2{s, s};
     const f16x2 hh = __builtin_convertvector(v, f16x2);
-    const f16x2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x2), f16x2);
+    const f16x2 ll = split2_low(v, hh);
 #else
     const f32x2 ss = {s, s};
     f32x2 xin = {x[j + 1], x[j]}, v;

@@ -54,8 +54,7 @@ FNO_DEV void put_split4_n(unsigned char* img, int term_bytes, int off, const flo
   else {
     const f32x2 v0 = f32x2{t.x, t.y} * f32x2{scale, scale}, v1 = f32x2{t.z, t.w} * f32x2{scale, scale};
     const f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
-    const f16x2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2), f16x2);
-    const f16x2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2), f16x2);
+    const f16x2 l0 = split2_low(v0, h0), l1 = split2_low(v1, h1);      // (one mixed-precision FMA per element: fno_dev.h)
     *reinterpret_cast<uint2*>(img + off) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
     *reinterpret_cast<uint2*>(img + term_bytes + off) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
   }

@@ -179,8 +179,8 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
     *reinterpret_cast<bf16x8*>(wimg + (((mt * KB + kb) * 2 + 0) * 64 + ln) * 16) = f[0];
     *reinterpret_cast<bf16x8*>(wimg + (((mt * KB + kb) * 2 + 1) * 64 + ln) * 16) = f[1];
   }
-  // forward-table fragments of this wave's strip position (B operand of the row DFT: k <-> pixel as the transposed accumulators
-  // hold them, column kk = l31 = 2 k2 + (re, im)), two fp16 terms scaled by the wave's own maximum
+  // forward-table fragments of this wave's strip position (A operand of the row DFT: k <-> pixel as the transposed accumulators
+  // hold them, row kk = l31 = 2 k2 + (re, im)), two fp16 terms scaled by the wave's own maximum
   bf16x8 tff[2][2];
   float st = 1.f;
   if constexpr (EPI != 0) {
@@ -397,16 +397,24 @@ __global__ void __launch_bounds__(256, 2) k_blk_fwd_s(PwFwdArgs a) {
           split_n_x8<2>(v, sg, gf);
           const f16x8 g0 = __builtin_bit_cast(f16x8, gf[0]), g1 = __builtin_bit_cast(f16x8, gf[1]);
           const f16x8 t0 = __builtin_bit_cast(f16x8, tff[kbd][0]), t1 = __builtin_bit_cast(f16x8, tff[kbd][1]);
-          lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(g1, t0, lo, 0, 0, 0);
-          lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(g0, t1, lo, 0, 0, 0);
-          hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(g0, t0, hi, 0, 0, 0);
+          // (the table rides on the A side: D[row = kk][col = channel] - every lane holds a channel, and only the registers whose
+          // rows are kept outputs are summed, scaled and written, as (re, im) pairs: 8 + 8 + 4 instructions per half at <= 8 kept
+          // bins where the other orientation spent 16 + 16 + 16 in 12 of its 32 lanes)
+          lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(t0, g1, lo, 0, 0, 0);
+          lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(t1, g0, lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(t0, g0, hi, 0, 0, 0);
         }
-        // D[row = channel][col = kk = l31]: kk = 2 k2 + (re, im)
-        if (l31 < 2 * a.K2out) {
+        // D[row kk = (r & 3) + 8 (r >> 2) + 4 half][col = channel mt 32 + l31]: kk = 2 k2 + (re, im); registers 4 q .. 4 q + 3 =
+        // rows 8 q + 4 half .. + 3 = bins 4 q + 2 half, 4 q + 2 half + 1
+        float* pc = pw + (mt * 32 + l31) * 2;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            pw[(l31 >> 1) * 132 + c * 2 + (l31 & 1)] = (hi[r] + lo[r]) * inv_gt;
+        for (int q = 0; q < 4; ++q) {
+          if (8 * q < 2 * a.K2out) {                       // (uniform: whole register quads beyond the kept rows are skipped)
+            const int k2 = 4 * q + 2 * half;
+            if (k2 < a.K2out)
+              *reinterpret_cast<float2*>(pc + k2 * 132) = make_float2((hi[4 * q] + lo[4 * q]) * inv_gt, (hi[4 * q + 1] + lo[4 * q + 1]) * inv_gt);
+            if (k2 + 1 < a.K2out)
+              *reinterpret_cast<float2*>(pc + (k2 + 1) * 132) = make_float2((hi[4 * q + 2] + lo[4 * q + 2]) * inv_gt, (hi[4 * q + 3] + lo[4 * q + 3]) * inv_gt);
           }
         }
       }

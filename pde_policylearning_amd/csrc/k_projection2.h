@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(256) k_absmax3_pack_w1(const float* __restrict
 // a chunk's dW1 (two 32 x 32 tiles) is split over the owner group's four waves by pixel halves (added through LDS at the end).
 // NT3 = 3: three bf16 terms, six products per k block; NT3 = 2: two fp16 terms, three products (fno_dev.h "h2"), operands
 // scaled by powers of two from a.amax = {max |x|, max |dy|, max |W1|, max |w2|} (device scalars)
+#ifndef FNO_PB_SDFOLD
+#define FNO_PB_SDFOLD 1      // 0: the split multiplies by the fp16 scale itself (A/B arm)
+#endif
 template <int C, int HID, bool RELU = false, int NT3 = 3>
 __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   FNO_CLK_ENTRY();
@@ -166,6 +169,8 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int l15 = lane & 15, quad = lane >> 4;
   const int hm = wave >> 2, nt = wave & 3;
+  float gk_six, gk_inf;
+  gelu_consts(gk_six, gk_inf);
   const int n0 = nt * 32;
   const int dmt = nt >> 1, dnt = MT == 2 ? (nt & 1) : 0;   // dW1 tile of an owner wave: hidden 32-block, channel 32-block
   const int dkh = MT == 2 ? 0 : (nt & 1);                   // C = 32: pixel half of the tile's K range
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     sa = h2_scale(*a.xmax); sw = h2_scale(a.amax[2]);
     sd = h2_scale(1.13f * a.amax[3] * a.amax[1]);         // |gelu'| <= 1.13 (ReLU: 1)
   }
-  const float inv_aw = 1.f / (sa * sw), inv_dw = 1.f / (sd * sw), inv_da = 1.f / (sd * sa);
+  const float inv_aw = 1.f / (sa * sw), inv_dw = 1.f / (sd * sw), inv_da = 1.f / (sd * sa), inv_sd = 1.f / sd;
   f32x16 dw1acc[CPW];
 #pragma unroll
   for (int k = 0; k < CPW; ++k)
@@ -252,7 +257,7 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
     for (int i = 0; i < XI; ++i) {
       const int c = (tid >> 5) + 16 * i, q = tid & 31;
       float4 t = xq[i];
-      if (a.act_in) { t.x = gelu_f(t.x); t.y = gelu_f(t.y); t.z = gelu_f(t.z); t.w = gelu_f(t.w); }
+      if (a.act_in) t = gelu4(t, gk_six, gk_inf);      // (on pairs: every wave is in this phase together, nobody's matrix products to hide behind)
       put_split4_n<NT3>(aimg, ATERM, swz_off(c, q >> 1) + 8 * (q & 1), t, sa);
     }
     if (tid < NPX) douts[tid] = a.dy[(size_t)b * a.PW + px0 + tid];
@@ -300,7 +305,10 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
       {
         f32x2 sdb = {0.f, 0.f}, sdw = {0.f, 0.f};      // even / odd pixels; added at the end of the chunk
         const int hrow = hm * 32 + l31;
-        const f32x2 b1p = {b1v, b1v}, w2p = {w2v, w2v};
+        // w2 carries the fp16 scale of dP1 (a power of two: every product below is the unscaled one times sd, bit for bit),
+        // so the split needs no multiply of its own; the bias-gradient sum is unscaled once per chunk
+        const float w2s = FNO_PB_SDFOLD ? w2v * sd : w2v;
+        const f32x2 b1p = {b1v, b1v}, w2p = {w2s, w2s};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float4 dy4 = ld4(douts + n0 + 8 * i + 4 * half);
@@ -321,11 +329,11 @@ __global__ void __launch_bounds__(512, 2) k_proj_bwd_t(ProjBwdArgs a) {
             sdw = __builtin_elementwise_fma(gv[h2], dyp[h2], sdw);
             sdb = sdb + dpp[h2];
           }
-          put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dpp[0][0], dpp[0][1], dpp[1][0], dpp[1][1]), sd);
+          put_split4_n<NT3>(dr, DTERM, swz_off(hrow, (n0 >> 3) + i) + 8 * half, make_float4(dpp[0][0], dpp[0][1], dpp[1][0], dpp[1][1]), FNO_PB_SDFOLD ? 1.f : sd);
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
-          if (k == ch) { sdb1[k] += sdb[0] + sdb[1]; sdw2[k] += sdw[0] + sdw[1]; }
+          if (k == ch) { sdb1[k] += (sdb[0] + sdb[1]) * (FNO_PB_SDFOLD ? inv_sd : 1.f); sdw2[k] += sdw[0] + sdw[1]; }
       }
       if (ch == 1) FNO_STAMP(tslot + 5);
       __syncthreads();         // dr[ch & 1] is complete; every reader of dr[(ch + 1) & 1] (chunk ch - 1) is done
