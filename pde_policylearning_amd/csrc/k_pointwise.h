@@ -408,9 +408,18 @@ __global__ void __launch_bounds__((C / 32) * (NPX / 32 / NTW) * 64, FNO_OCC_PWX)
           for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(acc[q][r]));
         }
         if (a.x1) {
-          if (a.act_out) {
+          if (a.act_out) {      // (on pairs, fno_dev.h: the same values in half the instructions)
+            float six, inf;
+            gelu_consts(six, inf);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = gelu_f(acc[q][r]);
+            for (int h8 = 0; h8 < 2; ++h8) {
+              float t[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) t[j] = acc[q][8 * h8 + j];
+              gelu8(t, six, inf);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) xp[((j & 3) + 8 * (2 * h8 + (j >> 2))) * PITCH] = t[j];
+            }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) xp[((r & 3) + 8 * (r >> 2)) * PITCH] = acc[q][r];
