@@ -8,7 +8,7 @@ float64 on float64 copies of the same float32 numbers; tolerance 1e-5 relative L
 gradients within the budget of tests/test_parity_gpu.py (1e-5, or BUDGET_SLACK x the float32 oracle's own distance from
 float64 where that is larger).  Outputs are held to plain 1e-5 wherever the float32 oracle itself is under 5e-6; every case
 appends its achieved numbers (engine / float32 oracle against float64, per tensor) to gpurun_out/hostile_errors.txt - the
-committed table is profiles/r05_hostile_errors.txt."""
+committed table is profiles/r06_hostile_errors.txt (round 5: r05_hostile_errors.txt)."""
 import os
 import numpy as np
 import pytest
