@@ -325,3 +325,25 @@ def test_corner_weight_of_the_wrong_extent_is_an_error_not_a_fault(dev):
     assert torch.isfinite(F.fno_blocks(x, skip, good, bias, modes, "ortho")).all()
     with pytest.raises(RuntimeError, match="spectral weight"):
         F.fno_blocks(x, skip, small, bias, modes, "ortho")
+
+
+def test_split2_low_mixed_precision_fma_is_bit_identical(tmp_path):
+    """fno_dev.h::split2_low forms the low term of every two-term fp16 split with v_fma_mixlo_f16 / v_fma_mixhi_f16 (hipcc does
+    not select them by itself).  tools/mix_split_test.hip compares it bit for bit with the compiler's form (v_cvt_f32_f16,
+    v_sub_f32, v_cvt_pk_f16_f32) on 2^23 values over the fp16 denormal .. overflow range and on 2.6e9 pairs in tester waves whose
+    SIMD partners issue MFMAs back to back (where the packed-fp32 op_sel forms of round 4 misread); exit code = mismatches."""
+    import os
+    import shutil
+    import subprocess
+    from pde_policylearning_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = build.hipcc_path()
+    assert hipcc and (os.path.exists(hipcc) or shutil.which(hipcc)), "hipcc is part of the image"
+    exe = str(tmp_path / "mix_split_test.bin")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Wno-unused-value",
+                        "-Wno-unused-result", "-o", exe, os.path.join(root, "tools", "mix_split_test.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "alone: 4194304 pairs, 0 different" in r.stdout and ", 0 different" in r.stdout.splitlines()[-1], r.stdout
